@@ -1,0 +1,106 @@
+"""One fixed training scenario, runnable against the reference import, the CPU
+oracle and the HIP product alike: closed-form weights, fixed inputs, two G+D
+pairs with Lightning's alternation/toggle semantics, recording
+losses, logits, gradients, norm buffers and post-optimizer parameters.
+
+Used by tests/golden/make_golden.py (reference -> fixtures) and by the parity
+tests (oracle / product vs fixtures)."""
+import copy
+
+import numpy as np
+import torch
+
+from helpers import FixedNoise, fill_closed_form, summarize, synthetic_noise, synthetic_real
+
+SIZES = {
+    # name: (features, batch, noise_dim)
+    "tiny": (8, 4, 16),
+    "full": (64, 8, 100),
+}
+STD_EXPTS = ("dc_gan", "wgan", "wgan_gp")
+
+
+def make_inputs(expt, size):
+    feats, bs, zdim = SIZES[size]
+    uniform = expt == "hologan"
+    inp = {}
+    for pair in range(2):
+        inp[f"real_d{pair}"] = synthetic_real(bs, seed=100 + pair)
+        inp[f"real_g{pair}"] = synthetic_real(bs, seed=200 + pair)
+        inp[f"z_d{pair}"] = synthetic_noise(bs, zdim, 300 + pair, uniform)
+        inp[f"z_g{pair}"] = synthetic_noise(bs, zdim, 400 + pair, uniform)
+        g = torch.Generator().manual_seed(500 + pair)
+        inp[f"alpha{pair}"] = torch.rand(bs, 1, 1, 1, generator=g)
+    return inp
+
+
+def _toggle(step, idx):
+    for p in step.discriminator.parameters():
+        p.requires_grad_(idx == 0)
+    for p in step.generator.parameters():
+        p.requires_grad_(idx == 1)
+
+
+def _dump(prefix, named, out, full):
+    for name, t in named:
+        if t is None:
+            continue
+        key = f"{prefix}/{name}"
+        if full:
+            out[key] = t.detach().cpu().numpy().copy()
+        else:
+            out[key] = summarize(t)
+
+
+def _buffers(prefix, step, out):
+    for net in ("generator", "discriminator"):
+        for name, b in getattr(step, net).named_buffers():
+            out[f"{prefix}/{net}.{name}"] = b.detach().cpu().numpy().copy()
+
+
+def run_scenario(step, inputs, device="cpu", full=True, set_alpha=None, pairs=2):
+    """``set_alpha(step, alpha)`` installs the GP interpolation coefficients for
+    implementations that accept injection; the reference draws them from the
+    host RNG, so make_golden.py patches torch.rand instead."""
+    dev = torch.device(device)
+    fill_closed_form(step.generator, 1)
+    fill_closed_form(step.discriminator, 2)
+    step.to(dev)
+    opts = step.configure_optimizers()
+    out = {}
+    labels = torch.zeros(len(inputs["real_d0"]), dtype=torch.int64, device=dev)
+
+    probe = copy.deepcopy(step)
+    with torch.no_grad():
+        fake = probe.generator(inputs["z_d0"].to(dev))
+        d_out = probe.discriminator(fake)
+        logit = d_out[0] if isinstance(d_out, tuple) else d_out
+    out["probe/fake"] = fake.cpu().numpy() if full else summarize(fake, 64)
+    out["probe/logits"] = logit.reshape(-1).cpu().numpy()
+    del probe
+
+    for pair in range(pairs):
+        for idx, tag in ((0, "d"), (1, "g")):
+            real = inputs[f"real_{tag}{pair}"].to(dev)
+            step.noise_distn = FixedNoise(inputs[f"z_{tag}{pair}"])
+            if set_alpha is not None:
+                set_alpha(step, inputs[f"alpha{pair}"])
+            _toggle(step, idx)
+            loss = step.training_step((real, labels), 2 * pair + idx, idx)
+            loss.backward()
+            out[f"loss_{tag}{pair}"] = np.float64(loss.item())
+            for k, v in step.logged.items():
+                out[f"log{pair}{tag}/{k}"] = np.float64(float(v))
+            if pair == 0:
+                net = step.discriminator if idx == 0 else step.generator
+                _dump(f"grad_{tag}", ((n, p.grad) for n, p in net.named_parameters()), out, full)
+                other = step.generator if idx == 0 else step.discriminator
+                leaked = [n for n, p in other.named_parameters() if p.grad is not None]
+                assert not leaked, "frozen network received gradients: %s" % leaked[:3]
+                _buffers(f"buf_{tag}", step, out)
+            opt = opts[idx]["optimizer"]
+            opt.step()
+            opt.zero_grad()
+    _dump("final/generator", step.generator.named_parameters(), out, full)
+    _dump("final/discriminator", step.discriminator.named_parameters(), out, full)
+    return out
