@@ -1,0 +1,134 @@
+/* gz_ops.h -- C ABI of libgz_hip.so: the MI355X (gfx950) kernels behind the G+D training step of
+ * ebartrum/lightning_gan_zoo.
+ *
+ * The reference has no FFI of its own: its hot path is torch.nn operator calls made from
+ *   core/models/standard_networks.py:9-93        (DCGAN/WGAN generator + discriminator)
+ *   core/lightning_module.py:104-128,158-207     (DCGAN / WGAN / WGANGP training_step)
+ *   core/utils/utils.py:39-58                    (gradient_penalty)
+ * Each entry point below replaces the aten operator(s) named in its comment; the Python side
+ * (lightning_gan_zoo_amd/functional.py) binds them with ctypes and wraps them in
+ * torch.autograd.Function objects (see INTEGRATION.md for the binding a maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers to DEVICE memory, fp32, contiguous NCHW; sizes as int; no torch types.
+ *   - every launcher takes the HIP stream explicitly, never synchronises, never allocates, and is
+ *     re-entrant (autograd runs backward on its own thread).
+ *   - return value: 0 on success, negative error code otherwise (GZ_ERR_*); never throws.
+ *   - workspaces are caller-allocated; *_workspace_bytes / *_elems tell how much.
+ */
+#ifndef GZ_OPS_H
+#define GZ_OPS_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define GZ_ACT_NONE 0
+#define GZ_ACT_RELU 1
+#define GZ_ACT_LRELU 2
+#define GZ_ACT_TANH 3
+
+/* ---- convolution family -------------------------------------------------------------------
+ * Geometry names: x [N,C,H,W] is the image side, y [N,K,OH,OW] the feature side,
+ * w [K,C,KH,KW] the Conv2d weight (a ConvTranspose2d weight [Cin,Cout,KH,KW] is the same array
+ * with K = Cin, C = Cout).  Supported (KH,KW,S,P): (4,4,2,1) (5,5,2,2) (3,3,1,1) (1,1,1,0).
+ */
+
+/* packed-weight sizes in floats */
+long long gz_conv2d_pack_fwd_elems(int K, int C, int KH, int KW);
+long long gz_conv2d_pack_dgrad_elems(int K, int C, int KH, int KW, int S);
+
+/* w -> [C*KH*KW][round4(K)] GEMM-B image for gz_conv2d_fwd */
+int gz_conv2d_pack_fwd(const float* w, float* wpack, int K, int C, int KH, int KW, hipStream_t stream);
+/* w -> [S*S phases][K*TY*TX][round4(C)] GEMM-B images for gz_conv2d_dgrad */
+int gz_conv2d_pack_dgrad(const float* w, float* wpack, int K, int C, int KH, int KW, int S, int P,
+                         hipStream_t stream);
+
+/* y = act(conv2d(x, w) + bias).  Replaces aten::convolution for nn.Conv2d forward
+ * (standard_networks.py:20-24,36-43) and the input gradient of nn.ConvTranspose2d. */
+int gz_conv2d_fwd(const float* x, const float* wpack, const float* bias, float* y, int N, int C, int H, int W,
+                  int K, int OH, int OW, int KH, int KW, int S, int P, int act, float slope, hipStream_t stream);
+
+/* x = act(conv_transpose2d(y, w) + bias).  Replaces nn.ConvTranspose2d forward
+ * (standard_networks.py:60-73,80-87) and aten::convolution_backward's grad_input for nn.Conv2d. */
+int gz_conv2d_dgrad(const float* y, const float* wpack, const float* bias, float* x, int N, int C, int H, int W,
+                    int K, int OH, int OW, int KH, int KW, int S, int P, int act, float slope,
+                    hipStream_t stream);
+
+/* dw[K,C,KH,KW] = weight gradient.  Replaces aten::convolution_backward's grad_weight. */
+size_t gz_conv2d_wgrad_workspace_bytes(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW);
+int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* workspace, size_t ws_bytes, int N, int C,
+                    int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream);
+
+/* c[M,N] = act(op(a) . op(b) + bias[n]); trans_a: a stored [K][M]; trans_b: b stored [N][K].
+ * Replaces the 1x1 -> 4x4 ConvTranspose2d of the generator's first block (standard_networks.py:60),
+ * its weight gradient, and nn.Linear. */
+int gz_gemm(const float* a, const float* b, const float* bias, float* c, int M, int N, int K, int lda, int ldb,
+            int ldc, int trans_a, int trans_b, int act, float slope, hipStream_t stream);
+
+/* ---- normalisation + activation -------------------------------------------------------------
+ * A tensor [N, C, inner] is N*C rows of `inner` contiguous floats (inner % 4 == 0).
+ * coef layout: 4 arrays of `ncoef` floats (scale, shift, mean, rstd); ncoef = C for per-channel
+ * statistics (BatchNorm), N*C for per-row statistics (InstanceNorm / AdaIN).
+ * workspace: gz_norm_workspace_bytes(N, C) bytes.
+ */
+size_t gz_norm_workspace_bytes(int N, int C);
+int gz_norm_coef_elems(int N, int C, int per_channel);
+
+/* training-mode BatchNorm2d statistics (biased var for normalisation; running stats updated with the
+ * unbiased var and `momentum`; *num_batches_tracked += 1).  Replaces the statistics half of
+ * aten::native_batch_norm for nn.BatchNorm2d (standard_networks.py:44,87). */
+int gz_batchnorm_stats(const float* x, const float* gamma, const float* beta, float* coef, float* running_mean,
+                       float* running_var, long long* num_batches_tracked, void* workspace, int N, int C,
+                       int inner, float eps, float momentum, hipStream_t stream);
+/* eval-mode coefficients from the running statistics */
+int gz_batchnorm_eval_coef(const float* gamma, const float* beta, const float* running_mean,
+                           const float* running_var, float* coef, int C, float eps, hipStream_t stream);
+/* per-row statistics: nn.InstanceNorm2d (standard_networks.py:46; gamma/beta per channel, biased var)
+ * or AdaIN (hologan_generator.py:333-345; gamma/beta per row, unbiased var). */
+int gz_rownorm_stats(const float* x, const float* gamma, const float* beta, float* coef, void* workspace, int N,
+                     int C, int inner, float eps, int affine_per_row, int unbiased, hipStream_t stream);
+/* out = act(x * scale + shift) */
+int gz_norm_act_fwd(const float* x, const float* coef, float* out, int N, int C, int inner, int per_channel,
+                    int act, float slope, hipStream_t stream);
+/* first backward of norm+act: dx (may be NULL), dgamma, dbeta (may be NULL); kbuf: 2*ncoef floats scratch */
+int gz_norm_act_bwd(const float* gout, const float* x, const float* coef, float* dx, float* dgamma, float* dbeta,
+                    void* workspace, float* kbuf, int N, int C, int inner, int per_channel, int affine_per_row,
+                    int act, float slope, hipStream_t stream);
+/* backward of gz_norm_act_bwd's dx (per-row statistics, per-channel affine): given v = dL/d(dx) returns
+ * gg_out = dL/d(gout), gx = dL/dx, ggamma = dL/dgamma (any may be NULL).  This is the InstanceNorm leg of
+ * the gradient-penalty double backward (core/utils/utils.py:48-54 with create_graph=True). */
+int gz_rownorm_act_bwd2(const float* gout, const float* v, const float* x, const float* coef, float* gg_out,
+                        float* gx, float* ggamma, void* workspace, int N, int C, int inner, int act, float slope,
+                        hipStream_t stream);
+/* dx = g * act'(.) with the derivative expressed through the activation OUTPUT (LeakyReLU, ReLU, tanh) */
+int gz_act_bwd(const float* g, const float* out, float* dx, long long count, int act, float slope,
+               hipStream_t stream);
+
+/* ---- row helpers (last discriminator layer, gradient-penalty tail, WGAN clip) -----------------
+ * matrices are [R][L] row-major with L % 4 == 0. */
+/* y[r] = sum_l a[r][l] * b[r][l]   (b_broadcast: b is a single row [L]) */
+int gz_rowdot(const float* a, const float* b, float* y, int R, int L, int b_broadcast, hipStream_t stream);
+/* out[r][:] = s[r] * x[r][:] (+ t[r] * x2[r][:], t = 1 - s when one_minus_s else s2); x_broadcast: x is [L] */
+int gz_rowscale(const float* x, const float* s, const float* x2, const float* s2, float* out, int R, int L,
+                int x_broadcast, int one_minus_s, hipStream_t stream);
+/* out[l] = sum_r g[r] * x[r][l] */
+size_t gz_coldot_workspace_bytes(int R, int L);
+int gz_coldot(const float* g, const float* x, float* out, float* workspace, size_t ws_bytes, int R, int L,
+              hipStream_t stream);
+/* p = clamp(p, lo, hi) in place (core/lightning_module.py:160-162) */
+int gz_clamp_(float* p, long long count, float lo, float hi, hipStream_t stream);
+
+/* library identification: returns the gfx target string the kernels were compiled for */
+const char* gz_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GZ_OPS_H */

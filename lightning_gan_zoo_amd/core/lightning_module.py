@@ -1,0 +1,141 @@
+"""Step classes of the hot path -- DCGAN, WGAN, WGANGP (HOLOGAN: see hologan section) -- with the
+reference's LightningModule surface (core/lightning_module.py:35-237):
+
+    __init__(cfg, logging_dir)
+    training_step(batch, batch_idx, optimizer_idx) -> loss tensor carrying an autograd graph
+    configure_optimizers() -> (dict_D, dict_G) with keys optimizer / lr_scheduler / frequency
+
+The generator / discriminator built from ``cfg`` are the HIP-kernel modules of
+``lightning_gan_zoo_amd.core.models``; the arithmetic of every line below that touches an
+image-sized tensor runs in libgz_hip.so.
+"""
+from abc import abstractmethod
+
+import torch
+
+from .. import functional as F
+from ..config import instantiate
+from ..harness import LightningModule
+from .utils.utils import gradient_penalty
+
+
+class _Identity:
+    def __call__(self, x):
+        return x
+
+
+def _build_transform(cfg):
+    """Resize -> ToTensor -> Normalize (reference :42-47); torchvision is optional here."""
+    try:
+        from torchvision import transforms
+    except Exception:  # noqa: BLE001 - synthetic / tensor datasets need no transform
+        return _Identity()
+    t = cfg.train
+    return transforms.Compose([
+        transforms.Resize((t.img_size, t.img_size)),
+        transforms.ToTensor(),
+        transforms.Normalize(mean=[t.data_mean for _ in range(t.channels_img)],
+                             std=[t.data_std for _ in range(t.channels_img)])])
+
+
+class BaseGAN(LightningModule):
+    def __init__(self, cfg, logging_dir=None):
+        super().__init__()
+        # construction order fixes the host RNG stream: D, then G, then fixed_noise (reference :38-50)
+        self.discriminator = instantiate(cfg.discriminator)
+        self.generator = instantiate(cfg.generator)
+        self.cfg = cfg
+        self.logging_dir = logging_dir
+        self.transform = _build_transform(cfg)
+        self.criterion = instantiate(cfg.train.criterion)
+        self.noise_distn = instantiate(cfg.model.noise_distn)
+        self.fixed_noise = self.noise_distn.sample((8, cfg.model.noise_dim))
+
+    @abstractmethod
+    def training_step(self, batch, batch_idx, optimizer_idx):
+        pass
+
+    def sample_noise(self, n):
+        # drawn on the host generator, then copied to the device (reference :107-108)
+        return self.noise_distn.sample((n, self.cfg.model.noise_dim)).to(self.device)
+
+    def validation_step(self, batch, batch_idx):
+        real, _ = batch
+        return {"real": real}
+
+    def configure_optimizers(self):
+        opt_disc = instantiate(self.cfg.disc_optimiser, self.discriminator.parameters())
+        opt_gen = instantiate(self.cfg.gen_optimiser, self.generator.parameters())
+        scheduler_disc = instantiate(self.cfg.optimisation.lr_scheduler, optimizer=opt_disc)
+        scheduler_gen = instantiate(self.cfg.optimisation.lr_scheduler, optimizer=opt_gen)
+        return ({"optimizer": opt_disc, "lr_scheduler": scheduler_disc,
+                 "frequency": self.cfg.optimisation.disc_freq},
+                {"optimizer": opt_gen, "lr_scheduler": scheduler_gen,
+                 "frequency": self.cfg.optimisation.gen_freq})
+
+
+class DCGAN(BaseGAN):
+    def training_step(self, batch, batch_idx, optimizer_idx):
+        real, _ = batch
+        fake = self.generator(self.sample_noise(len(real)))
+
+        if optimizer_idx == 0:      # discriminator (reference :112-121)
+            disc_real = self.discriminator(real).reshape(-1)
+            loss_disc_real = self.criterion(disc_real, torch.ones_like(disc_real))
+            disc_fake = self.discriminator(fake.detach()).reshape(-1)
+            loss_disc_fake = self.criterion(disc_fake, torch.zeros_like(disc_fake))
+            loss_disc = (loss_disc_real + loss_disc_fake) / 2
+            self.log("train/d_loss", loss_disc)
+            return loss_disc
+
+        if optimizer_idx == 1:      # generator (reference :124-128)
+            output = self.discriminator(fake).reshape(-1)
+            loss_gen = self.criterion(output, torch.ones_like(output))
+            self.log("train/g_loss", loss_gen)
+            return loss_gen
+
+
+class WGAN(BaseGAN):
+    def training_step(self, batch, batch_idx, optimizer_idx):
+        clip = self.cfg.train.weight_clip
+        for p in self.discriminator.parameters():       # every call, both branches (reference :160-162)
+            F.clamp_(p, -clip, clip)
+
+        real, _ = batch
+        fake = self.generator(self.sample_noise(len(real)))
+
+        if optimizer_idx == 0:
+            disc_real = self.discriminator(real).reshape(-1)
+            disc_fake = self.discriminator(fake.detach()).reshape(-1)
+            loss_disc = -(torch.mean(disc_real) - torch.mean(disc_fake))
+            self.log("train/d_loss", loss_disc)
+            return loss_disc
+
+        if optimizer_idx == 1:
+            gen_fake = self.discriminator(fake).reshape(-1)
+            loss_gen = -torch.mean(gen_fake)
+            self.log("train/g_loss", loss_gen)
+            return loss_gen
+
+
+class WGANGP(BaseGAN):
+    gp_alpha = None     # test hook: pin the interpolation coefficients ([N,1,1,1])
+
+    def training_step(self, batch, batch_idx, optimizer_idx):
+        real, _ = batch
+        fake = self.generator(self.sample_noise(len(real)))
+
+        if optimizer_idx == 0:
+            disc_real = self.discriminator(real).reshape(-1)
+            disc_fake = self.discriminator(fake.detach()).reshape(-1)
+            # `fake` is NOT detached here, as in the reference (:195-196)
+            gp = gradient_penalty(self.discriminator, real, fake, device=self.device, alpha=self.gp_alpha)
+            loss_disc = (self.cfg.loss_weight.lambda_gp * gp) - (torch.mean(disc_real) - torch.mean(disc_fake))
+            self.log("train/d_loss", loss_disc)
+            return loss_disc
+
+        if optimizer_idx == 1:
+            gen_fake = self.discriminator(fake).reshape(-1)
+            loss_gen = -torch.mean(gen_fake)
+            self.log("train/g_loss", loss_gen)
+            return loss_gen

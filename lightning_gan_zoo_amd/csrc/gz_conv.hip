@@ -1,0 +1,363 @@
+// C-ABI entry points for the convolution family {F, Dg, Wg} and the plain GEMM,
+// all on the fp32 MFMA implicit-GEMM core (gz_igemm.h).
+//
+//   F  : y  = conv(x, w)                 Conv2d forward; ConvTranspose2d input-gradient
+//   Dg : x  = conv_transpose(y, w)       Conv2d input-gradient; ConvTranspose2d forward
+//   Wg : dw = sum_pixels y (x) patch(x)  weight gradient of either
+//
+// Each one's two partial derivatives are the other two with arguments permuted
+// (SURVEY.md appendix C), so these three close the gradient-penalty double backward.
+// Replaces, for the hot path, the aten ops behind torch.nn.Conv2d / ConvTranspose2d at
+// reference core/models/standard_networks.py:20-24,36-43,60-73,80-87.
+#include "gz_igemm.h"
+#include "../../include/gz_ops.h"
+
+namespace gz {
+
+using Cfg128x128 = TileCfg<2, 2, 2, 2>;
+using Cfg128x64 = TileCfg<2, 2, 2, 1>;
+using Cfg128x32 = TileCfg<4, 1, 1, 1>;
+using Cfg64x64 = TileCfg<2, 2, 1, 1>;
+
+enum TileId { T128x128 = 0, T128x64 = 1, T128x32 = 2, T64x64 = 3 };
+
+static int g_force_tile = -2;
+
+static int forced_tile() {
+    if (g_force_tile == -2) {
+        const char* e = getenv("GZ_TILE");
+        g_force_tile = e ? atoi(e) : -1;
+    }
+    return g_force_tile;
+}
+
+// Tile choice: the chip has 256 CUs and a workgroup keeps one CU's matrix pipes busy, so prefer the
+// largest tile that still yields >= ~1 workgroup per CU; narrow N gets narrow tiles.
+static TileId pick_tile(long long M, long long N, int ny) {
+    int f = forced_tile();
+    if (f >= 0 && f <= 3) {
+        if (!(f == T128x128 && N <= 64) ) return (TileId)f;
+    }
+    if (N <= 32) return T128x32;
+    auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * ny; };
+    if (N <= 64) return tiles(128, 64) >= 256 ? T128x64 : T64x64;
+    if (tiles(128, 128) >= 256) return T128x128;
+    if (tiles(128, 64) >= 256) return T128x64;
+    return T64x64;
+}
+
+// ---------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------
+// dst[c][ld] (c < COLS) = src[r][c] transposed: dst[c*ld + r] = src[r*COLS + c]; zero for r in [R, ld)
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ src,
+                                                            float* __restrict__ dst, int R, int COLS, int ld) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < R && c < COLS) ? src[(long long)r * COLS + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < COLS && r < ld) dst[(long long)c * ld + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+// dgrad pack: wp[phase][(ko, ty, tx)][ldc] = w[ko][c][ky][kx], ky = ((py+P)%S) + S*ty (0 if >= KH)
+__global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                                         int K, int C, int KH, int KW, int S, int P, int TY,
+                                                         int TX, int ldc) {
+    const int ko = blockIdx.x;
+    const int phase = blockIdx.y;
+    const int py = phase / S, px = phase % S;
+    const int ry = (py + P) % S, rx = (px + P) % S;
+    const int taps = TY * TX;
+    const long long phase_stride = (long long)K * taps * ldc;
+    for (int i = threadIdx.x; i < taps * ldc; i += blockDim.x) {
+        int tap = i / ldc, c = i - tap * ldc;
+        int ky = ry + S * (tap / TX), kx = rx + S * (tap % TX);
+        float v = 0.f;
+        if (c < C && ky < KH && kx < KW) v = w[(((long long)ko * C + c) * KH + ky) * KW + kx];
+        wp[phase * phase_stride + ((long long)ko * taps + tap) * ldc + c] = v;
+    }
+}
+
+// out[i] = sum_s slab[s][i]
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                           int S, long long count) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += slab[(long long)s * count + i];
+    out[i] = acc;
+}
+
+static inline int round4(int v) { return (v + 3) & ~3; }
+
+template <int KH, int KW, int S, int P>
+struct Geo {
+    static constexpr int kh = KH, kw = KW, s = S, p = P;
+};
+
+static bool shape_ok(const ConvShape& s, int KH, int KW, int S, int P) {
+    if (s.N <= 0 || s.C <= 0 || s.K <= 0 || s.H <= 0 || s.W <= 0) return false;
+    if (s.OH != (s.H + 2 * P - KH) / S + 1 || s.OW != (s.W + 2 * P - KW) / S + 1) return false;
+    return true;
+}
+
+static bool too_large(long long elems) { return elems * 4 >= (1ll << 31); }
+
+// ---------------------------------------------------------------------------
+// F
+// ---------------------------------------------------------------------------
+template <class G, class Cfg>
+static int run_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvShape& s, int act,
+                   float slope, hipStream_t st) {
+    using AL = ConvFwdALoader<Cfg::BM, G::kh, G::kw, G::s, G::p>;
+    using BL = MContigLoader4<Cfg::BN>;
+    typename AL::Params pa{x, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW)};
+    int Kg = s.C * G::kh * G::kw;
+    typename BL::Params pb{wp, Kg, round4(s.K), round4(s.K), 0};
+    int M = s.N * s.OH * s.OW;
+    EpiNCHW::Params pe{y, M, s.K, s.OH * s.OW, make_fastdiv(s.OH * s.OW), bias, act, slope};
+    return launch_igemm<Cfg, AL, BL, EpiNCHW>(pa, pb, pe, M, s.K, Kg, 1, 1, st);
+}
+
+template <class G>
+static int dispatch_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvShape& s,
+                        int act, float slope, hipStream_t st) {
+    long long M = (long long)s.N * s.OH * s.OW;
+    switch (pick_tile(M, s.K, 1)) {
+        case T128x128: return run_fwd<G, Cfg128x128>(x, wp, bias, y, s, act, slope, st);
+        case T128x64: return run_fwd<G, Cfg128x64>(x, wp, bias, y, s, act, slope, st);
+        case T128x32: return run_fwd<G, Cfg128x32>(x, wp, bias, y, s, act, slope, st);
+        default: return run_fwd<G, Cfg64x64>(x, wp, bias, y, s, act, slope, st);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Dg
+// ---------------------------------------------------------------------------
+template <class G, class Cfg>
+static int run_dgrad(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s, int act,
+                     float slope, hipStream_t st) {
+    using AL = ConvDgALoader<Cfg::BM, G::kh, G::kw, G::s, G::p>;
+    using BL = MContigLoader4<Cfg::BN>;
+    using Epi = EpiPhase<G::s>;
+    const int AH = s.H / G::s, AW = s.W / G::s;
+    typename AL::Params pa{y, s, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW)};
+    int Kg = s.K * AL::TAPS;
+    int ldc = round4(s.C);
+    typename BL::Params pb{wp, Kg, ldc, ldc, (long long)Kg * ldc};
+    int M = s.N * AH * AW;
+    typename Epi::Params pe{x, M, s.C, s.H, s.W, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW), bias, act, slope};
+    return launch_igemm<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kg, G::s * G::s, 1, st);
+}
+
+template <class G>
+static int dispatch_dgrad(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s,
+                          int act, float slope, hipStream_t st) {
+    if (s.H % G::s || s.W % G::s) return GZ_ERR_UNSUPPORTED;
+    long long M = (long long)s.N * (s.H / G::s) * (s.W / G::s);
+    switch (pick_tile(M, s.C, G::s * G::s)) {
+        case T128x128: return run_dgrad<G, Cfg128x128>(y, wp, bias, x, s, act, slope, st);
+        case T128x64: return run_dgrad<G, Cfg128x64>(y, wp, bias, x, s, act, slope, st);
+        case T128x32: return run_dgrad<G, Cfg128x32>(y, wp, bias, x, s, act, slope, st);
+        default: return run_dgrad<G, Cfg64x64>(y, wp, bias, x, s, act, slope, st);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Wg
+// ---------------------------------------------------------------------------
+static int wgrad_splits(long long tiles, int chunks) {
+    if (tiles >= 256) return 1;
+    long long want = (512 + tiles - 1) / tiles;       // aim at ~2 workgroups per CU
+    long long cap = chunks / 8 > 0 ? chunks / 8 : 1;  // keep >= 8 chunks (128 pixels) per split
+    long long s = want < cap ? want : cap;
+    return (int)(s < 1 ? 1 : s);
+}
+
+template <class G, class Cfg>
+static int run_wgrad(const float* x, const float* y, float* dw, float* ws, size_t ws_bytes, const ConvShape& s,
+                     hipStream_t st) {
+    using AL = WgALoader<Cfg::BM>;
+    using BL = WgBLoader<Cfg::BN, G::kh, G::kw, G::s, G::p>;
+    const int KTOT = s.N * s.OH * s.OW;
+    const int NTOT = s.C * G::kh * G::kw;
+    typename AL::Params pa{y, s, make_fastdiv(s.OH * s.OW), KTOT};
+    typename BL::Params pb{x, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW), KTOT, NTOT};
+    long long tiles = (long long)((s.K + Cfg::BM - 1) / Cfg::BM) * ((NTOT + Cfg::BN - 1) / Cfg::BN);
+    int chunks = (KTOT + BK - 1) / BK;
+    int splits = wgrad_splits(tiles, chunks);
+    long long count = (long long)s.K * NTOT;
+    if (splits > 1) {
+        long long max_splits = (long long)(ws_bytes / 4) / count;
+        if (max_splits < 2) splits = 1;
+        else if (splits > max_splits) splits = (int)max_splits;
+    }
+    // recompute the real number of z-slices launch_igemm will use
+    int cps = (chunks + splits - 1) / splits;
+    int nz = (chunks + cps - 1) / cps;
+    float* out = nz > 1 ? ws : dw;
+    EpiRowMajor::Params pe{out, s.K, NTOT, NTOT, count, nullptr, ACT_NONE, 0.f};
+    int rc = launch_igemm<Cfg, AL, BL, EpiRowMajor>(pa, pb, pe, s.K, NTOT, KTOT, 1, splits, st);
+    if (rc != GZ_OK) return rc;
+    if (nz > 1) {
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws, dw, nz,
+                           count);
+        rc = launch_status();
+    }
+    return rc;
+}
+
+template <class G>
+static int dispatch_wgrad(const float* x, const float* y, float* dw, float* ws, size_t ws_bytes,
+                          const ConvShape& s, hipStream_t st) {
+    long long NTOT = (long long)s.C * G::kh * G::kw;
+    TileId t;
+    if (NTOT <= 32) t = T128x32;
+    else if (NTOT <= 64 || s.K <= 64) t = (s.K <= 64 ? T64x64 : T128x64);
+    else t = T128x128;
+    int f = forced_tile();
+    if (f >= 0 && f <= 3 && !(f == T128x128 && NTOT <= 64)) t = (TileId)f;
+    switch (t) {
+        case T128x128: return run_wgrad<G, Cfg128x128>(x, y, dw, ws, ws_bytes, s, st);
+        case T128x64: return run_wgrad<G, Cfg128x64>(x, y, dw, ws, ws_bytes, s, st);
+        case T128x32: return run_wgrad<G, Cfg128x32>(x, y, dw, ws, ws_bytes, s, st);
+        default: return run_wgrad<G, Cfg64x64>(x, y, dw, ws, ws_bytes, s, st);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// plain GEMM  C[M][N] = op(A) . op(B)  (+bias[n], activation)
+// ---------------------------------------------------------------------------
+template <class Cfg, class AL, class BL>
+static int run_gemm(const float* a, const float* b, const float* bias, float* c, int M, int N, int K, int lda,
+                    int ldb, int ldc, int act, float slope, hipStream_t st) {
+    typename AL::Params pa{a, K, M, lda, 0};
+    typename BL::Params pb{b, K, N, ldb, 0};
+    EpiRowMajor::Params pe{c, M, N, ldc, 0, bias, act, slope};
+    return launch_igemm<Cfg, AL, BL, EpiRowMajor>(pa, pb, pe, M, N, K, 1, 1, st);
+}
+
+template <class Cfg>
+static int gemm_ops(const float* a, const float* b, const float* bias, float* c, int M, int N, int K, int lda,
+                    int ldb, int ldc, int ta, int tb, int act, float slope, hipStream_t st) {
+    // ta == 0: A is [M][K] row-major (k contiguous);  ta == 1: A is stored [K][M] (m contiguous)
+    // tb == 0: B is [K][N] row-major (n contiguous);  tb == 1: B is stored [N][K] (k contiguous)
+    const bool b_vec = !tb && (ldb % 4 == 0) && (N % 4 == 0) && (((uintptr_t)b & 15) == 0);
+    if (!ta && !tb) {
+        if (b_vec) return run_gemm<Cfg, KContigLoader<Cfg::BM>, MContigLoader4<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st);
+        return run_gemm<Cfg, KContigLoader<Cfg::BM>, MContigLoader<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st);
+    }
+    if (ta && !tb) {
+        if (b_vec) return run_gemm<Cfg, MContigLoader<Cfg::BM>, MContigLoader4<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st);
+        return run_gemm<Cfg, MContigLoader<Cfg::BM>, MContigLoader<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st);
+    }
+    if (!ta && tb) return run_gemm<Cfg, KContigLoader<Cfg::BM>, KContigLoader<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st);
+    return run_gemm<Cfg, MContigLoader<Cfg::BM>, KContigLoader<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st);
+}
+
+}  // namespace gz
+
+using namespace gz;
+
+typedef Geo<4, 4, 2, 1> G4421;
+typedef Geo<5, 5, 2, 2> G5522;
+typedef Geo<3, 3, 1, 1> G3311;
+typedef Geo<1, 1, 1, 0> G1110;
+
+#define GZ_GEOM_DISPATCH(CALL)                                          \
+    if (KH == 4 && KW == 4 && S == 2 && P == 1) return CALL(G4421);     \
+    if (KH == 5 && KW == 5 && S == 2 && P == 2) return CALL(G5522);     \
+    if (KH == 3 && KW == 3 && S == 1 && P == 1) return CALL(G3311);     \
+    if (KH == 1 && KW == 1 && S == 1 && P == 0) return CALL(G1110);     \
+    return GZ_ERR_UNSUPPORTED;
+
+extern "C" {
+
+long long gz_conv2d_pack_fwd_elems(int K, int C, int KH, int KW) { return (long long)C * KH * KW * round4(K); }
+
+long long gz_conv2d_pack_dgrad_elems(int K, int C, int KH, int KW, int S) {
+    int TY = (KH + S - 1) / S, TX = (KW + S - 1) / S;
+    return (long long)S * S * K * TY * TX * round4(C);
+}
+
+int gz_conv2d_pack_fwd(const float* w, float* wp, int K, int C, int KH, int KW, hipStream_t stream) {
+    if (K <= 0 || C <= 0 || KH <= 0 || KW <= 0) return GZ_ERR_BAD_SHAPE;
+    int Kg = C * KH * KW, ld = round4(K);
+    dim3 grid((Kg + 31) / 32, (ld + 31) / 32);
+    hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, stream, w, wp, K, Kg, ld);
+    return launch_status();
+}
+
+int gz_conv2d_pack_dgrad(const float* w, float* wp, int K, int C, int KH, int KW, int S, int P,
+                         hipStream_t stream) {
+    if (K <= 0 || C <= 0 || KH <= 0 || KW <= 0 || S <= 0) return GZ_ERR_BAD_SHAPE;
+    int TY = (KH + S - 1) / S, TX = (KW + S - 1) / S;
+    hipLaunchKernelGGL(pack_dgrad_kernel, dim3(K, S * S), dim3(256), 0, stream, w, wp, K, C, KH, KW, S, P, TY, TX,
+                       round4(C));
+    return launch_status();
+}
+
+int gz_conv2d_fwd(const float* x, const float* wpack, const float* bias, float* y, int N, int C, int H, int W,
+                  int K, int OH, int OW, int KH, int KW, int S, int P, int act, float slope, hipStream_t stream) {
+    ConvShape s{N, C, H, W, K, OH, OW};
+    if (!shape_ok(s, KH, KW, S, P)) return GZ_ERR_BAD_SHAPE;
+    if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
+    if (((uintptr_t)wpack & 15) || ((uintptr_t)y & 15)) return GZ_ERR_BAD_SHAPE;
+#define CALL(G) dispatch_fwd<G>(x, wpack, bias, y, s, act, slope, stream)
+    GZ_GEOM_DISPATCH(CALL)
+#undef CALL
+}
+
+int gz_conv2d_dgrad(const float* y, const float* wpack, const float* bias, float* x, int N, int C, int H, int W,
+                    int K, int OH, int OW, int KH, int KW, int S, int P, int act, float slope,
+                    hipStream_t stream) {
+    ConvShape s{N, C, H, W, K, OH, OW};
+    if (!shape_ok(s, KH, KW, S, P)) return GZ_ERR_BAD_SHAPE;
+    if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
+    if ((uintptr_t)wpack & 15) return GZ_ERR_BAD_SHAPE;
+#define CALL(G) dispatch_dgrad<G>(y, wpack, bias, x, s, act, slope, stream)
+    GZ_GEOM_DISPATCH(CALL)
+#undef CALL
+}
+
+size_t gz_conv2d_wgrad_workspace_bytes(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW) {
+    long long count = (long long)K * C * KH * KW;
+    int chunks = (N * OH * OW + BK - 1) / BK;
+    // upper bound over the tile choices: smallest tile count is with 128x128 tiles
+    long long tiles = (long long)((K + 127) / 128) * ((C * KH * KW + 127) / 128);
+    int splits = wgrad_splits(tiles, chunks);
+    return splits > 1 ? (size_t)splits * count * 4 : 0;
+}
+
+int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* workspace, size_t ws_bytes, int N, int C,
+                    int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream) {
+    ConvShape s{N, C, H, W, K, OH, OW};
+    if (!shape_ok(s, KH, KW, S, P)) return GZ_ERR_BAD_SHAPE;
+    if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
+#define CALL(G) dispatch_wgrad<G>(x, y, dw, workspace, ws_bytes, s, stream)
+    GZ_GEOM_DISPATCH(CALL)
+#undef CALL
+}
+
+int gz_gemm(const float* a, const float* b, const float* bias, float* c, int M, int N, int K, int lda, int ldb,
+            int ldc, int trans_a, int trans_b, int act, float slope, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return GZ_ERR_BAD_SHAPE;
+    if (too_large((long long)M * K) || too_large((long long)K * N) || too_large((long long)M * N)) return GZ_ERR_TOO_LARGE;
+    switch (pick_tile(M, N, 1)) {
+        case T128x128: return gemm_ops<Cfg128x128>(a, b, bias, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, slope, stream);
+        case T128x64: return gemm_ops<Cfg128x64>(a, b, bias, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, slope, stream);
+        case T128x32: return gemm_ops<Cfg128x32>(a, b, bias, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, slope, stream);
+        default: return gemm_ops<Cfg64x64>(a, b, bias, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, slope, stream);
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,691 @@
+// fp32 implicit-GEMM core for gfx950: v_mfma_f32_32x32x2_f32 tiles fed from LDS.
+//
+//   C[m][n] = sum_k A[m][k] * B[k][n]
+//
+// One 256-thread workgroup (4 wavefronts of 64) owns a BM x BN tile of C.  K is
+// walked in chunks of BK=16.  Both operands live in LDS as [k][mn] images with
+// the M/N index contiguous: lane l of a wave feeds the MFMA with
+//   A[m = l&31][k = l>>5]   and   B[k = l>>5][n = l&31]
+// (one dword each), so a fragment read is a conflict-free ds_read_b32 of 32
+// consecutive words per half-wave and NCHW's pixel-contiguity maps straight onto
+// the M (forward / dgrad) or K (wgrad) axis without any transposition in HBM.
+//
+// Staging is global -> VGPR -> LDS, software pipelined over two LDS buffers: the
+// loads of chunk t+1 are issued before the MFMAs of chunk t and written to the
+// other buffer after them; one barrier per chunk.  Loads are raw buffer loads:
+// out-of-image taps / tails get a voffset >= num_records and read as 0 without
+// a branch.  fp32-input MFMA runs at 256 FLOP/clk/CU (= 157 TF peak), i.e. a
+// 128x128x16 chunk takes 2048 clk/CU, which leaves the memory pipeline ~8 B/clk/CU
+// to fill -- the loaders are deliberately simple.
+//
+// "Loader" concept (A or B operand):
+//   struct Params;  static constexpr int LD;        // LDS leading dimension
+//   void init(const Params&, int tile, int y, int tid);
+//   void issue(int chunk);                          // global -> registers
+//   void commit(float* lds);                        // registers -> lds[k*LD + mn]
+// "Epilogue" concept:
+//   struct Params;
+//   void store(const Params&, acc, m_base, n_base, lane, y, z);
+#pragma once
+#include "gz_common.h"
+
+namespace gz {
+
+constexpr int NT = 256;
+constexpr int BK = 16;
+constexpr uint32_t OOB = 0x80000000u;  // voffset that is out of range for every tensor (< 2 GiB)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+template <int WM_, int WN_, int TM_, int TN_>
+struct TileCfg {
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+    static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+};
+
+// ---------------------------------------------------------------------------
+// generic matrix loaders
+// ---------------------------------------------------------------------------
+
+// element (k, mn) at base[k*ld + mn]; mn contiguous; scalar loads.
+template <int BMN>
+struct MContigLoader {
+    struct Params {
+        const float* base;
+        int K, MN, ld;
+        long long batch_stride;  // elements, indexed by blockIdx.y
+    };
+    static constexpr int LD = BMN;
+    static constexpr int EPT = BMN * BK / NT;
+    static constexpr int STEP = NT / BMN;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t col_off;
+    int kb, mn_l, K, ld;
+    bool col_ok;
+    float r[EPT];
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        rsrc = make_rsrc(p.base + (long long)y * p.batch_stride, (uint32_t)p.K * p.ld * 4u);
+        mn_l = tid % BMN;
+        kb = tid / BMN;
+        int mn = tile * BMN + mn_l;
+        col_ok = mn < p.MN;
+        col_off = (uint32_t)mn * 4u;
+        K = p.K;
+        ld = p.ld;
+    }
+    __device__ __forceinline__ void issue(int kc) {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            int k = kc * BK + kb + STEP * j;
+            uint32_t v = (col_ok && k < K) ? (uint32_t)k * (uint32_t)ld * 4u + col_off : OOB;
+            r[j] = bload(rsrc, v, 0);
+        }
+    }
+    __device__ __forceinline__ void commit(float* dst) const {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) dst[(kb + STEP * j) * LD + mn_l] = r[j];
+    }
+};
+
+// same layout, 16-byte loads; requires ld % 4 == 0, MN % 4 == 0 and a 16-byte aligned base.
+template <int BMN>
+struct MContigLoader4 {
+    using Params = typename MContigLoader<BMN>::Params;
+    static constexpr int LD = BMN;
+    static constexpr int C4 = BMN / 4;                 // float4 columns
+    static constexpr int ROWS = NT / C4;               // rows covered per pass
+    static constexpr int PASSES = (BK + ROWS - 1) / ROWS;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t col_off;
+    int kb, c4, K, ld;
+    bool col_ok;
+    f32x4 r[PASSES];
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        rsrc = make_rsrc(p.base + (long long)y * p.batch_stride, (uint32_t)p.K * p.ld * 4u);
+        c4 = tid % C4;
+        kb = tid / C4;
+        int mn = tile * BMN + c4 * 4;
+        col_ok = mn < p.MN;
+        col_off = (uint32_t)mn * 4u;
+        K = p.K;
+        ld = p.ld;
+    }
+    __device__ __forceinline__ void issue(int kc) {
+#pragma unroll
+        for (int j = 0; j < PASSES; ++j) {
+            int kl = kb + ROWS * j;
+            int k = kc * BK + kl;
+            bool ok = col_ok && k < K && kl < BK;
+            uint32_t v = ok ? (uint32_t)k * (uint32_t)ld * 4u + col_off : OOB;
+            r[j] = bload4(rsrc, v, 0);
+        }
+    }
+    __device__ __forceinline__ void commit(float* dst) const {
+#pragma unroll
+        for (int j = 0; j < PASSES; ++j) {
+            int kl = kb + ROWS * j;
+            if (kl < BK) *reinterpret_cast<f32x4*>(dst + kl * LD + c4 * 4) = r[j];
+        }
+    }
+};
+
+// element (mn, k) at base[mn*ld + k]; k contiguous; transposed on the way into LDS.
+// LD = BMN + 2 makes the transposing ds_write_b32 conflict-free: a half-wave
+// holds 16 k x 2 mn and lands on banks (2k + mn) mod 32.
+template <int BMN>
+struct KContigLoader {
+    struct Params {
+        const float* base;
+        int K, MN, ld;
+        long long batch_stride;
+    };
+    static constexpr int LD = BMN + 2;
+    static constexpr int EPT = BMN / 16;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[EPT];
+    int kl, mn_l, K;
+    float r[EPT];
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        rsrc = make_rsrc(p.base + (long long)y * p.batch_stride, (uint32_t)p.MN * p.ld * 4u);
+        kl = tid & 15;
+        mn_l = tid >> 4;
+        K = p.K;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            int mn = tile * BMN + mn_l + 16 * j;
+            voff[j] = mn < p.MN ? ((uint32_t)mn * (uint32_t)p.ld + kl) * 4u : OOB;
+        }
+    }
+    __device__ __forceinline__ void issue(int kc) {
+        bool kok = kc * BK + kl < K;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) r[j] = bload(rsrc, kok ? voff[j] : OOB, (uint32_t)kc * BK * 4u);
+    }
+    __device__ __forceinline__ void commit(float* dst) const {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) dst[kl * LD + mn_l + 16 * j] = r[j];
+    }
+};
+
+// ---------------------------------------------------------------------------
+// convolution geometry
+// ---------------------------------------------------------------------------
+// x: [N, C, H, W]   ("image side": conv input, dgrad output)
+// y: [N, K, OH, OW] ("feature side": conv output, dgrad input)
+// w: [K, C, KH, KW] (Conv2d weight; a ConvTranspose2d weight [Cin_T, Cout_T, KH, KW]
+//                    is the same array with K = Cin_T, C = Cout_T)
+struct ConvShape {
+    int N, C, H, W, K, OH, OW;
+};
+
+// A operand of the forward GEMM: A[m = (n, oy, ox)][k = (c, ky, kx)] = x[n][c][oy*S-P+ky][ox*S-P+kx]
+template <int BM, int KH, int KW, int S, int P>
+struct ConvFwdALoader {
+    struct Params {
+        const float* x;
+        ConvShape s;
+        FastDiv div_ohw, div_ow;
+    };
+    static constexpr int LD = BM;
+    static constexpr int EPT = BM * BK / NT;
+    static constexpr int STEP = NT / BM;
+    static constexpr bool FIXED = (KH * KW == BK);  // a chunk is exactly one input channel
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[FIXED ? EPT : 1];
+    uint32_t nbase;
+    int kb, m_l, iy0, ix0, C, H, W;
+    bool m_ok;
+    float r[EPT];
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        const ConvShape& s = p.s;
+        rsrc = make_rsrc(p.x, (uint32_t)s.N * s.C * s.H * s.W * 4u);
+        m_l = tid % BM;
+        kb = tid / BM;
+        uint32_t m = (uint32_t)tile * BM + m_l;
+        m_ok = m < (uint32_t)s.N * s.OH * s.OW;
+        uint32_t n = fdiv(m, p.div_ohw);
+        uint32_t pix = m - n * (uint32_t)(s.OH * s.OW);
+        uint32_t oy = fdiv(pix, p.div_ow);
+        uint32_t ox = pix - oy * (uint32_t)s.OW;
+        iy0 = (int)oy * S - P;
+        ix0 = (int)ox * S - P;
+        nbase = n * (uint32_t)(s.C * s.H * s.W);
+        C = s.C; H = s.H; W = s.W;
+        if constexpr (FIXED) {
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                int tap = kb + STEP * j;
+                int iy = iy0 + tap / KW, ix = ix0 + tap % KW;
+                bool ok = m_ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                voff[j] = ok ? (nbase + (uint32_t)(iy * W + ix)) * 4u : OOB;
+            }
+        }
+    }
+    __device__ __forceinline__ void issue(int kc) {
+        if constexpr (FIXED) {
+            uint32_t soff = (uint32_t)kc * (uint32_t)(H * W) * 4u;
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) r[j] = bload(rsrc, voff[j], soff);
+        } else {
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                int k = kc * BK + kb + STEP * j;
+                int c = k / (KH * KW);
+                int tap = k - c * (KH * KW);
+                int iy = iy0 + tap / KW, ix = ix0 + tap % KW;
+                bool ok = m_ok && c < C && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                uint32_t v = ok ? (nbase + (uint32_t)((c * H + iy) * W + ix)) * 4u : OOB;
+                r[j] = bload(rsrc, v, 0);
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(float* dst) const {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) dst[(kb + STEP * j) * LD + m_l] = r[j];
+    }
+};
+
+// Transposed convolution / data gradient, decomposed into S*S output phases.
+// Phase (py, px) produces x[n][c][S*a+py][S*b+px]; along each axis it uses the taps
+//   t = 0..T-1 :  ky = ((py + P) % S) + S*t ,  oy = a + (py + P)/S - t
+// (taps with ky >= KH are zero in the packed weights).  Per phase:
+//   A[m = (n, a, b)][k = (ko, ty, tx)] = y[n][ko][a + dy(ty)][b + dx(tx)]
+template <int BM, int KH, int KW, int S, int P>
+struct ConvDgALoader {
+    static constexpr int TY = (KH + S - 1) / S, TX = (KW + S - 1) / S;
+    static constexpr int TAPS = TY * TX;
+    struct Params {
+        const float* y;
+        ConvShape s;
+        int AH, AW;  // phase grid: H/S, W/S
+        FastDiv div_ahw, div_aw;
+    };
+    static constexpr int LD = BM;
+    static constexpr int EPT = BM * BK / NT;
+    static constexpr int STEP = NT / BM;
+    static constexpr bool FIXED = (BK % TAPS == 0);  // a chunk is BK/TAPS whole feature channels
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[FIXED ? EPT : 1];
+    uint32_t nbase;
+    int kb, m_l, oy0, ox0, K, OH, OW;
+    bool m_ok;
+    float r[EPT];
+    __device__ __forceinline__ void init(const Params& p, int tile, int phase, int tid) {
+        const ConvShape& s = p.s;
+        rsrc = make_rsrc(p.y, (uint32_t)s.N * s.K * s.OH * s.OW * 4u);
+        m_l = tid % BM;
+        kb = tid / BM;
+        int py = phase / S, px = phase % S;
+        uint32_t m = (uint32_t)tile * BM + m_l;
+        m_ok = m < (uint32_t)s.N * p.AH * p.AW;
+        uint32_t n = fdiv(m, p.div_ahw);
+        uint32_t pix = m - n * (uint32_t)(p.AH * p.AW);
+        uint32_t a = fdiv(pix, p.div_aw);
+        uint32_t b = pix - a * (uint32_t)p.AW;
+        oy0 = (int)a + (py + P) / S;
+        ox0 = (int)b + (px + P) / S;
+        nbase = n * (uint32_t)(s.K * s.OH * s.OW);
+        K = s.K; OH = s.OH; OW = s.OW;
+        if constexpr (FIXED) {
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                int kk = kb + STEP * j;
+                int kol = kk / TAPS, tap = kk % TAPS;
+                int oy = oy0 - tap / TX, ox = ox0 - tap % TX;
+                bool ok = m_ok && (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
+                voff[j] = ok ? (nbase + (uint32_t)((kol * OH + oy) * OW + ox)) * 4u : OOB;
+            }
+        }
+    }
+    __device__ __forceinline__ void issue(int kc) {
+        if constexpr (FIXED) {
+            uint32_t soff = (uint32_t)kc * (uint32_t)((BK / TAPS) * OH * OW) * 4u;
+            // feature channels past K only occur in a partial last chunk; their weights are zero-padded
+            // but the reads must stay inside the tensor: the soffset is not range checked.
+            int ko_base = kc * (BK / TAPS);
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                int kol = (kb + STEP * j) / TAPS;
+                r[j] = bload(rsrc, ko_base + kol < K ? voff[j] : OOB, soff);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                int k = kc * BK + kb + STEP * j;
+                int ko = k / TAPS;
+                int tap = k - ko * TAPS;
+                int oy = oy0 - tap / TX, ox = ox0 - tap % TX;
+                bool ok = m_ok && ko < K && (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
+                uint32_t v = ok ? (nbase + (uint32_t)((ko * OH + oy) * OW + ox)) * 4u : OOB;
+                r[j] = bload(rsrc, v, 0);
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(float* dst) const {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) dst[(kb + STEP * j) * LD + m_l] = r[j];
+    }
+};
+
+// Weight gradient: dW[ko][(c, ky, kx)] = sum_{p = (n, oy, ox)} y[n][ko][oy][ox] * x[n][c][oy*S-P+ky][ox*S-P+kx]
+// A[m = ko][k = p] : k-contiguous inside one image.
+template <int BM>
+struct WgALoader {
+    struct Params {
+        const float* y;
+        ConvShape s;
+        FastDiv div_ohw;
+        int KTOT;  // N*OH*OW
+    };
+    static constexpr int LD = BM + 2;
+    static constexpr int EPT = BM / 16;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t koff[EPT];
+    int kl, m_l, OHW, KOHW, KTOT;
+    FastDiv div_ohw;
+    float r[EPT];
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        const ConvShape& s = p.s;
+        rsrc = make_rsrc(p.y, (uint32_t)s.N * s.K * s.OH * s.OW * 4u);
+        kl = tid & 15;
+        m_l = tid >> 4;
+        OHW = s.OH * s.OW;
+        KOHW = s.K * OHW;
+        KTOT = p.KTOT;
+        div_ohw = p.div_ohw;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            int ko = tile * BM + m_l + 16 * j;
+            koff[j] = ko < s.K ? (uint32_t)ko * (uint32_t)OHW : OOB;
+        }
+    }
+    __device__ __forceinline__ void issue(int kc) {
+        uint32_t p = (uint32_t)kc * BK + kl;
+        uint32_t n = fdiv(p, div_ohw);
+        uint32_t pix = p - n * (uint32_t)OHW;
+        uint32_t base = n * (uint32_t)KOHW + pix;
+        bool ok = p < (uint32_t)KTOT;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            uint32_t v = (ok && koff[j] != OOB) ? (base + koff[j]) * 4u : OOB;
+            r[j] = bload(rsrc, v, 0);
+        }
+    }
+    __device__ __forceinline__ void commit(float* dst) const {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) dst[kl * LD + m_l + 16 * j] = r[j];
+    }
+};
+
+// B[k = p][n = (c, ky, kx)] = x[n_img][c][oy*S-P+ky][ox*S-P+kx]
+template <int BN, int KH, int KW, int S, int P>
+struct WgBLoader {
+    struct Params {
+        const float* x;
+        ConvShape s;
+        FastDiv div_ohw, div_ow;
+        int KTOT, NTOT;  // N*OH*OW, C*KH*KW
+    };
+    static constexpr int LD = BN + 2;
+    static constexpr int EPT = BN / 16;
+    __amdgpu_buffer_rsrc_t rsrc;
+    int toff[EPT];   // (c*H + ky - P)*W + kx - P, or INT_MIN when the column is out of range
+    int ky_[EPT], kx_[EPT];
+    int kl, n_l, OHW, OW, H, W, CHW, KTOT;
+    FastDiv div_ohw, div_ow;
+    float r[EPT];
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        const ConvShape& s = p.s;
+        rsrc = make_rsrc(p.x, (uint32_t)s.N * s.C * s.H * s.W * 4u);
+        kl = tid & 15;
+        n_l = tid >> 4;
+        OHW = s.OH * s.OW; OW = s.OW; H = s.H; W = s.W; CHW = s.C * s.H * s.W;
+        KTOT = p.KTOT;
+        div_ohw = p.div_ohw; div_ow = p.div_ow;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            int col = tile * BN + n_l + 16 * j;
+            int c = col / (KH * KW);
+            int tap = col - c * (KH * KW);
+            ky_[j] = tap / KW - P;
+            kx_[j] = tap % KW - P;
+            toff[j] = col < p.NTOT ? (c * H + ky_[j]) * W + kx_[j] : INT32_MIN;
+        }
+    }
+    __device__ __forceinline__ void issue(int kc) {
+        uint32_t p = (uint32_t)kc * BK + kl;
+        uint32_t n = fdiv(p, div_ohw);
+        uint32_t pix = p - n * (uint32_t)OHW;
+        uint32_t oy = fdiv(pix, div_ow);
+        uint32_t ox = pix - oy * (uint32_t)OW;
+        int by = (int)oy * S, bx = (int)ox * S;
+        int base = (int)n * CHW + by * W + bx;
+        bool ok = p < (uint32_t)KTOT;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            bool v = ok && toff[j] != INT32_MIN && (unsigned)(by + ky_[j]) < (unsigned)H &&
+                     (unsigned)(bx + kx_[j]) < (unsigned)W;
+            r[j] = bload(rsrc, v ? (uint32_t)(base + toff[j]) * 4u : OOB, 0);
+        }
+    }
+    __device__ __forceinline__ void commit(float* dst) const {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) dst[kl * LD + n_l + 16 * j] = r[j];
+    }
+};
+
+// ---------------------------------------------------------------------------
+// epilogues.  Accumulator map of v_mfma_f32_32x32x2_f32: lane l, register r holds
+//   C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+// ---------------------------------------------------------------------------
+
+// C[z][m][n] row-major (n contiguous): wgrad slabs, plain GEMM.  Optional bias[n] + activation.
+struct EpiRowMajor {
+    struct Params {
+        float* c;
+        int M, N, ldc;
+        long long slab_stride;   // elements between split-K slabs / batches (z and y)
+        const float* bias;       // per column, may be null
+        int act;
+        float slope;
+    };
+    template <int TM, int TN>
+    __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
+                                                 int n_base, int lane, int y, int z) {
+        float* c = p.c + (long long)(z + y) * p.slab_stride;
+        const int col_l = lane & 31, half = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int n = n_base + j * 32 + col_l;
+            if (n >= p.N) continue;
+            float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m < p.M) c[(long long)m * p.ldc + n] = act_fwd(acc[i][j][r] + bv, p.act, p.slope);
+                }
+            }
+        }
+    }
+};
+
+// NCHW feature map: row m = (n, pix), column = channel.  4 consecutive registers are 4
+// consecutive pixels of one channel -> one 16-byte store per lane (needs OHW % 4 == 0,
+// otherwise scalar stores).  Optional bias[channel] + activation.
+struct EpiNCHW {
+    struct Params {
+        float* out;
+        int M, CH, HW;           // M = N*HW rows, CH channels
+        FastDiv div_hw;
+        const float* bias;
+        int act;
+        float slope;
+    };
+    template <int TM, int TN>
+    __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
+                                                 int n_base, int lane, int y, int z) {
+        const int col_l = lane & 31, half = lane >> 5;
+        const bool vec = (p.HW & 3) == 0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int ch = n_base + j * 32 + col_l;
+            if (ch >= p.CH) continue;
+            float bv = p.bias ? p.bias[ch] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int m = m_base + i * 32 + 8 * g + 4 * half;
+                    if (m >= p.M) continue;
+                    f32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = act_fwd(acc[i][j][4 * g + q] + bv, p.act, p.slope);
+                    if (vec) {
+                        uint32_t n = fdiv((uint32_t)m, p.div_hw);
+                        uint32_t pix = (uint32_t)m - n * (uint32_t)p.HW;
+                        *reinterpret_cast<f32x4*>(p.out + ((long long)n * p.CH + ch) * p.HW + pix) = v;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            int mq = m + q;
+                            if (mq < p.M) {
+                                uint32_t n = fdiv((uint32_t)mq, p.div_hw);
+                                uint32_t pix = (uint32_t)mq - n * (uint32_t)p.HW;
+                                p.out[((long long)n * p.CH + ch) * p.HW + pix] = v[q];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+};
+
+// dgrad / transposed-conv output: row m = (n, a, b) of phase y=(py,px) goes to
+// x[n][c][S*a+py][S*b+px].  Optional bias[c] + activation.
+template <int S>
+struct EpiPhase {
+    struct Params {
+        float* out;
+        int M, C, H, W, AH, AW;
+        FastDiv div_ahw, div_aw;
+        const float* bias;
+        int act;
+        float slope;
+    };
+    template <int TM, int TN>
+    __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
+                                                 int n_base, int lane, int y, int z) {
+        const int col_l = lane & 31, half = lane >> 5;
+        const int py = y / S, px = y % S;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= p.M) continue;
+                uint32_t n = fdiv((uint32_t)m, p.div_ahw);
+                uint32_t pix = (uint32_t)m - n * (uint32_t)(p.AH * p.AW);
+                uint32_t a = fdiv(pix, p.div_aw);
+                uint32_t b = pix - a * (uint32_t)p.AW;
+                long long o = ((long long)n * p.C * p.H + (S * a + py)) * p.W + (S * b + px);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    int c = n_base + j * 32 + col_l;
+                    if (c < p.C) {
+                        float bv = p.bias ? p.bias[c] : 0.f;
+                        p.out[o + (long long)c * p.H * p.W] = act_fwd(acc[i][j][r] + bv, p.act, p.slope);
+                    }
+                }
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------
+struct GridMap {
+    int tiles_m, tiles_n, ny;  // grid.x = tiles_m * tiles_n * ny (ny = dgrad phases / batches, fastest)
+    int chunks;                // total K chunks
+    int chunks_per_split;      // grid.z = ceil(chunks / chunks_per_split)
+};
+
+template <class Cfg, class AL, class BL, class Epi>
+__global__ __launch_bounds__(NT) void igemm_kernel(typename AL::Params pa, typename BL::Params pb,
+                                                   typename Epi::Params pe, GridMap gm) {
+    constexpr int LDA = AL::LD, LDB = BL::LD;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+    float* As = smem;
+    float* Bs = smem + 2 * BK * LDA;
+
+    const int tid = threadIdx.x;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+    // contiguous run of tiles (neighbouring tiles share operand panels in that XCD's L2).
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, rr = nwg & 7, x = bid & 7, i = bid >> 3;
+        bid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + i;
+    }
+    // phases of one tile are adjacent (same XCD, close in time): they read the same feature patch and
+    // their interleaved stores meet in that XCD's L2.
+    const int y = bid % gm.ny;
+    bid /= gm.ny;
+    const int tile_n = bid % gm.tiles_n;
+    const int tile_m = bid / gm.tiles_n;
+    const int z = blockIdx.z;
+    const int kc0 = z * gm.chunks_per_split;
+    const int kc1 = min(gm.chunks, kc0 + gm.chunks_per_split);
+
+    AL al;
+    BL bl;
+    al.init(pa, tile_m, y, tid);
+    bl.init(pb, tile_n, y, tid);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int a_rd = half * LDA + wm * TM * 32 + l32;
+    const int b_rd = half * LDB + wn * TN * 32 + l32;
+
+    if (kc0 < kc1) {
+        al.issue(kc0);
+        bl.issue(kc0);
+        al.commit(As);
+        bl.commit(Bs);
+    }
+    __syncthreads();
+
+    for (int kc = kc0; kc < kc1; ++kc) {
+        const int cur = (kc - kc0) & 1;
+        const bool more = kc + 1 < kc1;
+        if (more) {
+            al.issue(kc + 1);
+            bl.issue(kc + 1);
+        }
+        const float* Ar = As + cur * BK * LDA + a_rd;
+        const float* Br = Bs + cur * BK * LDB + b_rd;
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = Ar[2 * s * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Br[2 * s * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            al.commit(As + (cur ^ 1) * BK * LDA);
+            bl.commit(Bs + (cur ^ 1) * BK * LDB);
+        }
+        __syncthreads();
+    }
+
+    Epi::template store<TM, TN>(pe, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32,
+                                lane, y, z);
+}
+
+template <class Cfg, class AL, class BL, class Epi>
+inline int launch_igemm(const typename AL::Params& pa, const typename BL::Params& pb,
+                        const typename Epi::Params& pe, int M, int N, int K, int ny, int splits,
+                        hipStream_t stream) {
+    GridMap gm;
+    gm.tiles_m = (M + Cfg::BM - 1) / Cfg::BM;
+    gm.tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
+    gm.chunks = (K + BK - 1) / BK;
+    if (splits < 1) splits = 1;
+    gm.chunks_per_split = (gm.chunks + splits - 1) / splits;
+    int nz = (gm.chunks + gm.chunks_per_split - 1) / gm.chunks_per_split;
+    if (nz < 1) nz = 1;
+    gm.ny = ny;
+    dim3 grid(gm.tiles_m * gm.tiles_n * ny, 1, nz);
+    hipLaunchKernelGGL((igemm_kernel<Cfg, AL, BL, Epi>), grid, dim3(NT), 0, stream, pa, pb, pe, gm);
+    return launch_status();
+}
+
+}  // namespace gz

@@ -1,0 +1,528 @@
+// Normalisation + activation kernels (HBM-bound): BatchNorm2d(train/eval), InstanceNorm2d
+// (affine or not) fused with ReLU / LeakyReLU, their backward, and the double backward the
+// WGAN-GP gradient penalty needs (reference core/utils/utils.py:39-58 differentiates through
+// InstanceNorm's backward; standard_networks.py:44-47,87-88 are the call sites).
+//
+// Data model: a tensor [N, C, inner] is a set of rows = N*C of `inner` contiguous floats.
+// Statistics are per row (InstanceNorm / AdaIN) or per channel over all n (BatchNorm):
+// every pass is "row sums by wavefront shuffle" (+ a tiny finalize over rows) or a float4
+// elementwise apply, so each tensor is streamed once per pass with 16-byte accesses.
+// `per_channel` = 1 selects coefficient index row % C (BatchNorm), 0 selects the row itself.
+#include "gz_common.h"
+#include "../../include/gz_ops.h"
+
+namespace gz {
+
+constexpr int PW_THREADS = 256;
+
+struct RowGeom {
+    int rows, q4;       // rows, float4 per row
+    int lpr, rpw;       // lanes per row (pow2 <= 64), rows per wave
+};
+
+static RowGeom row_geom(long long rows, int inner) {
+    RowGeom g;
+    g.rows = (int)rows;
+    g.q4 = inner / 4;
+    int lpr = 1;
+    while (lpr < 64 && lpr < g.q4) lpr <<= 1;
+    g.lpr = lpr;
+    g.rpw = 64 / lpr;
+    return g;
+}
+
+static int row_grid(const RowGeom& g) {
+    long long groups = ((long long)g.rows + g.rpw - 1) / g.rpw;   // wave-sized work items
+    long long blocks = (groups + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+template <int NS>
+__device__ __forceinline__ void sub_reduce(float (&s)[NS], int lpr) {
+    for (int o = lpr >> 1; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[k] += __shfl_xor(s[k], o, 64);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// forward statistics
+// ---------------------------------------------------------------------------
+// sums[row] = (sum x, sum x^2)
+__global__ __launch_bounds__(PW_THREADS) void row_sums_kernel(const float* __restrict__ x, f32x2* __restrict__ sums,
+                                                              RowGeom g) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * PW_THREADS + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * PW_THREADS) >> 6;
+    const int sub = lane / g.lpr, l = lane % g.lpr;
+    for (long long row0 = (long long)wave * g.rpw; row0 < g.rows; row0 += (long long)nwaves * g.rpw) {
+        long long row = row0 + sub;
+        float s[2] = {0.f, 0.f};
+        if (row < g.rows) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(x) + row * g.q4;
+            for (int q = l; q < g.q4; q += g.lpr) {
+                f32x4 v = p[q];
+                s[0] += (v.x + v.y) + (v.z + v.w);
+                s[1] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+        }
+        sub_reduce<2>(s, g.lpr);
+        if (row < g.rows && l == 0) sums[row] = f32x2{s[0], s[1]};
+    }
+}
+
+// BatchNorm finalize: one thread per channel, fp64 combine over n.
+// coef[0*C..] = scale, coef[1*C..] = shift, coef[2*C..] = mean, coef[3*C..] = rstd
+__global__ void bn_finalize_kernel(const f32x2* __restrict__ sums, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ coef,
+                                   float* running_mean, float* running_var, long long* nbt, int N, int C,
+                                   int inner, float eps, float momentum) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = 0; n < N; ++n) {
+        f32x2 v = sums[(long long)n * C + c];
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+    }
+    double cnt = (double)N * inner;
+    double mean = s1 / cnt;
+    double var = s2 / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    float scale = ga * rstd;
+    coef[c] = scale;
+    coef[C + c] = be - (float)mean * scale;
+    coef[2 * C + c] = (float)mean;
+    coef[3 * C + c] = rstd;
+    if (running_mean) {
+        double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// BatchNorm eval: coefficients from the running statistics
+__global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ rm, const float* __restrict__ rv,
+                                    float* __restrict__ coef, int C, float eps) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float rstd = 1.f / sqrtf(rv[c] + eps);
+    float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    coef[c] = ga * rstd;
+    coef[C + c] = be - rm[c] * ga * rstd;
+    coef[2 * C + c] = rm[c];
+    coef[3 * C + c] = rstd;
+}
+
+// per-row finalize (InstanceNorm / AdaIN): rows = N*C, gamma/beta indexed by channel (stride_n = 0)
+// or by row (AdaIN: per-sample scale/bias, stride_n = C).  unbiased = 1 uses var * n/(n-1).
+__global__ void row_finalize_kernel(const f32x2* __restrict__ sums, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, float* __restrict__ coef, int rows, int C,
+                                    int inner, float eps, int affine_per_row, int unbiased) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    f32x2 v = sums[r];
+    double cnt = (double)inner;
+    double mean = (double)v.x / cnt;
+    double var = (double)v.y / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    if (unbiased && inner > 1) var = var * cnt / (cnt - 1.0);
+    float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    int gi = affine_per_row ? r : r % C;
+    float ga = gamma ? gamma[gi] : 1.f, be = beta ? beta[gi] : 0.f;
+    float scale = ga * rstd;
+    coef[r] = scale;
+    coef[rows + r] = be - (float)mean * scale;
+    coef[2 * rows + r] = (float)mean;
+    coef[3 * rows + r] = rstd;
+}
+
+// ---------------------------------------------------------------------------
+// forward apply: out = act(x * scale[i] + shift[i])
+// ---------------------------------------------------------------------------
+struct ApplyGeom {
+    long long total4;
+    int q4;             // float4 per row
+    FastDiv div_q4, div_c;
+    int C, per_channel, ncoef;   // ncoef = number of coefficient entries (C or rows)
+};
+
+__device__ __forceinline__ int coef_index(long long i4, const ApplyGeom& g) {
+    uint32_t row = fdiv((uint32_t)i4, g.div_q4);
+    if (g.per_channel) row -= fdiv(row, g.div_c) * (uint32_t)g.C;
+    return (int)row;
+}
+
+__global__ __launch_bounds__(PW_THREADS) void norm_act_apply_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ coef,
+                                                                    float* __restrict__ out, ApplyGeom g, int act,
+                                                                    float slope) {
+    const long long stride = (long long)gridDim.x * PW_THREADS;
+    for (long long i = (long long)blockIdx.x * PW_THREADS + threadIdx.x; i < g.total4; i += stride) {
+        int ci = coef_index(i, g);
+        float sc = coef[ci], sh = coef[g.ncoef + ci];
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = act_fwd(v[k] * sc + sh, act, slope);
+        reinterpret_cast<f32x4*>(out)[i] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// first backward
+//   z = x*scale + shift, dz = gout * act'(z), xh = (x - mean) * rstd
+//   rowsums: (sum dz, sum dz*xh)
+//   dx = scale * (dz - k1 - xh*k2),  k1 = mean(dz), k2 = mean(dz*xh) over the statistics group
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float act_grad_z(float z, int act, float slope) {
+    if (act == ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == ACT_LRELU) return z > 0.f ? 1.f : slope;
+    return 1.f;
+}
+
+__global__ __launch_bounds__(PW_THREADS) void norm_bwd_rowsums_kernel(const float* __restrict__ gout,
+                                                                      const float* __restrict__ x,
+                                                                      const float* __restrict__ coef,
+                                                                      f32x2* __restrict__ sums, RowGeom g, int C,
+                                                                      int per_channel, int ncoef, int act,
+                                                                      float slope) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * PW_THREADS + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * PW_THREADS) >> 6;
+    const int sub = lane / g.lpr, l = lane % g.lpr;
+    for (long long row0 = (long long)wave * g.rpw; row0 < g.rows; row0 += (long long)nwaves * g.rpw) {
+        long long row = row0 + sub;
+        float s[2] = {0.f, 0.f};
+        if (row < g.rows) {
+            int ci = per_channel ? (int)(row % C) : (int)row;
+            float sc = coef[ci], sh = coef[ncoef + ci], mean = coef[2 * ncoef + ci], rstd = coef[3 * ncoef + ci];
+            const f32x4* px = reinterpret_cast<const f32x4*>(x) + row * g.q4;
+            const f32x4* pg = reinterpret_cast<const f32x4*>(gout) + row * g.q4;
+            for (int q = l; q < g.q4; q += g.lpr) {
+                f32x4 xv = px[q], gv = pg[q];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float dz = gv[k] * act_grad_z(xv[k] * sc + sh, act, slope);
+                    s[0] += dz;
+                    s[1] += dz * ((xv[k] - mean) * rstd);
+                }
+            }
+        }
+        sub_reduce<2>(s, g.lpr);
+        if (row < g.rows && l == 0) sums[row] = f32x2{s[0], s[1]};
+    }
+}
+
+// BatchNorm: combine row sums over n -> k[0*C] = mean(dz), k[1*C] = mean(dz*xh); dgamma, dbeta
+__global__ void bn_bwd_finalize_kernel(const f32x2* __restrict__ sums, float* __restrict__ k,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C,
+                                       int inner) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = 0; n < N; ++n) {
+        f32x2 v = sums[(long long)n * C + c];
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+    }
+    double cnt = (double)N * inner;
+    k[c] = (float)(s1 / cnt);
+    k[C + c] = (float)(s2 / cnt);
+    if (dgamma) dgamma[c] = (float)s2;
+    if (dbeta) dbeta[c] = (float)s1;
+}
+
+// per-row statistics: k = sums / inner; dgamma/dbeta[c] = sum over n (per-channel affine) or per row
+__global__ void row_bwd_finalize_kernel(const f32x2* __restrict__ sums, float* __restrict__ k,
+                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C,
+                                        int inner, int affine_per_row) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int rows = N * C;
+    if (i < rows) {
+        f32x2 v = sums[i];
+        k[i] = v.x / (float)inner;
+        k[rows + i] = v.y / (float)inner;
+        if (affine_per_row) {
+            if (dgamma) dgamma[i] = v.y;
+            if (dbeta) dbeta[i] = v.x;
+        }
+    }
+    if (!affine_per_row && i < C && (dgamma || dbeta)) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int n = 0; n < N; ++n) {
+            f32x2 v = sums[(long long)n * C + i];
+            s1 += (double)v.x;
+            s2 += (double)v.y;
+        }
+        if (dgamma) dgamma[i] = (float)s2;
+        if (dbeta) dbeta[i] = (float)s1;
+    }
+}
+
+__global__ __launch_bounds__(PW_THREADS) void norm_bwd_apply_kernel(const float* __restrict__ gout,
+                                                                    const float* __restrict__ x,
+                                                                    const float* __restrict__ coef,
+                                                                    const float* __restrict__ k,
+                                                                    float* __restrict__ dx, ApplyGeom g, int act,
+                                                                    float slope) {
+    const long long stride = (long long)gridDim.x * PW_THREADS;
+    for (long long i = (long long)blockIdx.x * PW_THREADS + threadIdx.x; i < g.total4; i += stride) {
+        int ci = coef_index(i, g);
+        float sc = coef[ci], sh = coef[g.ncoef + ci], mean = coef[2 * g.ncoef + ci], rstd = coef[3 * g.ncoef + ci];
+        float k1 = k[ci], k2 = k[g.ncoef + ci];
+        f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+        f32x4 gv = reinterpret_cast<const f32x4*>(gout)[i];
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float dz = gv[q] * act_grad_z(xv[q] * sc + sh, act, slope);
+            float xh = (xv[q] - mean) * rstd;
+            o[q] = sc * (dz - k1 - xh * k2);
+        }
+        reinterpret_cast<f32x4*>(dx)[i] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// double backward (per-row statistics only: InstanceNorm).  With g = gout*act'(z) and
+// v = dL/d(dx):   sums5[row] = (sum v, sum g, sum g*xh, sum v*xh, sum v*g)
+//   gg_out = act'(z) * scale * (v - mean(v) - xh*mean(v*xh))
+//   gx     = -scale*rstd * [ xh*(mean(vg) - mean(v)mean(g) - c*mvx) + c*(v - mean(v) - xh*mvx)
+//                            + mvx*(g - mean(g) - xh*c) ],   c = mean(g*xh), mvx = mean(v*xh)
+//   ggamma[c] += rstd * inner * (mean(vg) - mean(v)mean(g) - mvx*c)        (summed over n)
+// ---------------------------------------------------------------------------
+struct Sums5 {
+    float v, g, gx, vx, vg;
+};
+
+__global__ __launch_bounds__(PW_THREADS) void norm_bwd2_rowsums_kernel(const float* __restrict__ gout,
+                                                                       const float* __restrict__ v,
+                                                                       const float* __restrict__ x,
+                                                                       const float* __restrict__ coef,
+                                                                       Sums5* __restrict__ sums, RowGeom g,
+                                                                       int act, float slope) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * PW_THREADS + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * PW_THREADS) >> 6;
+    const int sub = lane / g.lpr, l = lane % g.lpr;
+    const int ncoef = g.rows;
+    for (long long row0 = (long long)wave * g.rpw; row0 < g.rows; row0 += (long long)nwaves * g.rpw) {
+        long long row = row0 + sub;
+        float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (row < g.rows) {
+            float sc = coef[row], sh = coef[ncoef + row], mean = coef[2 * ncoef + row], rstd = coef[3 * ncoef + row];
+            const f32x4* px = reinterpret_cast<const f32x4*>(x) + row * g.q4;
+            const f32x4* pg = reinterpret_cast<const f32x4*>(gout) + row * g.q4;
+            const f32x4* pv = reinterpret_cast<const f32x4*>(v) + row * g.q4;
+            for (int q = l; q < g.q4; q += g.lpr) {
+                f32x4 xv = px[q], gv = pg[q], vv = pv[q];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float gz = gv[k] * act_grad_z(xv[k] * sc + sh, act, slope);
+                    float xh = (xv[k] - mean) * rstd;
+                    s[0] += vv[k];
+                    s[1] += gz;
+                    s[2] += gz * xh;
+                    s[3] += vv[k] * xh;
+                    s[4] += vv[k] * gz;
+                }
+            }
+        }
+        sub_reduce<5>(s, g.lpr);
+        if (row < g.rows && l == 0) sums[row] = Sums5{s[0], s[1], s[2], s[3], s[4]};
+    }
+}
+
+__global__ __launch_bounds__(PW_THREADS) void norm_bwd2_apply_kernel(
+    const float* __restrict__ gout, const float* __restrict__ v, const float* __restrict__ x,
+    const float* __restrict__ coef, const Sums5* __restrict__ sums, float* __restrict__ gg_out,
+    float* __restrict__ gx, ApplyGeom g, int act, float slope) {
+    const long long stride = (long long)gridDim.x * PW_THREADS;
+    const float inv = 1.f / (float)(g.q4 * 4);
+    for (long long i = (long long)blockIdx.x * PW_THREADS + threadIdx.x; i < g.total4; i += stride) {
+        int r = (int)fdiv((uint32_t)i, g.div_q4);
+        float sc = coef[r], sh = coef[g.ncoef + r], mean = coef[2 * g.ncoef + r], rstd = coef[3 * g.ncoef + r];
+        Sums5 s = sums[r];
+        float mv = s.v * inv, mg = s.g * inv, c = s.gx * inv, mvx = s.vx * inv, mvg = s.vg * inv;
+        float t1 = mvg - mv * mg - c * mvx;
+        f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+        f32x4 gv = reinterpret_cast<const f32x4*>(gout)[i];
+        f32x4 vv = reinterpret_cast<const f32x4*>(v)[i];
+        f32x4 o1, o2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float m = act_grad_z(xv[q] * sc + sh, act, slope);
+            float gz = gv[q] * m;
+            float xh = (xv[q] - mean) * rstd;
+            float pv = vv[q] - mv - xh * mvx;
+            o1[q] = m * sc * pv;
+            o2[q] = -sc * rstd * (xh * t1 + c * pv + mvx * (gz - mg - xh * c));
+        }
+        if (gg_out) reinterpret_cast<f32x4*>(gg_out)[i] = o1;
+        if (gx) reinterpret_cast<f32x4*>(gx)[i] = o2;
+    }
+}
+
+// ggamma[c] = sum_n rstd[n,c] * inner * (mvg - mv*mg - mvx*c)
+__global__ void norm_bwd2_ggamma_kernel(const Sums5* __restrict__ sums, const float* __restrict__ coef,
+                                        float* __restrict__ ggamma, int N, int C, int inner) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    int rows = N * C;
+    double acc = 0.0;
+    float inv = 1.f / (float)inner;
+    for (int n = 0; n < N; ++n) {
+        int r = n * C + c;
+        Sums5 s = sums[r];
+        float rstd = coef[3 * rows + r];
+        acc += (double)(rstd * (s.vg - s.v * s.g * inv - s.vx * s.gx * inv));
+    }
+    ggamma[c] = (float)acc;
+}
+
+// ---------------------------------------------------------------------------
+// plain activation backward: dx = g * act'(out) expressed through the output
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(PW_THREADS) void act_bwd_kernel(const float* __restrict__ g,
+                                                             const float* __restrict__ out,
+                                                             float* __restrict__ dx, long long total4, int act,
+                                                             float slope) {
+    const long long stride = (long long)gridDim.x * PW_THREADS;
+    for (long long i = (long long)blockIdx.x * PW_THREADS + threadIdx.x; i < total4; i += stride) {
+        f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 ov = reinterpret_cast<const f32x4*>(out)[i];
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = gv[q] * act_bwd_from_out(ov[q], act, slope);
+        reinterpret_cast<f32x4*>(dx)[i] = o;
+    }
+}
+
+static int ew_grid(long long total4) {
+    long long b = (total4 + PW_THREADS - 1) / PW_THREADS;
+    if (b > 256 * 8) b = 256 * 8;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+static ApplyGeom apply_geom(int N, int C, int inner, int per_channel) {
+    ApplyGeom g;
+    g.total4 = (long long)N * C * inner / 4;
+    g.q4 = inner / 4;
+    g.div_q4 = make_fastdiv(g.q4);
+    g.div_c = make_fastdiv(C);
+    g.C = C;
+    g.per_channel = per_channel;
+    g.ncoef = per_channel ? C : N * C;
+    return g;
+}
+
+static bool norm_shape_ok(int N, int C, int inner) {
+    return N > 0 && C > 0 && inner > 0 && (inner % 4) == 0 && (long long)N * C * inner * 4 < (1ll << 33) &&
+           (long long)N * C * inner / 4 < (1ll << 31);
+}
+
+}  // namespace gz
+
+using namespace gz;
+
+extern "C" {
+
+size_t gz_norm_workspace_bytes(int N, int C) { return (size_t)N * C * sizeof(Sums5); }
+
+int gz_norm_coef_elems(int N, int C, int per_channel) { return 4 * (per_channel ? C : N * C); }
+
+int gz_batchnorm_stats(const float* x, const float* gamma, const float* beta, float* coef, float* running_mean,
+                       float* running_var, long long* num_batches_tracked, void* workspace, int N, int C,
+                       int inner, float eps, float momentum, hipStream_t stream) {
+    if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
+    RowGeom g = row_geom((long long)N * C, inner);
+    hipLaunchKernelGGL(row_sums_kernel, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, (f32x2*)workspace, g);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, (const f32x2*)workspace, gamma,
+                       beta, coef, running_mean, running_var, num_batches_tracked, N, C, inner, eps, momentum);
+    return launch_status();
+}
+
+int gz_batchnorm_eval_coef(const float* gamma, const float* beta, const float* running_mean,
+                           const float* running_var, float* coef, int C, float eps, hipStream_t stream) {
+    if (C <= 0) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, gamma, beta, running_mean,
+                       running_var, coef, C, eps);
+    return launch_status();
+}
+
+int gz_rownorm_stats(const float* x, const float* gamma, const float* beta, float* coef, void* workspace, int N,
+                     int C, int inner, float eps, int affine_per_row, int unbiased, hipStream_t stream) {
+    if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
+    RowGeom g = row_geom((long long)N * C, inner);
+    hipLaunchKernelGGL(row_sums_kernel, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, (f32x2*)workspace, g);
+    int rows = N * C;
+    hipLaunchKernelGGL(row_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, (const f32x2*)workspace,
+                       gamma, beta, coef, rows, C, inner, eps, affine_per_row, unbiased);
+    return launch_status();
+}
+
+int gz_norm_act_fwd(const float* x, const float* coef, float* out, int N, int C, int inner, int per_channel,
+                    int act, float slope, hipStream_t stream) {
+    if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
+    ApplyGeom g = apply_geom(N, C, inner, per_channel);
+    hipLaunchKernelGGL(norm_act_apply_kernel, dim3(ew_grid(g.total4)), dim3(PW_THREADS), 0, stream, x, coef, out, g,
+                       act, slope);
+    return launch_status();
+}
+
+int gz_norm_act_bwd(const float* gout, const float* x, const float* coef, float* dx, float* dgamma, float* dbeta,
+                    void* workspace, float* kbuf, int N, int C, int inner, int per_channel, int affine_per_row,
+                    int act, float slope, hipStream_t stream) {
+    if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
+    RowGeom rg = row_geom((long long)N * C, inner);
+    ApplyGeom g = apply_geom(N, C, inner, per_channel);
+    hipLaunchKernelGGL(norm_bwd_rowsums_kernel, dim3(row_grid(rg)), dim3(PW_THREADS), 0, stream, gout, x, coef,
+                       (f32x2*)workspace, rg, C, per_channel, g.ncoef, act, slope);
+    if (per_channel) {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, stream,
+                           (const f32x2*)workspace, kbuf, dgamma, dbeta, N, C, inner);
+    } else {
+        int rows = N * C;
+        hipLaunchKernelGGL(row_bwd_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream,
+                           (const f32x2*)workspace, kbuf, dgamma, dbeta, N, C, inner, affine_per_row);
+    }
+    if (dx)
+        hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(ew_grid(g.total4)), dim3(PW_THREADS), 0, stream, gout, x, coef,
+                           kbuf, dx, g, act, slope);
+    return launch_status();
+}
+
+int gz_rownorm_act_bwd2(const float* gout, const float* v, const float* x, const float* coef, float* gg_out,
+                        float* gx, float* ggamma, void* workspace, int N, int C, int inner, int act, float slope,
+                        hipStream_t stream) {
+    if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
+    RowGeom rg = row_geom((long long)N * C, inner);
+    ApplyGeom g = apply_geom(N, C, inner, 0);
+    hipLaunchKernelGGL(norm_bwd2_rowsums_kernel, dim3(row_grid(rg)), dim3(PW_THREADS), 0, stream, gout, v, x, coef,
+                       (Sums5*)workspace, rg, act, slope);
+    if (gg_out || gx)
+        hipLaunchKernelGGL(norm_bwd2_apply_kernel, dim3(ew_grid(g.total4)), dim3(PW_THREADS), 0, stream, gout, v, x,
+                           coef, (const Sums5*)workspace, gg_out, gx, g, act, slope);
+    if (ggamma)
+        hipLaunchKernelGGL(norm_bwd2_ggamma_kernel, dim3((C + 127) / 128), dim3(128), 0, stream,
+                           (const Sums5*)workspace, coef, ggamma, N, C, inner);
+    return launch_status();
+}
+
+int gz_act_bwd(const float* g, const float* out, float* dx, long long count, int act, float slope,
+               hipStream_t stream) {
+    if (count <= 0 || (count & 3)) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(count / 4)), dim3(PW_THREADS), 0, stream, g, out, dx, count / 4,
+                       act, slope);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,627 @@
+"""torch.autograd.Function wrappers over the C-ABI HIP kernels (include/gz_ops.h).
+
+PyTorch is used for device memory, streams and the autograd tape only; every
+arithmetic step of the hot path is a call into libgz_hip.so.  The convolution
+family is closed under differentiation:
+
+    F(x, w)  = conv2d            dF/dx^T g  = Dg(g, w)   dF/dw^T g  = Wg(x, g)
+    Dg(g, w) = conv_transpose2d  dDg/dg^T v = F(v, w)    dDg/dw^T v = Wg(v, g)
+    Wg(x, g) = weight gradient   dWg/dx^T v = Dg(g, v)   dWg/dg^T v = F(x, v)
+
+so `torch.autograd.grad(..., create_graph=True)` (the WGAN-GP gradient penalty,
+reference core/utils/utils.py:48-54) works through these ops to any order.
+"""
+import ctypes
+import weakref
+from collections import namedtuple
+
+import torch
+
+from ._lib import check, lib
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+
+Geom = namedtuple("Geom", "kh kw stride pad")
+K4S2P1 = Geom(4, 4, 2, 1)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError("lightning_gan_zoo_amd: %s must live on the GPU (got %s); the HIP path has no CPU "
+                           "fallback" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise RuntimeError("lightning_gan_zoo_amd: %s must be float32, got %s" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def out_size(n, g):
+    return (n + 2 * g.pad - g.kh) // g.stride + 1
+
+
+# ---------------------------------------------------------------------------
+# packed weights (GEMM-B images).  Cached per Parameter object and version so the three
+# discriminator passes of one step share one pack.
+# ---------------------------------------------------------------------------
+_pack_cache = {}
+
+
+def _packed(w, kind, geom):
+    key = (w.data_ptr(), kind)
+    cacheable = isinstance(w, torch.nn.Parameter)
+    if cacheable:
+        hit = _pack_cache.get(key)
+        if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == tuple(w.shape):
+            return hit[3]
+    K, C, KH, KW = w.shape
+    if kind == "f":
+        n = lib.gz_conv2d_pack_fwd_elems(K, C, KH, KW)
+        wp = torch.empty(n, device=w.device, dtype=torch.float32)
+        check(lib.gz_conv2d_pack_fwd(_p(w), _p(wp), K, C, KH, KW, _stream()), "conv2d_pack_fwd")
+    else:
+        n = lib.gz_conv2d_pack_dgrad_elems(K, C, KH, KW, geom.stride)
+        wp = torch.empty(n, device=w.device, dtype=torch.float32)
+        check(lib.gz_conv2d_pack_dgrad(_p(w), _p(wp), K, C, KH, KW, geom.stride, geom.pad, _stream()),
+              "conv2d_pack_dgrad")
+    if cacheable:
+        _pack_cache[key] = (weakref.ref(w), w._version, tuple(w.shape), wp)
+    return wp
+
+
+def clear_pack_cache():
+    _pack_cache.clear()
+
+
+def invalidate(w):
+    """Forget the packed images of `w` after its memory was rewritten without a version bump
+    (raw in-place kernels: clamp_, the fused optimizers)."""
+    _pack_cache.pop((w.data_ptr(), "f"), None)
+    _pack_cache.pop((w.data_ptr(), "d"), None)
+
+
+# ---------------------------------------------------------------------------
+# raw (non-differentiable) launchers
+# ---------------------------------------------------------------------------
+def _conv_fwd_raw(x, w, bias, geom, act, slope):
+    N, C, H, W = x.shape
+    K = w.shape[0]
+    OH, OW = out_size(H, geom), out_size(W, geom)
+    y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
+    wp = _packed(w, "f", geom)
+    check(lib.gz_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(y), N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
+                            geom.pad, act, slope, _stream()), "conv2d_fwd")
+    return y
+
+
+def _conv_dgrad_raw(g, w, bias, geom, hw, act, slope):
+    N, K, OH, OW = g.shape
+    C = w.shape[1]
+    H, W = hw
+    x = torch.empty((N, C, H, W), device=g.device, dtype=torch.float32)
+    wp = _packed(w, "d", geom)
+    check(lib.gz_conv2d_dgrad(_p(g), _p(wp), _p(bias), _p(x), N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
+                              geom.pad, act, slope, _stream()), "conv2d_dgrad")
+    return x
+
+
+def _conv_wgrad_raw(x, g, geom):
+    N, C, H, W = x.shape
+    _, K, OH, OW = g.shape
+    dw = torch.empty((K, C, geom.kh, geom.kw), device=x.device, dtype=torch.float32)
+    nbytes = lib.gz_conv2d_wgrad_workspace_bytes(N, C, H, W, K, OH, OW, geom.kh, geom.kw)
+    ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+    check(lib.gz_conv2d_wgrad(_p(x), _p(g), _p(dw), _p(ws), nbytes, N, C, H, W, K, OH, OW, geom.kh, geom.kw,
+                              geom.stride, geom.pad, _stream()), "conv2d_wgrad")
+    return dw
+
+
+def _act_bwd_raw(g, out, act, slope):
+    dx = torch.empty_like(g)
+    check(lib.gz_act_bwd(_p(g), _p(out), _p(dx), g.numel(), act, slope, _stream()), "act_bwd")
+    return dx
+
+
+def gemm(a, b, bias=None, trans_a=False, trans_b=False, act=ACT_NONE, slope=0.0):
+    """c = act(op(a) @ op(b) + bias); raw launcher (no autograd)."""
+    a, b = _req(a, "a"), _req(b, "b")
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    N = b.shape[0] if trans_b else b.shape[1]
+    c = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    check(lib.gz_gemm(_p(a), _p(b), _p(bias), _p(c), M, N, K, a.shape[1], b.shape[1], N, int(trans_a), int(trans_b),
+                      act, slope, _stream()), "gemm")
+    return c
+
+
+# ---------------------------------------------------------------------------
+# activation backward as a differentiable op (linear in g; the mask is piecewise constant)
+# ---------------------------------------------------------------------------
+class _ActBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, out, act, slope):
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(g, out)
+        return _act_bwd_raw(_req(g), out, act, slope)
+
+    @staticmethod
+    def backward(ctx, v):
+        g, out = ctx.saved_tensors
+        gg = _ActBwd.apply(v, out, ctx.act, ctx.slope) if ctx.needs_input_grad[0] else None
+        go = None
+        if ctx.needs_input_grad[1] and ctx.act == ACT_TANH:
+            go = v * g * (-2.0 * out)   # d/d(out) of g*(1-out^2); only tanh has a non-constant mask
+        return gg, go, None, None
+
+
+# ---------------------------------------------------------------------------
+# F / Dg / Wg
+# ---------------------------------------------------------------------------
+class _ConvF(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, geom, act, slope):
+        x, w = _req(x, "x"), _req(w, "w")
+        y = _conv_fwd_raw(x, w, bias, geom, act, slope)
+        ctx.geom, ctx.act, ctx.slope = geom, act, slope
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        geom = ctx.geom
+        if ctx.act != ACT_NONE:
+            gy = _ActBwd.apply(gy, y, ctx.act, ctx.slope)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _ConvDg.apply(gy, w, None, geom, tuple(x.shape[2:]), ACT_NONE, 0.0)
+        if ctx.needs_input_grad[1]:
+            dw = _ConvWg.apply(x, gy, geom)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = gy.sum((0, 2, 3))
+        return dx, dw, db, None, None, None
+
+
+class _ConvDg(torch.autograd.Function):
+    """x = act(conv_transpose2d(g, w) + bias): ConvTranspose2d forward and Conv2d input gradient."""
+
+    @staticmethod
+    def forward(ctx, g, w, bias, geom, hw, act, slope):
+        g, w = _req(g, "g"), _req(w, "w")
+        x = _conv_dgrad_raw(g, w, bias, geom, hw, act, slope)
+        ctx.geom, ctx.act, ctx.slope = geom, act, slope
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(g, w, x if act != ACT_NONE else None)
+        return x
+
+    @staticmethod
+    def backward(ctx, v):
+        g, w, x = ctx.saved_tensors
+        geom = ctx.geom
+        if ctx.act != ACT_NONE:
+            v = _ActBwd.apply(v, x, ctx.act, ctx.slope)
+        dg = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dg = _ConvF.apply(v, w, None, geom, ACT_NONE, 0.0)
+        if ctx.needs_input_grad[1]:
+            dw = _ConvWg.apply(v, g, geom)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = v.sum((0, 2, 3))
+        return dg, dw, db, None, None, None, None
+
+
+class _ConvWg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, geom):
+        x, g = _req(x, "x"), _req(g, "g")
+        ctx.geom = geom
+        ctx.save_for_backward(x, g)
+        return _conv_wgrad_raw(x, g, geom)
+
+    @staticmethod
+    def backward(ctx, v):
+        x, g = ctx.saved_tensors
+        geom = ctx.geom
+        v = _req(v)
+        dx = dg = None
+        if ctx.needs_input_grad[0]:
+            dx = _ConvDg.apply(g, v, None, geom, tuple(x.shape[2:]), ACT_NONE, 0.0)
+        if ctx.needs_input_grad[1]:
+            dg = _ConvF.apply(x, v, None, geom, ACT_NONE, 0.0)
+        return dx, dg, None
+
+
+def conv2d(x, w, bias=None, geom=K4S2P1, act=ACT_NONE, slope=0.0):
+    return _ConvF.apply(x, w, bias, geom, act, slope)
+
+
+def conv_transpose2d(x, w, bias=None, geom=K4S2P1, act=ACT_NONE, slope=0.0):
+    """w is the ConvTranspose2d weight [Cin, Cout, KH, KW]; output size (H-1)*S - 2P + KH."""
+    H, W = x.shape[2:]
+    oh = (H - 1) * geom.stride - 2 * geom.pad + geom.kh
+    ow = (W - 1) * geom.stride - 2 * geom.pad + geom.kw
+    return _ConvDg.apply(x, w, bias, geom, (oh, ow), act, slope)
+
+
+# ---------------------------------------------------------------------------
+# dense layers on the same GEMM core: the generator's 1x1 -> 4x4 ConvTranspose2d
+# (reference standard_networks.py:60) and nn.Linear
+# ---------------------------------------------------------------------------
+class _MatMul(torch.autograd.Function):
+    """c = a @ b for row-major a [M,K], b [K,N]."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _req(a, "a"), _req(b, "b")
+        ctx.save_for_backward(a, b)
+        return gemm(a, b)
+
+    @staticmethod
+    def backward(ctx, gc):
+        a, b = ctx.saved_tensors
+        gc = _req(gc)
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = _MatMulNT.apply(gc, b)            # gc @ b^T
+        if ctx.needs_input_grad[1]:
+            gb = _MatMulTN.apply(a, gc)            # a^T @ gc
+        return ga, gb
+
+
+class _MatMulNT(torch.autograd.Function):
+    """c = a @ b^T for a [M,K], b [N,K]."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _req(a, "a"), _req(b, "b")
+        ctx.save_for_backward(a, b)
+        return gemm(a, b, trans_b=True)
+
+    @staticmethod
+    def backward(ctx, gc):
+        a, b = ctx.saved_tensors
+        gc = _req(gc)
+        ga = _MatMul.apply(gc, b) if ctx.needs_input_grad[0] else None       # gc @ b
+        gb = _MatMulTN.apply(gc, a) if ctx.needs_input_grad[1] else None     # gc^T @ a
+        return ga, gb
+
+
+class _MatMulTN(torch.autograd.Function):
+    """c = a^T @ b for a [K,M], b [K,N]."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _req(a, "a"), _req(b, "b")
+        ctx.save_for_backward(a, b)
+        return gemm(a, b, trans_a=True)
+
+    @staticmethod
+    def backward(ctx, gc):
+        a, b = ctx.saved_tensors
+        gc = _req(gc)
+        ga = _MatMulNT.apply(b, gc) if ctx.needs_input_grad[0] else None     # b @ gc^T
+        gb = _MatMul.apply(a, gc) if ctx.needs_input_grad[1] else None       # a @ gc
+        return ga, gb
+
+
+def matmul(a, b):
+    return _MatMul.apply(a, b)
+
+
+def matmul_nt(a, b):
+    return _MatMulNT.apply(a, b)
+
+
+def linear(x, weight, bias=None):
+    y = _MatMulNT.apply(x, weight)
+    return y if bias is None else y + bias
+
+
+# ---------------------------------------------------------------------------
+# last discriminator layer: Conv2d(C, 1, k4, s2, p0) on a 4x4 map == per-sample dot
+# ---------------------------------------------------------------------------
+def _rowdot_raw(a, b, bcast):
+    R, L = a.shape
+    y = torch.empty(R, device=a.device, dtype=torch.float32)
+    check(lib.gz_rowdot(_p(a), _p(b), _p(y), R, L, int(bcast), _stream()), "rowdot")
+    return y
+
+
+def _rowscale_raw(x, s, R, L, bcast):
+    out = torch.empty((R, L), device=s.device, dtype=torch.float32)
+    check(lib.gz_rowscale(_p(x), _p(s), None, None, _p(out), R, L, int(bcast), 0, _stream()), "rowscale")
+    return out
+
+
+def _coldot_raw(g, x):
+    R, L = x.shape
+    out = torch.empty(L, device=x.device, dtype=torch.float32)
+    nbytes = lib.gz_coldot_workspace_bytes(R, L)
+    ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+    check(lib.gz_coldot(_p(g), _p(x), _p(out), _p(ws), nbytes, R, L, _stream()), "coldot")
+    return out
+
+
+class _DotF(torch.autograd.Function):
+    """y[r] = <x[r,:], w>"""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x, w = _req(x, "x"), _req(w, "w")
+        ctx.save_for_backward(x, w)
+        return _rowdot_raw(x, w, True)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        dx = _DotDg.apply(g, w) if ctx.needs_input_grad[0] else None
+        dw = _DotWg.apply(x, g) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+class _DotDg(torch.autograd.Function):
+    """x[r,:] = g[r] * w"""
+
+    @staticmethod
+    def forward(ctx, g, w):
+        g, w = _req(g, "g"), _req(w, "w")
+        ctx.save_for_backward(g, w)
+        return _rowscale_raw(w, g, g.numel(), w.numel(), True)
+
+    @staticmethod
+    def backward(ctx, v):
+        g, w = ctx.saved_tensors
+        dg = _DotF.apply(v, w) if ctx.needs_input_grad[0] else None
+        dw = _DotWg.apply(v, g) if ctx.needs_input_grad[1] else None
+        return dg, dw
+
+
+class _DotWg(torch.autograd.Function):
+    """dw = sum_r g[r] * x[r,:]"""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        x, g = _req(x, "x"), _req(g, "g")
+        ctx.save_for_backward(x, g)
+        return _coldot_raw(g, x)
+
+    @staticmethod
+    def backward(ctx, v):
+        x, g = ctx.saved_tensors
+        dx = _DotDg.apply(g, v) if ctx.needs_input_grad[0] else None
+        dg = _DotF.apply(x, v) if ctx.needs_input_grad[1] else None
+        return dx, dg
+
+
+def full_dot_conv(x, w):
+    """Conv2d whose kernel covers the whole (unpadded) input: [N,C,H,W] x [1,C,H,W] -> [N,1,1,1]."""
+    n = x.shape[0]
+    y = _DotF.apply(x.reshape(n, -1), w.reshape(-1))
+    return y.reshape(n, 1, 1, 1)
+
+
+# ---------------------------------------------------------------------------
+# normalisation + activation
+# ---------------------------------------------------------------------------
+def _norm_ws(x, N, C):
+    return torch.empty(max(lib.gz_norm_workspace_bytes(N, C) // 4, 1), device=x.device, dtype=torch.float32)
+
+
+class _BatchNormAct(torch.autograd.Function):
+    """act(BatchNorm(x)); training mode updates the running buffers in place exactly like
+    nn.BatchNorm2d (momentum, unbiased running var, num_batches_tracked += 1)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act, slope):
+        x = _req(x, "x")
+        N, C = x.shape[:2]
+        inner = x.numel() // (N * C)
+        coef = torch.empty(4 * C, device=x.device, dtype=torch.float32)
+        st = _stream()
+        if training:
+            ws = _norm_ws(x, N, C)
+            check(lib.gz_batchnorm_stats(_p(x), _p(gamma), _p(beta), _p(coef), _p(running_mean), _p(running_var),
+                                         _p(nbt), _p(ws), N, C, inner, eps, momentum, st), "batchnorm_stats")
+        else:
+            check(lib.gz_batchnorm_eval_coef(_p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(coef), C,
+                                             eps, st), "batchnorm_eval_coef")
+        out = torch.empty_like(x)
+        check(lib.gz_norm_act_fwd(_p(x), _p(coef), _p(out), N, C, inner, 1, act, slope, st), "norm_act_fwd")
+        ctx.save_for_backward(x, coef)
+        ctx.cfg = (N, C, inner, act, slope, training)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        x, coef = ctx.saved_tensors
+        N, C, inner, act, slope, training = ctx.cfg
+        if not training:
+            raise RuntimeError("BatchNorm backward in eval mode is outside the hot path")
+        gout = _req(gout)
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x) if need_dx else None
+        dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+        dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
+        kbuf = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        ws = _norm_ws(x, N, C)
+        check(lib.gz_norm_act_bwd(_p(gout), _p(x), _p(coef), _p(dx), _p(dgamma), _p(dbeta), _p(ws), _p(kbuf), N, C,
+                                  inner, 1, 0, act, slope, _stream()), "norm_act_bwd")
+        return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
+                None, None, None, None, None, None, None, None)
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, nbt, training, momentum=0.1, eps=1e-5,
+                   act=ACT_NONE, slope=0.0):
+    return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act, slope)
+
+
+class _RowNormAct(torch.autograd.Function):
+    """act(InstanceNorm(x)) with per-channel affine (nn.InstanceNorm2d(affine=True), biased variance,
+    always instance statistics).  Its backward is itself differentiable (_RowNormActBwd)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, act, slope):
+        x = _req(x, "x")
+        N, C = x.shape[:2]
+        inner = x.numel() // (N * C)
+        coef = torch.empty(4 * N * C, device=x.device, dtype=torch.float32)
+        ws = _norm_ws(x, N, C)
+        st = _stream()
+        check(lib.gz_rownorm_stats(_p(x), _p(gamma), _p(beta), _p(coef), _p(ws), N, C, inner, eps, 0, 0, st),
+              "rownorm_stats")
+        out = torch.empty_like(x)
+        check(lib.gz_norm_act_fwd(_p(x), _p(coef), _p(out), N, C, inner, 0, act, slope, st), "norm_act_fwd")
+        ctx.save_for_backward(x, gamma, coef)
+        ctx.cfg = (N, C, inner, act, slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, gamma, coef = ctx.saved_tensors
+        dx, dgamma, dbeta = _RowNormActBwd.apply(gout, x, gamma, coef, ctx.cfg)
+        return (dx if ctx.needs_input_grad[0] else None,
+                dgamma if (gamma is not None and ctx.needs_input_grad[1]) else None,
+                dbeta if (gamma is not None and ctx.needs_input_grad[2]) else None, None, None, None)
+
+
+class _RowNormActBwd(torch.autograd.Function):
+    """(dx, dgamma, dbeta) of _RowNormAct as a function of (gout, x, gamma); `coef` carries the
+    statistics of x and is not an independent variable (the double backward formula accounts
+    for the dependence of mean / rstd on x)."""
+
+    @staticmethod
+    def forward(ctx, gout, x, gamma, coef, cfg):
+        N, C, inner, act, slope = cfg
+        gout = _req(gout)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+        dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
+        kbuf = torch.empty(2 * N * C, device=x.device, dtype=torch.float32)
+        ws = _norm_ws(x, N, C)
+        check(lib.gz_norm_act_bwd(_p(gout), _p(x), _p(coef), _p(dx), _p(dgamma), _p(dbeta), _p(ws), _p(kbuf), N, C,
+                                  inner, 0, 0, act, slope, _stream()), "norm_act_bwd")
+        ctx.save_for_backward(gout, x, gamma, coef)
+        ctx.cfg = cfg
+        ctx.set_materialize_grads(False)
+        return dx, dgamma, dbeta
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, v, v_dgamma, v_dbeta):
+        if v_dgamma is not None or v_dbeta is not None:
+            raise RuntimeError("second-order terms through dgamma/dbeta are outside the hot path")
+        gout, x, gamma, coef = ctx.saved_tensors
+        N, C, inner, act, slope = ctx.cfg
+        if v is None:
+            return None, None, None, None, None
+        v = _req(v)
+        gg = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        need_gamma = gamma is not None and ctx.needs_input_grad[2]
+        ggamma = torch.empty(C, device=x.device, dtype=torch.float32) if need_gamma else None
+        ws = _norm_ws(x, N, C)
+        check(lib.gz_rownorm_act_bwd2(_p(gout), _p(v), _p(x), _p(coef), _p(gg), _p(gx), _p(ggamma), _p(ws), N, C,
+                                      inner, act, slope, _stream()), "rownorm_act_bwd2")
+        return gg, gx, ggamma, None, None
+
+
+def instance_norm_act(x, gamma, beta, eps=1e-5, act=ACT_NONE, slope=0.0):
+    return _RowNormAct.apply(x, gamma, beta, eps, act, slope)
+
+
+# ---------------------------------------------------------------------------
+# gradient-penalty tail (reference core/utils/utils.py:41-42, 55-57)
+# ---------------------------------------------------------------------------
+class _Lerp(torch.autograd.Function):
+    """out[n] = alpha[n]*a[n] + (1-alpha[n])*b[n] for a, b [N, L], alpha [N]."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        a, b, alpha = _req(a, "a"), _req(b, "b"), _req(alpha, "alpha")
+        R, L = a.shape[0], a.numel() // a.shape[0]
+        out = torch.empty_like(a)
+        check(lib.gz_rowscale(_p(a), _p(alpha), _p(b), None, _p(out), R, L, 0, 1, _stream()), "rowscale(lerp)")
+        ctx.save_for_backward(alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (alpha,) = ctx.saved_tensors
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = row_scale(g, alpha)
+        if ctx.needs_input_grad[1]:
+            gb = row_scale(g, 1.0 - alpha)
+        return ga, gb, None
+
+
+def lerp_rows(a, b, alpha):
+    return _Lerp.apply(a, b, alpha.reshape(-1))
+
+
+class _RowScale(torch.autograd.Function):
+    """out[n] = s[n] * x[n]"""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        x, s = _req(x, "x"), _req(s, "s")
+        R, L = x.shape[0], x.numel() // x.shape[0]
+        out = torch.empty_like(x)
+        check(lib.gz_rowscale(_p(x), _p(s), None, None, _p(out), R, L, 0, 0, _stream()), "rowscale")
+        ctx.save_for_backward(x, s)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        gx = _RowScale.apply(g, s) if ctx.needs_input_grad[0] else None
+        gs = _RowDot.apply(g, x) if ctx.needs_input_grad[1] else None
+        return gx, gs
+
+
+class _RowDot(torch.autograd.Function):
+    """y[n] = <a[n], b[n]>"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _req(a, "a"), _req(b, "b")
+        ctx.save_for_backward(a, b)
+        R = a.shape[0]
+        return _rowdot_raw(a.reshape(R, -1), b.reshape(R, -1), False)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = _RowScale.apply(b, g) if ctx.needs_input_grad[0] else None
+        gb = _RowScale.apply(a, g) if ctx.needs_input_grad[1] else None
+        return ga, gb
+
+
+def row_scale(x, s):
+    return _RowScale.apply(x, s.reshape(-1))
+
+
+def row_dot(a, b):
+    return _RowDot.apply(a, b)
+
+
+def row_sumsq(x):
+    """sum of squares per sample, [N, ...] -> [N]"""
+    return _RowDot.apply(x, x)
+
+
+@torch.no_grad()
+def clamp_(t, lo, hi):
+    """in-place clamp of a parameter tensor (WGAN weight clipping, lightning_module.py:160-162)."""
+    if not t.is_cuda or not t.is_contiguous() or t.dtype != torch.float32:
+        raise RuntimeError("clamp_: expected a contiguous float32 GPU tensor")
+    check(lib.gz_clamp_(_p(t), t.numel(), float(lo), float(hi), _stream()), "clamp_")
+    invalidate(t)
+    return t

@@ -1,0 +1,104 @@
+"""Minimal training harness with the semantics of the Lightning generation the reference
+targets: one optimizer is active per batch, cycling
+D x disc_freq then G x gen_freq; ``toggle_optimizer`` freezes the other network's parameters
+during ``training_step``; then ``loss.backward(); optimizer.step(); optimizer.zero_grad()``.
+
+``LightningModule`` is pytorch_lightning's when that package is importable, otherwise a small
+stand-in offering what the step classes and callbacks use (``log``, ``device``).
+"""
+import torch
+from torch import nn
+
+try:  # pragma: no cover - pytorch_lightning is not installed in the build image
+    import pytorch_lightning as _pl
+    _PLBase = _pl.LightningModule
+    HAVE_LIGHTNING = True
+except Exception:  # noqa: BLE001
+    _PLBase = None
+    HAVE_LIGHTNING = False
+
+
+class _StandInLightningModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.logged = {}
+        self.current_epoch = 0
+        self.global_step = 0
+
+    def log(self, key, value, *args, **kwargs):
+        self.logged[key] = value.detach() if torch.is_tensor(value) else value
+
+    @property
+    def device(self):
+        for p in self.parameters():
+            return p.device
+        return torch.device("cpu")
+
+
+LightningModule = _PLBase if HAVE_LIGHTNING else _StandInLightningModule
+
+
+def toggle_optimizer(module, optimizer_idx):
+    """Only the active network's parameters require grad during a training_step."""
+    for p in module.discriminator.parameters():
+        p.requires_grad_(optimizer_idx == 0)
+    for p in module.generator.parameters():
+        p.requires_grad_(optimizer_idx == 1)
+
+
+def optimizer_schedule(frequencies):
+    """Lightning's 'frequency' rule: optimizer i is used for frequencies[i] consecutive batches."""
+    order = []
+    for idx, f in enumerate(frequencies):
+        order.extend([idx] * int(f))
+    return order
+
+
+class Trainer:
+    """Drives ``module.training_step`` over an iterable of batches with optimizer alternation.
+
+    ``grad_sync`` (optional, see ddp.GradSync) averages the active network's gradients over the
+    data-parallel ranks between backward and the optimizer step."""
+
+    def __init__(self, module, grad_sync=None):
+        self.module = module
+        self.optim = module.configure_optimizers()
+        self.order = optimizer_schedule([o["frequency"] for o in self.optim])
+        self.grad_sync = grad_sync
+        self.batch_idx = 0
+
+    def active_optimizer(self, batch_idx=None):
+        i = self.batch_idx if batch_idx is None else batch_idx
+        return self.order[i % len(self.order)]
+
+    def step(self, batch):
+        idx = self.active_optimizer()
+        m = self.module
+        toggle_optimizer(m, idx)
+        if self.grad_sync is not None:
+            self.grad_sync.before_step(idx)
+        loss = m.training_step(batch, self.batch_idx, idx)
+        loss.backward()
+        opt = self.optim[idx]["optimizer"]
+        if self.grad_sync is not None:
+            self.grad_sync.after_backward(idx, opt)
+        else:
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        self.batch_idx += 1
+        return loss.detach(), idx
+
+    def end_epoch(self):
+        for o in self.optim:
+            sch = o.get("lr_scheduler")
+            if sch is not None:
+                sch.step()
+        if hasattr(self.module, "current_epoch"):
+            try:
+                self.module.current_epoch += 1
+            except AttributeError:
+                pass
+
+    def finish(self):
+        if self.grad_sync is not None:
+            self.grad_sync.flush()
