@@ -7,9 +7,12 @@ Run in the build container only (the reference does not exist on the GPU box):
     python tests/golden/make_golden.py            # all fixtures
     python tests/golden/make_golden.py dc_gan     # one experiment
 
-Each fixture holds the scenario inputs (``in/...``) and everything
-tests/scenario.py records (``out/...``).  'tiny' fixtures store full tensors,
-'full' fixtures (features 64) store (norm, sum, 16 samples) summaries.
+Each fixture holds the latent / alpha inputs (``in/...``; the synthetic reals are regenerated
+from their seeds and pinned by a checksum), everything tests/scenario.py records (``out/...``)
+and, per recorded quantity, the reference's own fp32 rounding sensitivity ``cond/...`` = relative
+discrepancy between its fp32 and fp64 runs (L2 for tensors).  'tiny' fixtures store full tensors,
+'full' fixtures (features 64) store (norm, sum, 16 samples) summaries.  ``*_stable`` fixtures use
+scenario.stabilise() (all ReLU masks away from the threshold).
 """
 import os
 import sys
@@ -53,29 +56,66 @@ def build_reference_step(expt, size):
     return cls(cfg, logging_dir=None), ns
 
 
+def run_reference(expt, size, stable, dtype, full, inputs):
+    step, ns = build_reference_step(expt, size)
+    proxy = _TorchProxy()
+    ns.utils.torch = proxy
+
+    def set_alpha(_step, alpha, proxy=proxy):
+        proxy.alpha = alpha
+
+    try:
+        out = scenario.run_scenario(step, inputs, "cpu", full=full, set_alpha=set_alpha, stable=stable,
+                                    dtype=dtype)
+    finally:
+        ns.utils.torch = torch
+    return out
+
+
+def sensitivity(o32, o64):
+    cond = {}
+    for k, a in o32.items():
+        a = np.asarray(a, dtype=np.float64)
+        b = np.asarray(o64[k], dtype=np.float64)
+        if a.dtype.kind in "iu" or np.asarray(o32[k]).dtype.kind in "iu":
+            continue
+        if a.ndim == 0:
+            cond[k] = abs(a - b) / max(abs(b), 1e-30)
+        else:
+            cond[k] = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+    return cond
+
+
 def main(argv):
-    torch.set_num_threads(4)
+    torch.set_num_threads(8)
     expts = argv or list(scenario.STD_EXPTS)
     for expt in expts:
-        for size in ("tiny", "full"):
-            step, ns = build_reference_step(expt, size)
-            proxy = _TorchProxy()
-            ns.utils.torch = proxy
-
-            def set_alpha(_step, alpha, proxy=proxy):
-                proxy.alpha = alpha
-
-            inputs = scenario.make_inputs(expt, size)
-            out = scenario.run_scenario(step, inputs, "cpu", full=(size == "tiny"),
-                                        set_alpha=set_alpha)
-            ns.utils.torch = torch
-            blob = {"in/" + k: v.numpy() for k, v in inputs.items()}
+        variants = [("tiny", False), ("full", False)]
+        if expt != "wgan":      # WGAN clamps every D parameter to +-0.01, norm biases included
+            variants.append(("full", True))
+        for size, stable in variants:
+            full = size == "tiny"
+            inputs = scenario.make_inputs(expt, size, stable)      # drawn in fp32, shared by both runs
+            out = run_reference(expt, size, stable, torch.float32, full, inputs)
+            # fp64 run of the same reference code: how well-defined is each quantity in fp32?
+            torch.set_default_dtype(torch.float64)
+            try:
+                o64 = run_reference(expt, size, stable, torch.float64, True, inputs)
+            finally:
+                torch.set_default_dtype(torch.float32)
+            o32_full = out if full else run_reference(expt, size, stable, torch.float32, True, inputs)
+            cond = sensitivity(o32_full, o64)
+            blob = {"in/" + k: v.numpy() for k, v in inputs.items() if not k.startswith("real_")}
+            blob["in/real_checksum"] = np.float64(sum(float(v.double().sum()) for k, v in sorted(inputs.items())
+                                                      if k.startswith("real_")))
             blob.update({"out/" + k: np.asarray(v) for k, v in out.items()})
-            path = os.path.join(HERE, f"{expt}_{size}.npz")
+            blob.update({"cond/" + k: np.float64(v) for k, v in cond.items()})
+            path = os.path.join(HERE, f"{expt}_{size}{'_stable' if stable else ''}.npz")
             np.savez_compressed(path, **blob)
+            worst = sorted(((v, k) for k, v in cond.items()), reverse=True)[:2]
             print(f"{path}: {len(blob)} arrays, {os.path.getsize(path) / 1e6:.2f} MB, "
                   f"loss_d0={out['loss_d0']:.6f} loss_g0={out['loss_g0']:.6f} "
-                  f"loss_d1={out['loss_d1']:.6f} loss_g1={out['loss_g1']:.6f}")
+                  f"loss_d1={out['loss_d1']:.6f} loss_g1={out['loss_g1']:.6f}  worst cond {worst}")
 
 
 if __name__ == "__main__":

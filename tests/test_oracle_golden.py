@@ -21,30 +21,81 @@ def build_oracle_step(expt, size):
     return locate(cfg.model.lm["_target_"])(cfg, logging_dir=None)
 
 
-def load_golden(expt, size):
-    blob = np.load(os.path.join(GOLDEN_DIR, f"{expt}_{size}.npz"))
-    inputs = {k[3:]: torch.from_numpy(blob[k]) for k in blob.files if k.startswith("in/")}
+def load_golden(expt, size, stable=False):
+    """-> (inputs, golden outputs, cond).  The synthetic reals are regenerated from their seeds
+    and checked against the fixture's checksum; z / alpha come from the fixture."""
+    blob = np.load(os.path.join(GOLDEN_DIR, f"{expt}_{size}{'_stable' if stable else ''}.npz"))
+    inputs = scenario.make_inputs(expt, size, stable)
+    for k in blob.files:
+        if k.startswith("in/") and k != "in/real_checksum":
+            assert torch.equal(inputs[k[3:]], torch.from_numpy(blob[k])), f"host RNG drift in {k}"
+    chk = sum(float(v.double().sum()) for k, v in sorted(inputs.items()) if k.startswith("real_"))
+    assert abs(chk - float(blob["in/real_checksum"])) < 1e-6 * max(1.0, abs(chk)), "host RNG drift in reals"
     golden = {k[4:]: blob[k] for k in blob.files if k.startswith("out/")}
-    return inputs, golden
+    cond = {k[5:]: float(blob[k]) for k in blob.files if k.startswith("cond/")}
+    return inputs, golden, cond
 
 
-def compare(out, golden, tol, label, atol_scale=None):
+STRICT_PREFIXES = ("probe/", "buf_")
+
+
+def compare(out, golden, tol, label, atol_scale=None, cond=None, cond_factor=10.0, final_abs=0.0):
+    """Every recorded quantity within ``tol`` of the fixture, relative to the largest reference
+    magnitude of that quantity (scalars: relative to max(|ref|, atol_scale), where atol_scale is
+    the logit scale -- WGAN losses are differences of logit means).  Integer tensors (BatchNorm
+    ``num_batches_tracked``) must be bit-exact.
+
+    ``cond`` (from the fixture) is the reference's OWN fp32 rounding sensitivity per quantity: the
+    relative discrepancy between its fp32 and fp64 runs.  Gradients that pass through ReLU /
+    LeakyReLU masks whose pre-activation is zero up to rounding are only defined to that
+    accuracy by the fp32 reference itself (up to 4e-2 for G gradients of the features-64 nets),
+    so for non-forward quantities the bar is max(tol, cond_factor * cond[k]) on the relative L2
+    error.  Forward quantities (``probe/``, norm buffers) always use ``tol`` in max-norm, and the
+    ``*_stable`` fixtures (masks kept away from the threshold) have cond <= 3e-4 throughout.
+
+    ``final/*`` (parameters after the optimizer steps) additionally accept ``final_abs`` absolute
+    slack per element: Adam's first steps are lr*g/(|g|+eps) = +-lr whatever |g| is, so an entry
+    whose gradient is zero up to rounding can land on either side."""
     assert set(out) == set(golden), sorted(set(out) ^ set(golden))[:5]
-    worst = (0.0, None)
+    errs = []
     for k, ref in golden.items():
         got = np.asarray(out[k])
         assert got.shape == ref.shape, (k, got.shape, ref.shape)
         if ref.dtype.kind in "iu":                     # counters: bit-exact
             assert np.array_equal(got, ref), k
             continue
+        t = tol
+        if cond is None and k.startswith("final/"):
+            # same torch CPU kernels, but their summation order depends on the thread count and
+            # Adam / RMSprop normalise the step: +-1e-6 gradients become +-lr differences
+            t = max(tol, 2e-4)
+        strict = k.startswith(STRICT_PREFIXES)
+        if cond is not None and not strict:
+            t = max(tol, cond_factor * cond.get(k, 0.0))
+        g64, r64 = got.astype(np.float64).ravel(), ref.astype(np.float64).ravel()
         if ref.ndim == 0:
             scale = max(abs(float(ref)), atol_scale or 0.0, 1e-30)
             e = abs(float(got) - float(ref)) / scale
-        else:
+        elif strict or cond is None:
             e = rel_err(got, ref)
-        if e > worst[0]:
-            worst = (e, k)
-    assert worst[0] <= tol, f"{label}: worst rel err {worst[0]:.3e} at {worst[1]}"
+        else:
+            summary = g64.size == 18 and ref.ndim == 1     # [l2 norm, sum, 16 sampled entries]
+            if summary:
+                e = abs(g64[0] - r64[0]) / max(abs(r64[0]), 1e-30)
+                d = np.abs(g64[2:] - r64[2:])
+                scale = max(np.abs(r64[2:]).max(), r64[0] * 1e-3, 1e-30)
+            else:
+                e = np.linalg.norm(g64 - r64) / max(np.linalg.norm(r64), 1e-30)
+                d = np.abs(g64 - r64)
+                scale = max(np.abs(r64).max(), 1e-30)
+            slack = final_abs if k.startswith("final/") else 0.0
+            # individual entries: 10x the L2 bar (a single flipped mask entry is a local O(1) change)
+            e = max(e, max(d.max() - slack, 0.0) / scale / 10.0)
+        errs.append((e / t, e, t, k))
+    errs.sort(reverse=True)
+    worst = errs[0]
+    assert worst[0] <= 1.0, (f"{label}: {worst[3]} rel err {worst[1]:.3e} > bar {worst[2]:.3e}; "
+                             f"next: {[(k, f'{e:.1e}/{t:.1e}') for _, e, t, k in errs[1:4]]}")
     return worst
 
 
@@ -56,11 +107,21 @@ def set_alpha(step, alpha):
 @pytest.mark.parametrize("expt", scenario.STD_EXPTS)
 def test_oracle_matches_reference_fixture(expt, size):
     torch.set_num_threads(4)
-    inputs, golden = load_golden(expt, size)
+    inputs, golden, _ = load_golden(expt, size)
     step = build_oracle_step(expt, size)
     out = scenario.run_scenario(step, inputs, "cpu", full=(size == "tiny"), set_alpha=set_alpha)
     scale = float(np.abs(golden["probe/logits"]).max())
-    compare(out, golden, 1e-5, f"oracle {expt}/{size}", atol_scale=scale)
+    compare(out, golden, 1e-5, f"oracle {expt}/{size}", atol_scale=scale)      # no conditioning slack
+
+
+@pytest.mark.parametrize("expt", ["dc_gan", "wgan_gp"])
+def test_oracle_matches_stable_mask_fixture(expt):
+    torch.set_num_threads(4)
+    inputs, golden, _ = load_golden(expt, "full", stable=True)
+    step = build_oracle_step(expt, "full")
+    out = scenario.run_scenario(step, inputs, "cpu", full=False, set_alpha=set_alpha, stable=True)
+    scale = float(np.abs(golden["probe/logits"]).max())
+    compare(out, golden, 1e-5, f"oracle {expt}/full/stable", atol_scale=scale)
 
 
 def test_oracle_state_dict_names_match_reference_listing():
