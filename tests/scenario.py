@@ -82,12 +82,30 @@ def _buffers(prefix, step, out):
             out[f"{prefix}/{net}.{name}"] = b.detach().cpu().numpy().copy()
 
 
+def initial_params(step, full=True, stable=False):
+    """The closed-form starting point in the same format as run_scenario's ``final/`` entries."""
+    fill_closed_form(step.generator, 1)
+    fill_closed_form(step.discriminator, 2)
+    if stable:
+        stabilise(step)
+    out = {}
+    _dump("final/generator", step.generator.named_parameters(), out, full)
+    _dump("final/discriminator", step.discriminator.named_parameters(), out, full)
+    return out
+
+
 def run_scenario(step, inputs, device="cpu", full=True, set_alpha=None, pairs=2, stable=False,
-                 dtype=torch.float32):
+                 dtype=torch.float32, shadow=None):
     """``set_alpha(step, alpha)`` installs the GP interpolation coefficients for
     implementations that accept injection; the reference draws them from the
     host RNG, so make_golden.py patches torch.rand instead.  ``dtype=float64`` is used only to
-    measure the reference's own fp32 rounding sensitivity (the ``cond/`` entries of a fixture)."""
+    measure the reference's own fp32 rounding sensitivity (the ``cond/`` entries of a fixture).
+
+    ``shadow``: a CPU oracle step.  Before every training_step of pair >= 1 it is loaded with the
+    state_dict of ``step`` (as trained so far) and evaluates the same batch; its loss is recorded
+    as ``shadow_loss_*``.  Losses after optimizer steps cannot be compared with a fixture at 1e-3
+    (Adam turns rounding-level gradient differences into +-lr parameter differences), but they
+    can be compared with the oracle evaluated on the very same parameters."""
     dev = torch.device(device)
     fill_closed_form(step.generator, 1)
     fill_closed_form(step.discriminator, 2)
@@ -117,6 +135,16 @@ def run_scenario(step, inputs, device="cpu", full=True, set_alpha=None, pairs=2,
             if set_alpha is not None:
                 set_alpha(step, inputs[f"alpha{pair}"])
             _toggle(step, idx)
+            if shadow is not None and pair >= 1:
+                for net in ("generator", "discriminator"):
+                    sd = {k: v.detach().cpu() for k, v in getattr(step, net).state_dict().items()}
+                    getattr(shadow, net).load_state_dict(sd)
+                shadow.noise_distn = FixedNoise(inputs[f"z_{tag}{pair}"])
+                if set_alpha is not None:
+                    set_alpha(shadow, inputs[f"alpha{pair}"])
+                _toggle(shadow, idx)
+                sl = shadow.training_step((inputs[f"real_{tag}{pair}"], labels.cpu()), 2 * pair + idx, idx)
+                out[f"shadow_loss_{tag}{pair}"] = np.float64(sl.item())
             loss = step.training_step((real, labels), 2 * pair + idx, idx)
             loss.backward()
             out[f"loss_{tag}{pair}"] = np.float64(loss.item())
