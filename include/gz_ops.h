@@ -66,6 +66,9 @@ size_t gz_conv2d_wgrad_workspace_bytes(int N, int C, int H, int W, int K, int OH
 int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* workspace, size_t ws_bytes, int N, int C,
                     int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream);
 
+/* diagnostic: tile configuration a launch would use (op 0 F, 1 Dg, 2 Wg) -> 0 128x128, 1 128x64, 2 128x32, 3 64x64 */
+int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S);
+
 /* c[M,N] = act(op(a) . op(b) + bias[n]); trans_a: a stored [K][M]; trans_b: b stored [N][K].
  * Replaces the 1x1 -> 4x4 ConvTranspose2d of the generator's first block (standard_networks.py:60),
  * its weight gradient, and nn.Linear. */

@@ -15,7 +15,7 @@ import torch
 
 from .. import functional as F
 from ..config import instantiate
-from ..harness import LightningModule
+from ..harness import LightningModule, draw_on_host
 from .utils.utils import gradient_penalty
 
 
@@ -56,8 +56,9 @@ class BaseGAN(LightningModule):
         pass
 
     def sample_noise(self, n):
-        # drawn on the host generator, then copied to the device (reference :107-108)
-        return self.noise_distn.sample((n, self.cfg.model.noise_dim)).to(self.device)
+        # drawn on the host generator, then copied to the device (reference :107-108); single host
+        # thread + pinned staging, see harness.few_host_threads / HostStager
+        return draw_on_host(lambda: self.noise_distn.sample((n, self.cfg.model.noise_dim)), self.device)
 
     def validation_step(self, batch, batch_idx):
         real, _ = batch
@@ -96,6 +97,8 @@ class DCGAN(BaseGAN):
 
 
 class WGAN(BaseGAN):
+    mutates_discriminator_before_forward = True     # tells ddp.GradSync not to defer D's step past the clamp
+
     def training_step(self, batch, batch_idx, optimizer_idx):
         clip = self.cfg.train.weight_clip
         for p in self.discriminator.parameters():       # every call, both branches (reference :160-162)

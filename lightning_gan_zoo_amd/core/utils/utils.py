@@ -3,6 +3,7 @@ import torch
 from torch import nn
 
 from ... import functional as F
+from ...harness import draw_on_host
 
 
 @torch.no_grad()
@@ -24,9 +25,9 @@ def gradient_penalty(critic, real, fake, device="cpu", alpha=None):
     per-sample squared norm and their second-order backward all run on the HIP kernels.
     """
     bs = real.shape[0]
-    if alpha is None:
-        alpha = torch.rand((bs, 1, 1, 1))
-    alpha = alpha.reshape(bs).to(device=real.device, dtype=torch.float32)
+    given = alpha
+    alpha = draw_on_host(lambda: (torch.rand((bs, 1, 1, 1)) if given is None else given).reshape(bs).float(),
+                         real.device)
     interpolated_images = F.lerp_rows(real, fake, alpha)
     interpolated_images.requires_grad_()
     mixed_scores = critic(interpolated_images)

@@ -76,4 +76,9 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? GZ_OK : GZ_ERR_HI
 
 inline int launch_status() { return hip_status(hipGetLastError()); }
 
+// hipGetLastError is sticky per host thread: an unrelated, already-handled failure inside another
+// library (e.g. a pointer-attribute query on host memory) would otherwise be reported by the next
+// launcher.  Every C-ABI entry point clears it before its own launches.
+inline void clear_stale_error() { (void)hipGetLastError(); }
+
 }  // namespace gz

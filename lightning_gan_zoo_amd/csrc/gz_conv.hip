@@ -290,6 +290,7 @@ long long gz_conv2d_pack_dgrad_elems(int K, int C, int KH, int KW, int S) {
 }
 
 int gz_conv2d_pack_fwd(const float* w, float* wp, int K, int C, int KH, int KW, hipStream_t stream) {
+    gz::clear_stale_error();
     if (K <= 0 || C <= 0 || KH <= 0 || KW <= 0) return GZ_ERR_BAD_SHAPE;
     int Kg = C * KH * KW, ld = round4(K);
     dim3 grid((Kg + 31) / 32, (ld + 31) / 32);
@@ -299,6 +300,7 @@ int gz_conv2d_pack_fwd(const float* w, float* wp, int K, int C, int KH, int KW, 
 
 int gz_conv2d_pack_dgrad(const float* w, float* wp, int K, int C, int KH, int KW, int S, int P,
                          hipStream_t stream) {
+    gz::clear_stale_error();
     if (K <= 0 || C <= 0 || KH <= 0 || KW <= 0 || S <= 0) return GZ_ERR_BAD_SHAPE;
     int TY = (KH + S - 1) / S, TX = (KW + S - 1) / S;
     hipLaunchKernelGGL(pack_dgrad_kernel, dim3(K, S * S), dim3(256), 0, stream, w, wp, K, C, KH, KW, S, P, TY, TX,
@@ -308,6 +310,7 @@ int gz_conv2d_pack_dgrad(const float* w, float* wp, int K, int C, int KH, int KW
 
 int gz_conv2d_fwd(const float* x, const float* wpack, const float* bias, float* y, int N, int C, int H, int W,
                   int K, int OH, int OW, int KH, int KW, int S, int P, int act, float slope, hipStream_t stream) {
+    gz::clear_stale_error();
     ConvShape s{N, C, H, W, K, OH, OW};
     if (!shape_ok(s, KH, KW, S, P)) return GZ_ERR_BAD_SHAPE;
     if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
@@ -320,6 +323,7 @@ int gz_conv2d_fwd(const float* x, const float* wpack, const float* bias, float* 
 int gz_conv2d_dgrad(const float* y, const float* wpack, const float* bias, float* x, int N, int C, int H, int W,
                     int K, int OH, int OW, int KH, int KW, int S, int P, int act, float slope,
                     hipStream_t stream) {
+    gz::clear_stale_error();
     ConvShape s{N, C, H, W, K, OH, OW};
     if (!shape_ok(s, KH, KW, S, P)) return GZ_ERR_BAD_SHAPE;
     if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
@@ -340,6 +344,7 @@ size_t gz_conv2d_wgrad_workspace_bytes(int N, int C, int H, int W, int K, int OH
 
 int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* workspace, size_t ws_bytes, int N, int C,
                     int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream) {
+    gz::clear_stale_error();
     ConvShape s{N, C, H, W, K, OH, OW};
     if (!shape_ok(s, KH, KW, S, P)) return GZ_ERR_BAD_SHAPE;
     if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
@@ -348,8 +353,23 @@ int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* workspace,
 #undef CALL
 }
 
+/* which tile configuration a launch of op (0 F, 1 Dg, 2 Wg) would use: 0 128x128, 1 128x64, 2 128x32, 3 64x64 */
+int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S) {
+    if (op == 0) return pick_tile((long long)N * OH * OW, K, 1);
+    if (op == 1) return pick_tile((long long)N * (H / S) * (W / S), C, S * S);
+    long long NTOT = (long long)C * KH * KW;
+    int t;
+    if (NTOT <= 32) t = T128x32;
+    else if (NTOT <= 64 || K <= 64) t = (K <= 64 ? T64x64 : T128x64);
+    else t = T128x128;
+    int f = forced_tile();
+    if (f >= 0 && f <= 3 && !(f == T128x128 && NTOT <= 64)) t = f;
+    return t;
+}
+
 int gz_gemm(const float* a, const float* b, const float* bias, float* c, int M, int N, int K, int lda, int ldb,
             int ldc, int trans_a, int trans_b, int act, float slope, hipStream_t stream) {
+    gz::clear_stale_error();
     if (M <= 0 || N <= 0 || K <= 0) return GZ_ERR_BAD_SHAPE;
     if (too_large((long long)M * K) || too_large((long long)K * N) || too_large((long long)M * N)) return GZ_ERR_TOO_LARGE;
     switch (pick_tile(M, N, 1)) {

@@ -104,6 +104,7 @@ using namespace gz;
 extern "C" {
 
 int gz_rowdot(const float* a, const float* b, float* y, int R, int L, int b_broadcast, hipStream_t stream) {
+    gz::clear_stale_error();
     if (R <= 0 || L <= 0 || (L & 3)) return GZ_ERR_BAD_SHAPE;
     int blocks = (R + 3) / 4;
     if (blocks > 2048) blocks = 2048;
@@ -113,6 +114,7 @@ int gz_rowdot(const float* a, const float* b, float* y, int R, int L, int b_broa
 
 int gz_rowscale(const float* x, const float* s, const float* x2, const float* s2, float* out, int R, int L,
                 int x_broadcast, int one_minus_s, hipStream_t stream) {
+    gz::clear_stale_error();
     if (R <= 0 || L <= 0 || (L & 3)) return GZ_ERR_BAD_SHAPE;
     long long total4 = (long long)R * (L / 4);
     if (total4 >= (1ll << 31)) return GZ_ERR_TOO_LARGE;
@@ -128,6 +130,7 @@ size_t gz_coldot_workspace_bytes(int R, int L) {
 
 int gz_coldot(const float* g, const float* x, float* out, float* workspace, size_t ws_bytes, int R, int L,
               hipStream_t stream) {
+    gz::clear_stale_error();
     if (R <= 0 || L <= 0 || (L & 3)) return GZ_ERR_BAD_SHAPE;
     int slices = R >= 64 ? 32 : 1;
     if (slices > 1 && ws_bytes < (size_t)slices * L * 4) return GZ_ERR_WORKSPACE;
@@ -141,6 +144,7 @@ int gz_coldot(const float* g, const float* x, float* out, float* workspace, size
 }
 
 int gz_clamp_(float* p, long long count, float lo, float hi, hipStream_t stream) {
+    gz::clear_stale_error();
     if (count <= 0) return GZ_ERR_BAD_SHAPE;
     hipLaunchKernelGGL(clamp_kernel, dim3(grid_for(count)), dim3(MT), 0, stream, p, count, lo, hi);
     return launch_status();

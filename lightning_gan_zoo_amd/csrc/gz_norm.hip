@@ -442,6 +442,7 @@ int gz_norm_coef_elems(int N, int C, int per_channel) { return 4 * (per_channel 
 int gz_batchnorm_stats(const float* x, const float* gamma, const float* beta, float* coef, float* running_mean,
                        float* running_var, long long* num_batches_tracked, void* workspace, int N, int C,
                        int inner, float eps, float momentum, hipStream_t stream) {
+    gz::clear_stale_error();
     if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
     RowGeom g = row_geom((long long)N * C, inner);
     hipLaunchKernelGGL(row_sums_kernel, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, (f32x2*)workspace, g);
@@ -452,6 +453,7 @@ int gz_batchnorm_stats(const float* x, const float* gamma, const float* beta, fl
 
 int gz_batchnorm_eval_coef(const float* gamma, const float* beta, const float* running_mean,
                            const float* running_var, float* coef, int C, float eps, hipStream_t stream) {
+    gz::clear_stale_error();
     if (C <= 0) return GZ_ERR_BAD_SHAPE;
     hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, gamma, beta, running_mean,
                        running_var, coef, C, eps);
@@ -460,6 +462,7 @@ int gz_batchnorm_eval_coef(const float* gamma, const float* beta, const float* r
 
 int gz_rownorm_stats(const float* x, const float* gamma, const float* beta, float* coef, void* workspace, int N,
                      int C, int inner, float eps, int affine_per_row, int unbiased, hipStream_t stream) {
+    gz::clear_stale_error();
     if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
     RowGeom g = row_geom((long long)N * C, inner);
     hipLaunchKernelGGL(row_sums_kernel, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, (f32x2*)workspace, g);
@@ -471,6 +474,7 @@ int gz_rownorm_stats(const float* x, const float* gamma, const float* beta, floa
 
 int gz_norm_act_fwd(const float* x, const float* coef, float* out, int N, int C, int inner, int per_channel,
                     int act, float slope, hipStream_t stream) {
+    gz::clear_stale_error();
     if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
     ApplyGeom g = apply_geom(N, C, inner, per_channel);
     hipLaunchKernelGGL(norm_act_apply_kernel, dim3(ew_grid(g.total4)), dim3(PW_THREADS), 0, stream, x, coef, out, g,
@@ -481,6 +485,7 @@ int gz_norm_act_fwd(const float* x, const float* coef, float* out, int N, int C,
 int gz_norm_act_bwd(const float* gout, const float* x, const float* coef, float* dx, float* dgamma, float* dbeta,
                     void* workspace, float* kbuf, int N, int C, int inner, int per_channel, int affine_per_row,
                     int act, float slope, hipStream_t stream) {
+    gz::clear_stale_error();
     if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
     RowGeom rg = row_geom((long long)N * C, inner);
     ApplyGeom g = apply_geom(N, C, inner, per_channel);
@@ -503,6 +508,7 @@ int gz_norm_act_bwd(const float* gout, const float* x, const float* coef, float*
 int gz_rownorm_act_bwd2(const float* gout, const float* v, const float* x, const float* coef, float* gg_out,
                         float* gx, float* ggamma, void* workspace, int N, int C, int inner, int act, float slope,
                         hipStream_t stream) {
+    gz::clear_stale_error();
     if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
     RowGeom rg = row_geom((long long)N * C, inner);
     ApplyGeom g = apply_geom(N, C, inner, 0);
@@ -519,6 +525,7 @@ int gz_rownorm_act_bwd2(const float* gout, const float* v, const float* x, const
 
 int gz_act_bwd(const float* g, const float* out, float* dx, long long count, int act, float slope,
                hipStream_t stream) {
+    gz::clear_stale_error();
     if (count <= 0 || (count & 3)) return GZ_ERR_BAD_SHAPE;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(count / 4)), dim3(PW_THREADS), 0, stream, g, out, dx, count / 4,
                        act, slope);

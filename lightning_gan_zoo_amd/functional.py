@@ -47,6 +47,46 @@ def out_size(n, g):
 
 
 # ---------------------------------------------------------------------------
+# optional per-launch timing (bench.py): HIP events recorded on the stream the kernel is launched
+# on, around each implicit-GEMM launch.  Off by default; costs nothing when off.
+# ---------------------------------------------------------------------------
+class KernelTimer:
+    def __init__(self):
+        self.records = []      # (label, flops, start_event, end_event)
+
+    def summary(self):
+        """{label: (launches, total_ms, total_flops)} -- call after a device synchronize."""
+        agg = {}
+        for label, flops, s, e in self.records:
+            n, ms, fl = agg.get(label, (0, 0.0, 0.0))
+            agg[label] = (n + 1, ms + s.elapsed_time(e), fl + flops)
+        return agg
+
+
+_timer = None
+_TILES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "64x64"}
+
+
+def set_kernel_timer(timer):
+    global _timer
+    _timer = timer
+
+
+def _timed(op, shape, geom, flops, launch):
+    if _timer is None:
+        return launch()
+    N, C, H, W, K, OH, OW = shape
+    tile = lib.gz_conv2d_tile(op, N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride)
+    label = "igemm<%s,%s>" % (("F", "Dg", "Wg")[op], _TILES.get(tile, "?"))
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = launch()
+    e.record()
+    _timer.records.append((label, flops, s, e))
+    return r
+
+
+# ---------------------------------------------------------------------------
 # packed weights (GEMM-B images).  Cached per Parameter object and version so the three
 # discriminator passes of one step share one pack.
 # ---------------------------------------------------------------------------
@@ -95,8 +135,9 @@ def _conv_fwd_raw(x, w, bias, geom, act, slope):
     OH, OW = out_size(H, geom), out_size(W, geom)
     y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
     wp = _packed(w, "f", geom)
-    check(lib.gz_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(y), N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
-                            geom.pad, act, slope, _stream()), "conv2d_fwd")
+    _timed(0, (N, C, H, W, K, OH, OW), geom, 2.0 * N * OH * OW * K * C * geom.kh * geom.kw, lambda: check(
+        lib.gz_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(y), N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
+                          geom.pad, act, slope, _stream()), "conv2d_fwd"))
     return y
 
 
@@ -106,8 +147,9 @@ def _conv_dgrad_raw(g, w, bias, geom, hw, act, slope):
     H, W = hw
     x = torch.empty((N, C, H, W), device=g.device, dtype=torch.float32)
     wp = _packed(w, "d", geom)
-    check(lib.gz_conv2d_dgrad(_p(g), _p(wp), _p(bias), _p(x), N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
-                              geom.pad, act, slope, _stream()), "conv2d_dgrad")
+    _timed(1, (N, C, H, W, K, OH, OW), geom, 2.0 * N * OH * OW * K * C * geom.kh * geom.kw, lambda: check(
+        lib.gz_conv2d_dgrad(_p(g), _p(wp), _p(bias), _p(x), N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
+                            geom.pad, act, slope, _stream()), "conv2d_dgrad"))
     return x
 
 
@@ -117,8 +159,9 @@ def _conv_wgrad_raw(x, g, geom):
     dw = torch.empty((K, C, geom.kh, geom.kw), device=x.device, dtype=torch.float32)
     nbytes = lib.gz_conv2d_wgrad_workspace_bytes(N, C, H, W, K, OH, OW, geom.kh, geom.kw)
     ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
-    check(lib.gz_conv2d_wgrad(_p(x), _p(g), _p(dw), _p(ws), nbytes, N, C, H, W, K, OH, OW, geom.kh, geom.kw,
-                              geom.stride, geom.pad, _stream()), "conv2d_wgrad")
+    _timed(2, (N, C, H, W, K, OH, OW), geom, 2.0 * N * OH * OW * K * C * geom.kh * geom.kw, lambda: check(
+        lib.gz_conv2d_wgrad(_p(x), _p(g), _p(dw), _p(ws), nbytes, N, C, H, W, K, OH, OW, geom.kh, geom.kw,
+                            geom.stride, geom.pad, _stream()), "conv2d_wgrad"))
     return dw
 
 

@@ -6,6 +6,8 @@ during ``training_step``; then ``loss.backward(); optimizer.step(); optimizer.ze
 ``LightningModule`` is pytorch_lightning's when that package is importable, otherwise a small
 stand-in offering what the step classes and callbacks use (``log``, ``device``).
 """
+import contextlib
+
 import torch
 from torch import nn
 
@@ -36,6 +38,73 @@ class _StandInLightningModule(nn.Module):
 
 
 LightningModule = _PLBase if HAVE_LIGHTNING else _StandInLightningModule
+
+
+@contextlib.contextmanager
+def few_host_threads(n=1):
+    """Run tiny host-side tensor ops (noise draw, staging copy) on ``n`` intra-op threads.
+
+    With the default thread count (= cores) every small CPU op wakes the whole OpenMP team, whose
+    idle workers then spin; under a container CPU quota that gets the process throttled for tens of
+    milliseconds every few steps -- the GPU queue starves although the host does almost nothing
+    (measured on the MI355X box: 60-300 ms stalls per step, gone with one thread).  The values drawn
+    do not depend on the thread count (CPU random kernels consume the generator serially)."""
+    old = torch.get_num_threads()
+    if old != n:
+        torch.set_num_threads(n)
+    try:
+        yield
+    finally:
+        if old != n:
+            torch.set_num_threads(old)
+
+
+def draw_on_host(fn, device):
+    """``fn()`` draws a small tensor on the host generator; returns it on ``device``."""
+    with few_host_threads(1):
+        t = fn()
+        return _stager.to_device(t, device)
+
+
+class HostStager:
+    """Host -> device hand-off for small per-step tensors drawn on the HOST generator (latent noise,
+    gradient-penalty alpha).  The reference does ``sample(...).to(device)`` from pageable memory
+    (core/lightning_module.py:107-108); on ROCm a pageable hipMemcpy drains the stream and stalls
+    for tens of ms every few calls (measured: 50-180 ms, i.e. more than the whole G+D pair), so the
+    same values go through a small ring of pinned buffers and an asynchronous copy instead.  The
+    host RNG stream, the values and the device they land on are unchanged."""
+
+    def __init__(self, depth=4):
+        self.depth = depth
+        self.slots = {}     # (shape, dtype) -> [buffers, events, cursor]
+
+    def to_device(self, t, device):
+        device = torch.device(device)
+        if device.type != "cuda" or t.is_cuda:
+            return t.to(device)
+        key = (tuple(t.shape), t.dtype)
+        slot = self.slots.get(key)
+        if slot is None:
+            slot = [[torch.empty(t.shape, dtype=t.dtype).pin_memory() for _ in range(self.depth)],
+                    [None] * self.depth, 0]
+            self.slots[key] = slot
+        bufs, events, cur = slot
+        if events[cur] is not None:
+            events[cur].synchronize()          # the copy that last used this buffer has completed
+        bufs[cur].copy_(t)
+        out = bufs[cur].to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        events[cur] = ev
+        slot[2] = (cur + 1) % self.depth
+        return out
+
+
+_stager = HostStager()
+
+
+def host_to_device(t, device):
+    return _stager.to_device(t, device)
 
 
 def toggle_optimizer(module, optimizer_idx):
