@@ -128,6 +128,9 @@ int gz_coldot(const float* g, const float* x, float* out, float* workspace, size
 /* p = clamp(p, lo, hi) in place (core/lightning_module.py:160-162) */
 int gz_clamp_(float* p, long long count, float lo, float hi, hipStream_t stream);
 
+/* text of the last HIP error seen by a launcher on the calling thread ("" if none) */
+const char* gz_last_error(void);
+
 /* library identification: returns the gfx target string the kernels were compiled for */
 const char* gz_build_info(void);
 

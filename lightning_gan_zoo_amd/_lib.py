@@ -67,6 +67,10 @@ class _Lib:
                 raise RuntimeError(
                     "lightning_gan_zoo_amd: HIP kernel library %s is missing; build it with "
                     "`python -m lightning_gan_zoo_amd.build` (there is no CPU fallback)" % LIB_PATH)
+            # torch ships its own libamdhip64 / libhsa-runtime64; load it first so that this library
+            # binds to the SAME HIP runtime instance (otherwise the process ends up with two runtimes
+            # and ours reports "no ROCm-capable device")
+            import torch  # noqa: F401
             dll = ctypes.CDLL(LIB_PATH)
             for name, (restype, argtypes) in parse_header().items():
                 fn = getattr(dll, name)   # AttributeError if the library does not export it
@@ -84,4 +88,10 @@ lib = _Lib()
 
 def check(rc, what):
     if rc != 0:
-        raise RuntimeError("libgz_hip: %s failed with code %d (%s)" % (what, rc, ERRORS.get(rc, "?")))
+        detail = ""
+        if rc == -4:
+            try:
+                detail = ": " + lib.gz_last_error().decode()
+            except Exception:  # noqa: BLE001
+                pass
+        raise RuntimeError("libgz_hip: %s failed with code %d (%s%s)" % (what, rc, ERRORS.get(rc, "?"), detail))

@@ -72,7 +72,16 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-inline int hip_status(hipError_t e) { return e == hipSuccess ? GZ_OK : GZ_ERR_HIP; }
+inline const char*& last_error_slot() {
+    static thread_local const char* msg = "";
+    return msg;
+}
+
+inline int hip_status(hipError_t e) {
+    if (e == hipSuccess) return GZ_OK;
+    last_error_slot() = hipGetErrorString(e);
+    return GZ_ERR_HIP;
+}
 
 inline int launch_status() { return hip_status(hipGetLastError()); }
 

@@ -152,4 +152,6 @@ int gz_clamp_(float* p, long long count, float lo, float hi, hipStream_t stream)
 
 }  // extern "C"
 
+extern "C" const char* gz_last_error(void) { return gz::last_error_slot(); }
+
 extern "C" const char* gz_build_info(void) { return "gz_hip gfx950 fp32-mfma " __DATE__; }

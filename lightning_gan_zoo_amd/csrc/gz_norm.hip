@@ -73,21 +73,24 @@ __global__ __launch_bounds__(PW_THREADS) void row_sums_kernel(const float* __res
     }
 }
 
-// BatchNorm finalize: one thread per channel, fp64 combine over n.
+// BatchNorm finalize: one wavefront per channel; lanes stride over n, fp64 shuffle-combine.
 // coef[0*C..] = scale, coef[1*C..] = shift, coef[2*C..] = mean, coef[3*C..] = rstd
-__global__ void bn_finalize_kernel(const f32x2* __restrict__ sums, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ coef,
-                                   float* running_mean, float* running_var, long long* nbt, int N, int C,
-                                   int inner, float eps, float momentum) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) *nbt += 1;
-    if (c >= C) return;
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const f32x2* __restrict__ sums,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ coef,
+                                                         float* running_mean, float* running_var, long long* nbt,
+                                                         int N, int C, int inner, float eps, float momentum) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    if (c == 0 && lane == 0 && nbt) *nbt += 1;
     double s1 = 0.0, s2 = 0.0;
-    for (int n = 0; n < N; ++n) {
+    for (int n = lane; n < N; n += 64) {
         f32x2 v = sums[(long long)n * C + c];
         s1 += (double)v.x;
         s2 += (double)v.y;
     }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if (lane != 0) return;
     double cnt = (double)N * inner;
     double mean = s1 / cnt;
     double var = s2 / cnt - mean * mean;
@@ -220,18 +223,21 @@ __global__ __launch_bounds__(PW_THREADS) void norm_bwd_rowsums_kernel(const floa
     }
 }
 
-// BatchNorm: combine row sums over n -> k[0*C] = mean(dz), k[1*C] = mean(dz*xh); dgamma, dbeta
-__global__ void bn_bwd_finalize_kernel(const f32x2* __restrict__ sums, float* __restrict__ k,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C,
-                                       int inner) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// BatchNorm: combine row sums over n -> k[0*C] = mean(dz), k[1*C] = mean(dz*xh); dgamma, dbeta.
+// One wavefront per channel.
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const f32x2* __restrict__ sums, float* __restrict__ k,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             int N, int C, int inner) {
+    const int c = blockIdx.x, lane = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int n = 0; n < N; ++n) {
+    for (int n = lane; n < N; n += 64) {
         f32x2 v = sums[(long long)n * C + c];
         s1 += (double)v.x;
         s2 += (double)v.y;
     }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if (lane != 0) return;
     double cnt = (double)N * inner;
     k[c] = (float)(s1 / cnt);
     k[C + c] = (float)(s2 / cnt);
@@ -239,7 +245,7 @@ __global__ void bn_bwd_finalize_kernel(const f32x2* __restrict__ sums, float* __
     if (dbeta) dbeta[c] = (float)s1;
 }
 
-// per-row statistics: k = sums / inner; dgamma/dbeta[c] = sum over n (per-channel affine) or per row
+// per-row statistics: k = sums / inner (and per-row dgamma / dbeta for AdaIN-style affine)
 __global__ void row_bwd_finalize_kernel(const f32x2* __restrict__ sums, float* __restrict__ k,
                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C,
                                         int inner, int affine_per_row) {
@@ -254,16 +260,24 @@ __global__ void row_bwd_finalize_kernel(const f32x2* __restrict__ sums, float* _
             if (dbeta) dbeta[i] = v.x;
         }
     }
-    if (!affine_per_row && i < C && (dgamma || dbeta)) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int n = 0; n < N; ++n) {
-            f32x2 v = sums[(long long)n * C + i];
-            s1 += (double)v.x;
-            s2 += (double)v.y;
-        }
-        if (dgamma) dgamma[i] = (float)s2;
-        if (dbeta) dbeta[i] = (float)s1;
+}
+
+// per-channel affine over per-row statistics (InstanceNorm): dgamma[c] = sum_n s2[n,c], dbeta[c] = sum_n s1[n,c]
+__global__ __launch_bounds__(64) void row_bwd_affine_kernel(const f32x2* __restrict__ sums,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int N, int C) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = lane; n < N; n += 64) {
+        f32x2 v = sums[(long long)n * C + c];
+        s1 += (double)v.x;
+        s2 += (double)v.y;
     }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if (lane != 0) return;
+    if (dgamma) dgamma[c] = (float)s2;
+    if (dbeta) dbeta[c] = (float)s1;
 }
 
 __global__ __launch_bounds__(PW_THREADS) void norm_bwd_apply_kernel(const float* __restrict__ gout,
@@ -370,21 +384,22 @@ __global__ __launch_bounds__(PW_THREADS) void norm_bwd2_apply_kernel(
     }
 }
 
-// ggamma[c] = sum_n rstd[n,c] * inner * (mvg - mv*mg - mvx*c)
-__global__ void norm_bwd2_ggamma_kernel(const Sums5* __restrict__ sums, const float* __restrict__ coef,
-                                        float* __restrict__ ggamma, int N, int C, int inner) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    int rows = N * C;
+// ggamma[c] = sum_n rstd[n,c] * inner * (mvg - mv*mg - mvx*c); one wavefront per channel
+__global__ __launch_bounds__(64) void norm_bwd2_ggamma_kernel(const Sums5* __restrict__ sums,
+                                                              const float* __restrict__ coef,
+                                                              float* __restrict__ ggamma, int N, int C, int inner) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int rows = N * C;
     double acc = 0.0;
-    float inv = 1.f / (float)inner;
-    for (int n = 0; n < N; ++n) {
+    const float inv = 1.f / (float)inner;
+    for (int n = lane; n < N; n += 64) {
         int r = n * C + c;
         Sums5 s = sums[r];
         float rstd = coef[3 * rows + r];
         acc += (double)(rstd * (s.vg - s.v * s.g * inv - s.vx * s.gx * inv));
     }
-    ggamma[c] = (float)acc;
+    acc = wave_sum_d(acc);
+    if (lane == 0) ggamma[c] = (float)acc;
 }
 
 // ---------------------------------------------------------------------------
@@ -446,8 +461,8 @@ int gz_batchnorm_stats(const float* x, const float* gamma, const float* beta, fl
     if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
     RowGeom g = row_geom((long long)N * C, inner);
     hipLaunchKernelGGL(row_sums_kernel, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, (f32x2*)workspace, g);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, (const f32x2*)workspace, gamma,
-                       beta, coef, running_mean, running_var, num_batches_tracked, N, C, inner, eps, momentum);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, stream, (const f32x2*)workspace, gamma, beta, coef,
+                       running_mean, running_var, num_batches_tracked, N, C, inner, eps, momentum);
     return launch_status();
 }
 
@@ -492,12 +507,15 @@ int gz_norm_act_bwd(const float* gout, const float* x, const float* coef, float*
     hipLaunchKernelGGL(norm_bwd_rowsums_kernel, dim3(row_grid(rg)), dim3(PW_THREADS), 0, stream, gout, x, coef,
                        (f32x2*)workspace, rg, C, per_channel, g.ncoef, act, slope);
     if (per_channel) {
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, stream,
-                           (const f32x2*)workspace, kbuf, dgamma, dbeta, N, C, inner);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, stream, (const f32x2*)workspace, kbuf, dgamma,
+                           dbeta, N, C, inner);
     } else {
         int rows = N * C;
         hipLaunchKernelGGL(row_bwd_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream,
                            (const f32x2*)workspace, kbuf, dgamma, dbeta, N, C, inner, affine_per_row);
+        if (!affine_per_row && (dgamma || dbeta))
+            hipLaunchKernelGGL(row_bwd_affine_kernel, dim3(C), dim3(64), 0, stream, (const f32x2*)workspace, dgamma,
+                               dbeta, N, C);
     }
     if (dx)
         hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(ew_grid(g.total4)), dim3(PW_THREADS), 0, stream, gout, x, coef,
@@ -518,8 +536,8 @@ int gz_rownorm_act_bwd2(const float* gout, const float* v, const float* x, const
         hipLaunchKernelGGL(norm_bwd2_apply_kernel, dim3(ew_grid(g.total4)), dim3(PW_THREADS), 0, stream, gout, v, x,
                            coef, (const Sums5*)workspace, gg_out, gx, g, act, slope);
     if (ggamma)
-        hipLaunchKernelGGL(norm_bwd2_ggamma_kernel, dim3((C + 127) / 128), dim3(128), 0, stream,
-                           (const Sums5*)workspace, coef, ggamma, N, C, inner);
+        hipLaunchKernelGGL(norm_bwd2_ggamma_kernel, dim3(C), dim3(64), 0, stream, (const Sums5*)workspace, coef, ggamma,
+                           N, C, inner);
     return launch_status();
 }
 
