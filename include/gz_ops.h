@@ -75,6 +75,33 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
 int gz_gemm(const float* a, const float* b, const float* bias, float* c, int M, int N, int K, int lda, int ldb,
             int ldc, int trans_a, int trans_b, int act, float slope, hipStream_t stream);
 
+/* ---- cubic 3-D convolution family (HoloGAN ConvTranspose3d k3 s2 p1 op1, hologan_generator.py:29-30) ------
+ * x [N,C,D,H,W] image side, y [N,K,OD,OH,OW] feature side, w [K,C,KS,KS,KS]; only (KS,S,P) = (3,2,1). */
+long long gz_conv3d_pack_fwd_elems(int K, int C, int KS);
+long long gz_conv3d_pack_dgrad_elems(int K, int C, int KS, int S);
+int gz_conv3d_pack_fwd(const float* w, float* wpack, int K, int C, int KS, hipStream_t stream);
+int gz_conv3d_pack_dgrad(const float* w, float* wpack, int K, int C, int KS, int S, int P, hipStream_t stream);
+/* y = act(conv3d(x, w) + bias): input gradient of nn.ConvTranspose3d */
+int gz_conv3d_fwd(const float* x, const float* wpack, const float* bias, float* y, int N, int C, int D, int H, int W,
+                  int K, int OD, int OH, int OW, int KS, int S, int P, int act, float slope, hipStream_t stream);
+/* x = act(conv_transpose3d(y, w) + bias): nn.ConvTranspose3d forward */
+int gz_conv3d_dgrad(const float* y, const float* wpack, const float* bias, float* x, int N, int C, int D, int H,
+                    int W, int K, int OD, int OH, int OW, int KS, int S, int P, int act, float slope,
+                    hipStream_t stream);
+size_t gz_conv3d_wgrad_workspace_bytes(int N, int C, int K, int OD, int OH, int OW, int KS);
+int gz_conv3d_wgrad(const float* x, const float* y, float* dw, float* workspace, size_t ws_bytes, int N, int C, int D,
+                    int H, int W, int K, int OD, int OH, int OW, int KS, int S, int P, hipStream_t stream);
+
+/* ---- HoloGAN rigid-body resampling (hologan_generator.py:198-321 + the permute/flip/reshape of :130-133) ----
+ * vox [N,C,S,S,S]; minv [N,16] row-major inverse transforms; out2d [N, C*S, S, S] with
+ * out2d[n][c*S + (S-1-y)][z][x] = trilinear(vox[n][c], minv[n] . (x,y,z,1)).  idx_out (may be NULL):
+ * int64 [8][N*S^3], the clamped corner indices in the reference's idx_a..idx_h order. */
+int gz_rigid_resample_fwd(const float* vox, const float* minv, float* out2d, long long* idx_out, int N, int C, int S,
+                          hipStream_t stream);
+/* gvox [N,C,S,S,S] = scatter-add adjoint of the above (zeroed inside) */
+int gz_rigid_resample_bwd(const float* gout2d, const float* minv, float* gvox, int N, int C, int S,
+                          hipStream_t stream);
+
 /* ---- normalisation + activation -------------------------------------------------------------
  * A tensor [N, C, inner] is N*C rows of `inner` contiguous floats (inner % 4 == 0).
  * coef layout: 4 arrays of `ncoef` floats (scale, shift, mean, rstd); ncoef = C for per-channel
@@ -103,7 +130,7 @@ int gz_norm_act_fwd(const float* x, const float* coef, float* out, int N, int C,
 /* first backward of norm+act: dx (may be NULL), dgamma, dbeta (may be NULL); kbuf: 2*ncoef floats scratch */
 int gz_norm_act_bwd(const float* gout, const float* x, const float* coef, float* dx, float* dgamma, float* dbeta,
                     void* workspace, float* kbuf, int N, int C, int inner, int per_channel, int affine_per_row,
-                    int act, float slope, hipStream_t stream);
+                    int unbiased, int act, float slope, hipStream_t stream);
 /* backward of gz_norm_act_bwd's dx (per-row statistics, per-channel affine): given v = dL/d(dx) returns
  * gg_out = dL/d(gout), gx = dL/dx, ggamma = dL/dgamma (any may be NULL).  This is the InstanceNorm leg of
  * the gradient-penalty double backward (core/utils/utils.py:48-54 with create_graph=True). */

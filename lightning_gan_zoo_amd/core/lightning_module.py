@@ -142,3 +142,31 @@ class WGANGP(BaseGAN):
             loss_gen = -torch.mean(gen_fake)
             self.log("train/g_loss", loss_gen)
             return loss_gen
+
+
+class HOLOGAN(BaseGAN):
+    """reference core/lightning_module.py:209-237"""
+
+    def training_step(self, batch, batch_idx, optimizer_idx):
+        real, _ = batch
+        z = self.sample_noise(len(real))
+        fake = self.generator(z)
+
+        if optimizer_idx == 0:
+            disc_real, _ = self.discriminator(real)
+            loss_disc_real = self.criterion(disc_real, torch.ones_like(disc_real))
+            disc_fake, d_z_pred = self.discriminator(fake.detach())
+            loss_disc_fake = self.criterion(disc_fake, torch.zeros_like(disc_fake))
+            loss_disc = (loss_disc_real + loss_disc_fake) / 2
+            q_loss = torch.mean((d_z_pred - z) ** 2)
+            self.log("train/d_loss", loss_disc)
+            self.log("train/q_loss", q_loss)
+            return loss_disc + q_loss
+
+        if optimizer_idx == 1:
+            output, d_z_pred = self.discriminator(fake)
+            loss_gen = self.criterion(output, torch.ones_like(output))
+            q_loss = torch.mean((d_z_pred - z) ** 2)
+            self.log("train/g_loss", loss_gen)
+            self.log("train/q_loss", q_loss)
+            return loss_gen + q_loss

@@ -1,0 +1,76 @@
+"""HoloGAN discriminator on the MI355X HIP kernels; drop-in for reference
+core/models/hologan_discriminator.py:7-78 (same constructor, same state_dict -- including the
+``conv2d`` / ``conv2d_spec_norm`` double registration and the ``weight_orig/weight_u/weight_v``
+spectral-norm entries -- same init order and quirks).
+
+    Conv2d k5 s2 p2 + bias + LeakyReLU(0.2)            (fused epilogue)
+    3 x [spectral-norm Conv2d k5 s2 p2 + bias -> InstanceNorm2d (no affine) + LeakyReLU]
+    heads: Linear 8192->1 (logit); Linear 8192->128 + LeakyReLU -> Linear 128->z + tanh
+"""
+from torch import nn
+
+from ... import functional as F
+
+K5S2P2 = F.Geom(5, 5, 2, 2)
+
+
+def truncated_normal_initializer(weight, mean=0, std=0.02):
+    size = weight.shape
+    tmp = weight.new_empty(size + (4,)).normal_()
+    valid = (tmp < 2) & (tmp > -2)
+    ind = valid.max(-1, keepdim=True)[1]
+    weight.data.copy_(tmp.gather(-1, ind).squeeze(-1))
+    weight.data.mul_(std).add_(mean)
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, in_planes, out_planes):
+        super().__init__()
+        self.conv2d = nn.Conv2d(in_planes, out_planes, kernel_size=5, stride=2, padding=2)
+        truncated_normal_initializer(self.conv2d.weight)
+        nn.init.constant_(self.conv2d.bias, val=0.0)
+        self.conv2d_spec_norm = nn.utils.spectral_norm(self.conv2d)     # parameter holder: weight_orig, weight_u/v
+        self.instance_norm = nn.InstanceNorm2d(out_planes)
+        self.lrelu = nn.LeakyReLU(0.2)
+
+    def forward(self, x):
+        c = self.conv2d
+        w = F.spectral_normalize(c.weight_orig, c.weight_u, c.weight_v, self.training)
+        y = F.conv2d(x, w, c.bias, K5S2P2)
+        return F.instance_norm_act(y, None, None, self.instance_norm.eps, F.ACT_LRELU, self.lrelu.negative_slope)
+
+
+class Discriminator(nn.Module):
+    def __init__(self, in_planes, out_planes, z_planes):
+        super().__init__()
+        self.conv2d = nn.Conv2d(in_planes, out_planes, kernel_size=5, stride=2, padding=2)
+        truncated_normal_initializer(self.conv2d.weight)
+        nn.init.constant_(self.conv2d.bias, val=0.0)
+        self.lrelu = nn.LeakyReLU(0.2)
+        self.blocks = nn.Sequential(
+            BasicBlock(out_planes * 1, out_planes * 2),
+            BasicBlock(out_planes * 2, out_planes * 4),
+            BasicBlock(out_planes * 4, out_planes * 8))
+        self.linear1 = nn.Linear(out_planes * 8 * 4 * 4, 1)
+        truncated_normal_initializer(self.linear1.weight)
+        nn.init.constant_(self.linear1.bias, val=0.0)
+        self.linear2 = nn.Linear(out_planes * 8 * 4 * 4, 128)
+        truncated_normal_initializer(self.linear1.weight)     # sic (reference :46)
+        nn.init.constant_(self.linear2.bias, val=0.0)
+        self.linear3 = nn.Linear(128, z_planes)
+        truncated_normal_initializer(self.linear1.weight)     # sic (reference :50)
+        nn.init.constant_(self.linear3.bias, val=0.0)
+        self.sigmoid = nn.Sigmoid()
+        self.tanh = nn.Tanh()
+
+    def forward(self, x):
+        batch_size = x.size(0)
+        slope = self.lrelu.negative_slope
+        h = F.conv2d(x, self.conv2d.weight, self.conv2d.bias, K5S2P2, F.ACT_LRELU, slope)
+        for blk in self.blocks:
+            h = blk(h)
+        h = h.reshape(batch_size, -1)
+        logit = F.linear_act(h, self.linear1.weight, self.linear1.bias)
+        enc = F.linear_act(h, self.linear2.weight, self.linear2.bias, F.ACT_LRELU, slope)
+        z_prediction = F.linear_act(enc, self.linear3.weight, self.linear3.bias, F.ACT_TANH)
+        return logit, z_prediction

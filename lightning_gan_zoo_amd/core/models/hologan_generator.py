@@ -1,0 +1,154 @@
+"""HoloGAN generator on the MI355X HIP kernels; drop-in for reference
+core/models/hologan_generator.py:7-345 (same constructor, parameter names / shapes / init order):
+
+    learned constant [1, 8C, 4,4,4] -> AdaIN(z)+ReLU
+    -> 2 x [ConvTranspose3d k3 s2 p1 op1 (MFMA implicit GEMM, 8 sub-voxel phases) -> AdaIN(z)+ReLU]
+    -> rigid-body resampling of the 16^3 volume under the sampled view (trilinear gather kernel that
+       writes the permuted/flipped [N, 16C, 16, 16] map directly)
+    -> 1x1 "learned projection" ConvTranspose2d + ReLU (fused epilogue)
+    -> 2 x [ConvTranspose2d k4 s2 p1 -> AdaIN(z)+ReLU] -> Conv2d k3 p1 + tanh (fused epilogue)
+
+The child nn modules are parameter holders; forward only calls lightning_gan_zoo_amd.functional.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from ... import functional as F
+from ...harness import draw_on_host, few_host_threads
+
+K3S1P1 = F.Geom(3, 3, 1, 1)
+K1S1P0 = F.Geom(1, 1, 1, 0)
+
+
+class ZMapping(nn.Module):
+    def __init__(self, z_dimension, output_channel):
+        super().__init__()
+        self.output_channel = output_channel
+        self.linear1 = nn.Linear(z_dimension, output_channel * 2)
+        nn.init.normal_(self.linear1.weight, std=0.02)
+        nn.init.constant_(self.linear1.bias, val=0.0)
+        self.relu = nn.ReLU()
+
+    def forward(self, x):
+        out = F.linear_act(x, self.linear1.weight, self.linear1.bias, F.ACT_RELU)
+        c = self.output_channel
+        return out[:, :c].contiguous(), out[:, c:].contiguous()
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, z_planes, in_planes, out_planes, transpose_dim):
+        super().__init__()
+        if transpose_dim == 2:
+            self.convTranspose = nn.ConvTranspose2d(in_planes, out_planes, kernel_size=4, stride=2, padding=1)
+        else:
+            self.convTranspose = nn.ConvTranspose3d(in_planes, out_planes, kernel_size=3, stride=2,
+                                                    output_padding=1, padding=1)
+        nn.init.normal_(self.convTranspose.weight, std=0.02)
+        nn.init.constant_(self.convTranspose.bias, val=0.0)
+        self.zMapping = ZMapping(z_planes, out_planes)
+        self.relu = nn.ReLU()
+        self.transpose_dim = transpose_dim
+
+    def forward(self, h, z):
+        ct = self.convTranspose
+        if self.transpose_dim == 2:
+            h = F.conv_transpose2d(h, ct.weight, ct.bias, F.K4S2P1)
+        else:
+            h = F.conv_transpose3d(h, ct.weight, ct.bias)
+        s, b = self.zMapping(z)
+        return F.adain_act(h, s, b, 1e-8, F.ACT_RELU)
+
+
+def _mat(rows):
+    return torch.cat([torch.cat(r, dim=2) for r in rows], dim=1)
+
+
+def view_inverse_matrices(view, size=16, new_size=16):
+    """Per-sample inverse of  C_new . (T . S . (Rz . Ry)) . C_old  -- computed on the HOST in fp32 with
+    the reference's operation order (hologan_generator.py:145-214) so the matrices, and hence the
+    integer voxel indices derived from them, agree with the reference bit for bit.  [N, 4, 4]."""
+    view = torch.as_tensor(view)
+    col = lambda i: view[:, i].reshape(-1, 1, 1).float()      # noqa: E731
+    th, ga, sc, tx, ty, tz = (col(i) for i in range(6))
+    one, zero = torch.ones_like(th), torch.zeros_like(th)
+    rot_z = _mat([[th.cos(), th.sin(), zero, zero], [-th.sin(), th.cos(), zero, zero],
+                  [zero, zero, one, zero], [zero, zero, zero, one]])
+    rot_y = _mat([[ga.cos(), zero, ga.sin(), zero], [zero, one, zero, zero],
+                  [-ga.sin(), zero, ga.cos(), zero], [zero, zero, zero, one]])
+    scl = _mat([[sc, zero, zero, zero], [zero, sc, zero, zero], [zero, zero, sc, zero], [zero, zero, zero, one]])
+    trn = _mat([[one, zero, zero, tx], [zero, one, zero, ty], [zero, zero, one, tz], [zero, zero, zero, one]])
+    m = torch.matmul(torch.matmul(trn, scl), torch.matmul(rot_z, rot_y))
+    n = view.shape[0]
+
+    def centre(v):
+        return torch.tensor([[1, 0, 0, v], [0, 1, 0, v], [0, 0, 1, v], [0, 0, 0, 1.0]]).reshape(1, 4, 4).repeat(n, 1, 1)
+
+    return torch.matmul(torch.matmul(centre(new_size * 0.5), m), centre(-size * 0.5)).inverse()
+
+
+class Generator(nn.Module):
+    def __init__(self, in_planes, out_planes, z_planes, view_args, img_size, view_planes=6, gpu=True):
+        super().__init__()
+        # `gpu` is accepted for signature parity; the module follows its parameters' device (.to(device))
+        tensor = (torch.randn(1, in_planes * 8, 4, 4, 4) - 0.5) / 0.5
+        self.x = nn.Parameter(tensor)
+        self.view_args = view_args
+        self.zMapping = ZMapping(z_planes, in_planes * 8)
+        self.block1 = BasicBlock(z_planes, in_planes=in_planes * 8, out_planes=in_planes * 2, transpose_dim=3)
+        self.block2 = BasicBlock(z_planes, in_planes=in_planes * 2, out_planes=in_planes, transpose_dim=3)
+        self.convTranspose2d1 = nn.ConvTranspose2d(in_planes * 16, in_planes * 16, kernel_size=1)
+        nn.init.normal_(self.convTranspose2d1.weight, std=0.02)
+        nn.init.constant_(self.convTranspose2d1.bias, val=0.0)
+        self.block3 = BasicBlock(z_planes, in_planes=in_planes * 16, out_planes=in_planes * 4, transpose_dim=2)
+        self.block4 = BasicBlock(z_planes, in_planes=in_planes * 4, out_planes=in_planes, transpose_dim=2)
+        if img_size == 64:
+            self.final_layer = nn.Conv2d(in_planes, out_planes, kernel_size=3, padding=1)
+        elif img_size == 128:
+            # the reference's 128 branch (ConvTranspose2d k4 p1, stride 1) yields 65x65 and cannot feed its
+            # own discriminator; not supported on the HIP path
+            raise NotImplementedError("HoloGAN img_size=128 is broken in the reference; only 64 is supported")
+        else:
+            raise ValueError("img_size must be 64")
+        nn.init.normal_(self.final_layer.weight, std=0.02)
+        nn.init.constant_(self.final_layer.bias, val=0.0)
+        self.relu = nn.ReLU()
+        self.tanh = nn.Tanh()
+
+    def sample_view(self, batch_size):
+        """Transformation parameters from numpy's global generator, reference :80-114 (call order kept)."""
+        a = self.view_args
+        theta = np.random.randint(a["azimuth_low"], a["azimuth_high"], (batch_size)).astype(float) * math.pi / 180.0
+        if a["elevation_low"] < a["elevation_high"]:
+            gamma = np.random.randint(a["elevation_low"], a["elevation_high"], (batch_size)).astype(float)
+            gamma = gamma * math.pi / 180.0
+        else:
+            gamma = np.zeros(batch_size).astype(float)
+        scale = float(np.random.uniform(a["scale_low"], a["scale_high"]))
+        shift = [a["trans%s_low" % ax] + np.random.random(batch_size) * (a["trans%s_high" % ax] - a["trans%s_low" % ax])
+                 for ax in ("X", "Y", "Z")]
+        view = np.zeros((batch_size, 6))
+        view[:, 0], view[:, 1], view[:, 2] = theta, gamma, scale
+        view[:, 3], view[:, 4], view[:, 5] = shift
+        return view
+
+    def forward(self, z, view_in=None):
+        n = z.shape[0]
+        if view_in is None:
+            view_in = self.sample_view(n)
+        dev = self.x.device
+        minv = draw_on_host(lambda: view_inverse_matrices(view_in).reshape(n, 16).contiguous(), dev)
+
+        s0, b0 = self.zMapping(z)
+        h = F.adain_act(self.x.repeat(n, 1, 1, 1, 1), s0, b0, 1e-8, F.ACT_RELU)
+        h = self.block1(h, z)
+        h = self.block2(h, z)
+        h = F.rigid_resample(h, minv)                                 # [N, 16*C, 16, 16]
+        p = self.convTranspose2d1
+        h = F.conv_transpose2d(h, p.weight, p.bias, K1S1P0, F.ACT_RELU)
+        h = self.block3(h, z)
+        h = self.block4(h, z)
+        f = self.final_layer
+        return F.conv2d(h, f.weight, f.bias, K3S1P1, F.ACT_TANH)

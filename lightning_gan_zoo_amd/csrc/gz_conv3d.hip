@@ -1,0 +1,240 @@
+// C-ABI entry points for the cubic-kernel 3-D convolution family on the fp32 MFMA implicit-GEMM core:
+// HoloGAN's ConvTranspose3d(k3, s2, p1, output_padding 1) forward (= Dg), its input gradient (= F)
+// and weight gradient (= Wg).  Reference call sites: core/models/hologan_generator.py:29-30,55-58.
+#include "gz_igemm.h"
+#include "../../include/gz_ops.h"
+
+namespace gz {
+
+using C3_128x128 = TileCfg<2, 2, 2, 2>;
+using C3_128x64 = TileCfg<2, 2, 2, 1>;
+using C3_128x32 = TileCfg<4, 1, 1, 1>;
+using C3_64x64 = TileCfg<2, 2, 1, 1>;
+
+static inline int r4(int v) { return (v + 3) & ~3; }
+
+static int pick3(long long M, long long N, int ny) {
+    if (N <= 32) return 2;
+    auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * ny; };
+    if (N <= 64) return tiles(128, 64) >= 256 ? 1 : 3;
+    if (tiles(128, 128) >= 256) return 0;
+    if (tiles(128, 64) >= 256) return 1;
+    return 3;
+}
+
+// wp[col][ld] = w[r][col] (r < R rows of length COLS), zero padded to ld
+__global__ __launch_bounds__(256) void transpose_pad3_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                             int R, int COLS, int ld) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < R && c < COLS) ? src[(long long)r * COLS + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < COLS && r < ld) dst[(long long)c * ld + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+// wp[phase][(ko, td, ty, tx)][ldc] = w[ko][c][kd][ky][kx], k* = ((p* + P) % S) + S * t*  (0 if >= KS)
+__global__ __launch_bounds__(256) void pack_dgrad3_kernel(const float* __restrict__ w, float* __restrict__ wp, int K,
+                                                          int C, int KS, int S, int P, int T, int ldc) {
+    const int ko = blockIdx.x, phase = blockIdx.y;
+    const int pd = phase / (S * S), py = (phase / S) % S, px = phase % S;
+    const int rd = (pd + P) % S, ry = (py + P) % S, rx = (px + P) % S;
+    const int taps = T * T * T;
+    const long long phase_stride = (long long)K * taps * ldc;
+    for (int i = threadIdx.x; i < taps * ldc; i += blockDim.x) {
+        int tap = i / ldc, c = i - tap * ldc;
+        int kd = rd + S * (tap / (T * T)), ky = ry + S * ((tap / T) % T), kx = rx + S * (tap % T);
+        float v = 0.f;
+        if (c < C && kd < KS && ky < KS && kx < KS) v = w[((((long long)ko * C + c) * KS + kd) * KS + ky) * KS + kx];
+        wp[phase * phase_stride + ((long long)ko * taps + tap) * ldc + c] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs3_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                            int S, long long count) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += slab[(long long)s * count + i];
+    out[i] = acc;
+}
+
+static bool shape3_ok(const Conv3DShape& s, int KS, int S, int P) {
+    if (s.N <= 0 || s.C <= 0 || s.K <= 0 || s.D <= 0 || s.H <= 0 || s.W <= 0) return false;
+    auto o = [&](int v) { return (v + 2 * P - KS) / S + 1; };
+    return s.OD == o(s.D) && s.OH == o(s.H) && s.OW == o(s.W);
+}
+
+static bool big3(long long e) { return e * 4 >= (1ll << 31); }
+
+template <class Cfg, int KS, int S, int P>
+static int run_fwd3(const float* x, const float* wp, const float* bias, float* y, const Conv3DShape& s, int act,
+                    float slope, hipStream_t st) {
+    using AL = Conv3DFwdALoader<Cfg::BM, KS, S, P>;
+    using BL = MContigLoader4<Cfg::BN>;
+    const int osp = s.OD * s.OH * s.OW;
+    typename AL::Params pa{x, s, make_fastdiv(osp), make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW)};
+    int Kg = s.C * KS * KS * KS;
+    typename BL::Params pb{wp, Kg, r4(s.K), r4(s.K), 0};
+    int M = s.N * osp;
+    EpiNCHW::Params pe{y, M, s.K, osp, make_fastdiv(osp), bias, act, slope};
+    return launch_igemm<Cfg, AL, BL, EpiNCHW>(pa, pb, pe, M, s.K, Kg, 1, 1, st);
+}
+
+template <class Cfg, int KS, int S, int P>
+static int run_dgrad3(const float* y, const float* wp, const float* bias, float* x, const Conv3DShape& s, int act,
+                      float slope, hipStream_t st) {
+    using AL = Conv3DDgALoader<Cfg::BM, KS, S, P>;
+    using BL = MContigLoader4<Cfg::BN>;
+    using Epi = EpiPhase3D<S>;
+    const int AD = s.D / S, AH = s.H / S, AW = s.W / S;
+    typename AL::Params pa{y, s, AD, AH, AW, make_fastdiv(AD * AH * AW), make_fastdiv(AH * AW), make_fastdiv(AW)};
+    int Kg = s.K * AL::TAPS;
+    int ldc = r4(s.C);
+    typename BL::Params pb{wp, Kg, ldc, ldc, (long long)Kg * ldc};
+    int M = s.N * AD * AH * AW;
+    typename Epi::Params pe{x, M, s.C, s.D, s.H, s.W, AD, AH, AW, make_fastdiv(AD * AH * AW), make_fastdiv(AH * AW),
+                            make_fastdiv(AW), bias, act, slope};
+    return launch_igemm<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kg, S * S * S, 1, st);
+}
+
+static int splits3(long long tiles, int chunks) {
+    if (tiles >= 256) return 1;
+    long long want = (512 + tiles - 1) / tiles;
+    long long cap = chunks / 8 > 0 ? chunks / 8 : 1;
+    long long s = want < cap ? want : cap;
+    return (int)(s < 1 ? 1 : s);
+}
+
+template <class Cfg, int KS, int S, int P>
+static int run_wgrad3(const float* x, const float* y, float* dw, float* ws, size_t ws_bytes, const Conv3DShape& s,
+                      hipStream_t st) {
+    using AL = WgALoader<Cfg::BM>;
+    using BL = Wg3DBLoader<Cfg::BN, KS, S, P>;
+    const int osp = s.OD * s.OH * s.OW;
+    const int KTOT = s.N * osp;
+    const int NTOT = s.C * KS * KS * KS;
+    ConvShape flat{s.N, s.C, 1, 1, s.K, osp, 1};      // WgALoader only needs N, K and OH*OW
+    typename AL::Params pa{y, flat, make_fastdiv(osp), KTOT};
+    typename BL::Params pb{x, s, make_fastdiv(osp), make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW), KTOT, NTOT};
+    long long tiles = (long long)((s.K + Cfg::BM - 1) / Cfg::BM) * ((NTOT + Cfg::BN - 1) / Cfg::BN);
+    int chunks = (KTOT + BK - 1) / BK;
+    int splits = splits3(tiles, chunks);
+    long long count = (long long)s.K * NTOT;
+    if (splits > 1) {
+        long long max_splits = (long long)(ws_bytes / 4) / count;
+        if (max_splits < 2) splits = 1;
+        else if (splits > max_splits) splits = (int)max_splits;
+    }
+    int cps = (chunks + splits - 1) / splits;
+    int nz = (chunks + cps - 1) / cps;
+    float* out = nz > 1 ? ws : dw;
+    EpiRowMajor::Params pe{out, s.K, NTOT, NTOT, count, nullptr, ACT_NONE, 0.f};
+    int rc = launch_igemm<Cfg, AL, BL, EpiRowMajor>(pa, pb, pe, s.K, NTOT, KTOT, 1, splits, st);
+    if (rc != GZ_OK) return rc;
+    if (nz > 1) {
+        hipLaunchKernelGGL(reduce_slabs3_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws, dw, nz,
+                           count);
+        rc = launch_status();
+    }
+    return rc;
+}
+
+}  // namespace gz
+
+using namespace gz;
+
+#define GZ3_TILE_SWITCH(T, CALL)              \
+    switch (T) {                              \
+        case 0: return CALL(C3_128x128);      \
+        case 1: return CALL(C3_128x64);       \
+        case 2: return CALL(C3_128x32);       \
+        default: return CALL(C3_64x64);       \
+    }
+
+extern "C" {
+
+long long gz_conv3d_pack_fwd_elems(int K, int C, int KS) { return (long long)C * KS * KS * KS * r4(K); }
+
+long long gz_conv3d_pack_dgrad_elems(int K, int C, int KS, int S) {
+    int T = (KS + S - 1) / S;
+    return (long long)S * S * S * K * T * T * T * r4(C);
+}
+
+int gz_conv3d_pack_fwd(const float* w, float* wp, int K, int C, int KS, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (K <= 0 || C <= 0 || KS <= 0) return GZ_ERR_BAD_SHAPE;
+    int Kg = C * KS * KS * KS, ld = r4(K);
+    hipLaunchKernelGGL(transpose_pad3_kernel, dim3((Kg + 31) / 32, (ld + 31) / 32), dim3(256), 0, stream, w, wp, K, Kg,
+                       ld);
+    return launch_status();
+}
+
+int gz_conv3d_pack_dgrad(const float* w, float* wp, int K, int C, int KS, int S, int P, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (K <= 0 || C <= 0 || KS <= 0 || S <= 0) return GZ_ERR_BAD_SHAPE;
+    int T = (KS + S - 1) / S;
+    hipLaunchKernelGGL(pack_dgrad3_kernel, dim3(K, S * S * S), dim3(256), 0, stream, w, wp, K, C, KS, S, P, T, r4(C));
+    return launch_status();
+}
+
+int gz_conv3d_fwd(const float* x, const float* wpack, const float* bias, float* y, int N, int C, int D, int H, int W,
+                  int K, int OD, int OH, int OW, int KS, int S, int P, int act, float slope, hipStream_t stream) {
+    gz::clear_stale_error();
+    Conv3DShape s{N, C, D, H, W, K, OD, OH, OW};
+    if (KS != 3 || S != 2 || P != 1) return GZ_ERR_UNSUPPORTED;
+    if (!shape3_ok(s, KS, S, P)) return GZ_ERR_BAD_SHAPE;
+    if (big3((long long)N * C * D * H * W) || big3((long long)N * K * OD * OH * OW)) return GZ_ERR_TOO_LARGE;
+    if (((uintptr_t)wpack & 15) || ((uintptr_t)y & 15)) return GZ_ERR_BAD_SHAPE;
+    int t = pick3((long long)N * OD * OH * OW, K, 1);
+#define CALL(CFG) run_fwd3<CFG, 3, 2, 1>(x, wpack, bias, y, s, act, slope, stream)
+    GZ3_TILE_SWITCH(t, CALL)
+#undef CALL
+}
+
+int gz_conv3d_dgrad(const float* y, const float* wpack, const float* bias, float* x, int N, int C, int D, int H,
+                    int W, int K, int OD, int OH, int OW, int KS, int S, int P, int act, float slope,
+                    hipStream_t stream) {
+    gz::clear_stale_error();
+    Conv3DShape s{N, C, D, H, W, K, OD, OH, OW};
+    if (KS != 3 || S != 2 || P != 1) return GZ_ERR_UNSUPPORTED;
+    if (!shape3_ok(s, KS, S, P) || D % S || H % S || W % S) return GZ_ERR_BAD_SHAPE;
+    if (big3((long long)N * C * D * H * W) || big3((long long)N * K * OD * OH * OW)) return GZ_ERR_TOO_LARGE;
+    if ((uintptr_t)wpack & 15) return GZ_ERR_BAD_SHAPE;
+    int t = pick3((long long)N * (D / S) * (H / S) * (W / S), C, S * S * S);
+#define CALL(CFG) run_dgrad3<CFG, 3, 2, 1>(y, wpack, bias, x, s, act, slope, stream)
+    GZ3_TILE_SWITCH(t, CALL)
+#undef CALL
+}
+
+size_t gz_conv3d_wgrad_workspace_bytes(int N, int C, int K, int OD, int OH, int OW, int KS) {
+    long long count = (long long)K * C * KS * KS * KS;
+    int chunks = (N * OD * OH * OW + BK - 1) / BK;
+    long long tiles = (long long)((K + 127) / 128) * ((C * KS * KS * KS + 127) / 128);
+    int splits = splits3(tiles, chunks);
+    return splits > 1 ? (size_t)splits * count * 4 : 0;
+}
+
+int gz_conv3d_wgrad(const float* x, const float* y, float* dw, float* workspace, size_t ws_bytes, int N, int C, int D,
+                    int H, int W, int K, int OD, int OH, int OW, int KS, int S, int P, hipStream_t stream) {
+    gz::clear_stale_error();
+    Conv3DShape s{N, C, D, H, W, K, OD, OH, OW};
+    if (KS != 3 || S != 2 || P != 1) return GZ_ERR_UNSUPPORTED;
+    if (!shape3_ok(s, KS, S, P)) return GZ_ERR_BAD_SHAPE;
+    if (big3((long long)N * C * D * H * W) || big3((long long)N * K * OD * OH * OW)) return GZ_ERR_TOO_LARGE;
+    long long NTOT = (long long)C * KS * KS * KS;
+    int t = NTOT <= 32 ? 2 : ((NTOT <= 64 || K <= 64) ? (K <= 64 ? 3 : 1) : 0);
+#define CALL(CFG) run_wgrad3<CFG, 3, 2, 1>(x, y, dw, workspace, ws_bytes, s, stream)
+    GZ3_TILE_SWITCH(t, CALL)
+#undef CALL
+}
+
+}  // extern "C"

@@ -444,6 +444,191 @@ struct WgBLoader {
 };
 
 // ---------------------------------------------------------------------------
+// 3-D (cubic kernel KS, stride S, padding P) variants: HoloGAN's ConvTranspose3d(k3, s2, p1, op1)
+// x: [N, C, D, H, W] image side, y: [N, K, OD, OH, OW] feature side, w: [K, C, KS, KS, KS]
+// ---------------------------------------------------------------------------
+struct Conv3DShape {
+    int N, C, D, H, W, K, OD, OH, OW;
+};
+
+// forward 3-D conv: A[m = (n, od, oy, ox)][k = (c, kd, ky, kx)]
+template <int BM, int KS, int S, int P>
+struct Conv3DFwdALoader {
+    struct Params {
+        const float* x;
+        Conv3DShape s;
+        FastDiv div_odhw, div_ohw, div_ow;
+    };
+    static constexpr int LD = BM;
+    static constexpr int EPT = BM * BK / NT;
+    static constexpr int STEP = NT / BM;
+    static constexpr int T3 = KS * KS * KS;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t nbase;
+    int kb, m_l, id0, iy0, ix0, C, D, H, W;
+    bool m_ok;
+    float r[EPT];
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        const Conv3DShape& s = p.s;
+        rsrc = make_rsrc(p.x, (uint32_t)s.N * s.C * s.D * s.H * s.W * 4u);
+        m_l = tid % BM;
+        kb = tid / BM;
+        uint32_t m = (uint32_t)tile * BM + m_l;
+        m_ok = m < (uint32_t)s.N * s.OD * s.OH * s.OW;
+        uint32_t n = fdiv(m, p.div_odhw);
+        uint32_t v = m - n * (uint32_t)(s.OD * s.OH * s.OW);
+        uint32_t od = fdiv(v, p.div_ohw);
+        v -= od * (uint32_t)(s.OH * s.OW);
+        uint32_t oy = fdiv(v, p.div_ow);
+        uint32_t ox = v - oy * (uint32_t)s.OW;
+        id0 = (int)od * S - P; iy0 = (int)oy * S - P; ix0 = (int)ox * S - P;
+        nbase = n * (uint32_t)(s.C * s.D * s.H * s.W);
+        C = s.C; D = s.D; H = s.H; W = s.W;
+    }
+    __device__ __forceinline__ void issue(int kc) {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            int k = kc * BK + kb + STEP * j;
+            int c = k / T3;
+            int tap = k - c * T3;
+            int kd = tap / (KS * KS), ky = (tap / KS) % KS, kx = tap % KS;
+            int id = id0 + kd, iy = iy0 + ky, ix = ix0 + kx;
+            bool ok = m_ok && c < C && (unsigned)id < (unsigned)D && (unsigned)iy < (unsigned)H &&
+                      (unsigned)ix < (unsigned)W;
+            uint32_t v = ok ? (nbase + (uint32_t)(((c * D + id) * H + iy) * W + ix)) * 4u : OOB;
+            r[j] = bload(rsrc, v, 0);
+        }
+    }
+    __device__ __forceinline__ void commit(float* dst) const {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) dst[(kb + STEP * j) * LD + m_l] = r[j];
+    }
+};
+
+// transposed 3-D conv, phase (pd, py, px): A[m = (n, a, b, c)][k = (ko, td, ty, tx)]
+template <int BM, int KS, int S, int P>
+struct Conv3DDgALoader {
+    static constexpr int T = (KS + S - 1) / S;
+    static constexpr int TAPS = T * T * T;
+    struct Params {
+        const float* y;
+        Conv3DShape s;
+        int AD, AH, AW;
+        FastDiv div_adhw, div_ahw, div_aw;
+    };
+    static constexpr int LD = BM;
+    static constexpr int EPT = BM * BK / NT;
+    static constexpr int STEP = NT / BM;
+    static_assert(BK % TAPS == 0, "a chunk must hold whole feature channels");
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[EPT];
+    int kb, m_l, K, OSP;
+    float r[EPT];
+    __device__ __forceinline__ void init(const Params& p, int tile, int phase, int tid) {
+        const Conv3DShape& s = p.s;
+        rsrc = make_rsrc(p.y, (uint32_t)s.N * s.K * s.OD * s.OH * s.OW * 4u);
+        m_l = tid % BM;
+        kb = tid / BM;
+        const int pd = phase / (S * S), py = (phase / S) % S, px = phase % S;
+        uint32_t m = (uint32_t)tile * BM + m_l;
+        bool m_ok = m < (uint32_t)s.N * p.AD * p.AH * p.AW;
+        uint32_t n = fdiv(m, p.div_adhw);
+        uint32_t v = m - n * (uint32_t)(p.AD * p.AH * p.AW);
+        uint32_t a = fdiv(v, p.div_ahw);
+        v -= a * (uint32_t)(p.AH * p.AW);
+        uint32_t b = fdiv(v, p.div_aw);
+        uint32_t c = v - b * (uint32_t)p.AW;
+        const int od0 = (int)a + (pd + P) / S, oy0 = (int)b + (py + P) / S, ox0 = (int)c + (px + P) / S;
+        OSP = s.OD * s.OH * s.OW;
+        K = s.K;
+        uint32_t nbase = n * (uint32_t)(s.K * OSP);
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            int kk = kb + STEP * j;
+            int kol = kk / TAPS, tap = kk % TAPS;
+            int od = od0 - tap / (T * T), oy = oy0 - (tap / T) % T, ox = ox0 - tap % T;
+            bool ok = m_ok && (unsigned)od < (unsigned)s.OD && (unsigned)oy < (unsigned)s.OH &&
+                      (unsigned)ox < (unsigned)s.OW;
+            voff[j] = ok ? (nbase + (uint32_t)(kol * OSP + (od * s.OH + oy) * s.OW + ox)) * 4u : OOB;
+        }
+    }
+    __device__ __forceinline__ void issue(int kc) {
+        uint32_t soff = (uint32_t)kc * (uint32_t)((BK / TAPS) * OSP) * 4u;
+        int ko_base = kc * (BK / TAPS);
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            int kol = (kb + STEP * j) / TAPS;
+            r[j] = bload(rsrc, ko_base + kol < K ? voff[j] : OOB, soff);
+        }
+    }
+    __device__ __forceinline__ void commit(float* dst) const {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) dst[(kb + STEP * j) * LD + m_l] = r[j];
+    }
+};
+
+// 3-D weight gradient, B[k = p = (n, od, oy, ox)][col = (c, kd, ky, kx)]
+template <int BN, int KS, int S, int P>
+struct Wg3DBLoader {
+    struct Params {
+        const float* x;
+        Conv3DShape s;
+        FastDiv div_odhw, div_ohw, div_ow;
+        int KTOT, NTOT;
+    };
+    static constexpr int LD = BN + 2;
+    static constexpr int EPT = BN / 16;
+    static constexpr int T3 = KS * KS * KS;
+    __amdgpu_buffer_rsrc_t rsrc;
+    int toff[EPT], kd_[EPT], ky_[EPT], kx_[EPT];
+    int kl, n_l, ODHW, OHW, OW, D, H, W, CDHW, KTOT;
+    FastDiv div_odhw, div_ohw, div_ow;
+    float r[EPT];
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        const Conv3DShape& s = p.s;
+        rsrc = make_rsrc(p.x, (uint32_t)s.N * s.C * s.D * s.H * s.W * 4u);
+        kl = tid & 15;
+        n_l = tid >> 4;
+        ODHW = s.OD * s.OH * s.OW; OHW = s.OH * s.OW; OW = s.OW;
+        D = s.D; H = s.H; W = s.W; CDHW = s.C * s.D * s.H * s.W;
+        KTOT = p.KTOT;
+        div_odhw = p.div_odhw; div_ohw = p.div_ohw; div_ow = p.div_ow;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            int col = tile * BN + n_l + 16 * j;
+            int c = col / T3;
+            int tap = col - c * T3;
+            kd_[j] = tap / (KS * KS) - P;
+            ky_[j] = (tap / KS) % KS - P;
+            kx_[j] = tap % KS - P;
+            toff[j] = col < p.NTOT ? ((c * D + kd_[j]) * H + ky_[j]) * W + kx_[j] : INT32_MIN;
+        }
+    }
+    __device__ __forceinline__ void issue(int kc) {
+        uint32_t p = (uint32_t)kc * BK + kl;
+        uint32_t n = fdiv(p, div_odhw);
+        uint32_t v = p - n * (uint32_t)ODHW;
+        uint32_t od = fdiv(v, div_ohw);
+        v -= od * (uint32_t)OHW;
+        uint32_t oy = fdiv(v, div_ow);
+        uint32_t ox = v - oy * (uint32_t)OW;
+        int bd = (int)od * S, by = (int)oy * S, bx = (int)ox * S;
+        int base = (int)n * CDHW + (bd * H + by) * W + bx;
+        bool ok = p < (uint32_t)KTOT;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            bool v2 = ok && toff[j] != INT32_MIN && (unsigned)(bd + kd_[j]) < (unsigned)D &&
+                      (unsigned)(by + ky_[j]) < (unsigned)H && (unsigned)(bx + kx_[j]) < (unsigned)W;
+            r[j] = bload(rsrc, v2 ? (uint32_t)(base + toff[j]) * 4u : OOB, 0);
+        }
+    }
+    __device__ __forceinline__ void commit(float* dst) const {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) dst[kl * LD + n_l + 16 * j] = r[j];
+    }
+};
+
+// ---------------------------------------------------------------------------
 // epilogues.  Accumulator map of v_mfma_f32_32x32x2_f32: lane l, register r holds
 //   C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
 // ---------------------------------------------------------------------------
@@ -566,6 +751,51 @@ struct EpiPhase {
                     if (c < p.C) {
                         float bv = p.bias ? p.bias[c] : 0.f;
                         p.out[o + (long long)c * p.H * p.W] = act_fwd(acc[i][j][r] + bv, p.act, p.slope);
+                    }
+                }
+            }
+        }
+    }
+};
+
+// 3-D transposed-conv output: row m = (n, a, b, c) of phase y = (pd, py, px) goes to
+// x[n][ch][S*a+pd][S*b+py][S*c+px].  Optional bias[ch] + activation.
+template <int S>
+struct EpiPhase3D {
+    struct Params {
+        float* out;
+        int M, C, D, H, W, AD, AH, AW;
+        FastDiv div_adhw, div_ahw, div_aw;
+        const float* bias;
+        int act;
+        float slope;
+    };
+    template <int TM, int TN>
+    __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
+                                                 int n_base, int lane, int y, int z) {
+        const int col_l = lane & 31, half = lane >> 5;
+        const int pd = y / (S * S), py = (y / S) % S, px = y % S;
+        const long long chs = (long long)p.D * p.H * p.W;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= p.M) continue;
+                uint32_t n = fdiv((uint32_t)m, p.div_adhw);
+                uint32_t v = (uint32_t)m - n * (uint32_t)(p.AD * p.AH * p.AW);
+                uint32_t a = fdiv(v, p.div_ahw);
+                v -= a * (uint32_t)(p.AH * p.AW);
+                uint32_t b = fdiv(v, p.div_aw);
+                uint32_t c = v - b * (uint32_t)p.AW;
+                long long o = (long long)n * p.C * chs + ((long long)(S * a + pd) * p.H + (S * b + py)) * p.W +
+                              (S * c + px);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    int ch = n_base + j * 32 + col_l;
+                    if (ch < p.C) {
+                        float bv = p.bias ? p.bias[ch] : 0.f;
+                        p.out[o + (long long)ch * chs] = act_fwd(acc[i][j][r] + bv, p.act, p.slope);
                     }
                 }
             }

@@ -246,15 +246,17 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const f32x2* __rest
 }
 
 // per-row statistics: k = sums / inner (and per-row dgamma / dbeta for AdaIN-style affine)
+// With the unbiased variance (AdaIN) d xh_i/d x_j = rstd (delta_ij - 1/n - xh_i xh_j / (n-1)), hence the
+// second coefficient is sum(dz*xh) / (n-1).
 __global__ void row_bwd_finalize_kernel(const f32x2* __restrict__ sums, float* __restrict__ k,
                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C,
-                                        int inner, int affine_per_row) {
+                                        int inner, int affine_per_row, int unbiased) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int rows = N * C;
     if (i < rows) {
         f32x2 v = sums[i];
         k[i] = v.x / (float)inner;
-        k[rows + i] = v.y / (float)inner;
+        k[rows + i] = v.y / (float)((unbiased && inner > 1) ? inner - 1 : inner);
         if (affine_per_row) {
             if (dgamma) dgamma[i] = v.y;
             if (dbeta) dbeta[i] = v.x;
@@ -499,7 +501,7 @@ int gz_norm_act_fwd(const float* x, const float* coef, float* out, int N, int C,
 
 int gz_norm_act_bwd(const float* gout, const float* x, const float* coef, float* dx, float* dgamma, float* dbeta,
                     void* workspace, float* kbuf, int N, int C, int inner, int per_channel, int affine_per_row,
-                    int act, float slope, hipStream_t stream) {
+                    int unbiased, int act, float slope, hipStream_t stream) {
     gz::clear_stale_error();
     if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
     RowGeom rg = row_geom((long long)N * C, inner);
@@ -512,7 +514,7 @@ int gz_norm_act_bwd(const float* gout, const float* x, const float* coef, float*
     } else {
         int rows = N * C;
         hipLaunchKernelGGL(row_bwd_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream,
-                           (const f32x2*)workspace, kbuf, dgamma, dbeta, N, C, inner, affine_per_row);
+                           (const f32x2*)workspace, kbuf, dgamma, dbeta, N, C, inner, affine_per_row, unbiased);
         if (!affine_per_row && (dgamma || dbeta))
             hipLaunchKernelGGL(row_bwd_affine_kernel, dim3(C), dim3(64), 0, stream, (const f32x2*)workspace, dgamma,
                                dbeta, N, C);

@@ -495,7 +495,7 @@ class _BatchNormAct(torch.autograd.Function):
         kbuf = torch.empty(2 * C, device=x.device, dtype=torch.float32)
         ws = _norm_ws(x, N, C)
         check(lib.gz_norm_act_bwd(_p(gout), _p(x), _p(coef), _p(dx), _p(dgamma), _p(dbeta), _p(ws), _p(kbuf), N, C,
-                                  inner, 1, 0, act, slope, _stream()), "norm_act_bwd")
+                                  inner, 1, 0, 0, act, slope, _stream()), "norm_act_bwd")
         return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
                 None, None, None, None, None, None, None, None)
 
@@ -549,7 +549,7 @@ class _RowNormActBwd(torch.autograd.Function):
         kbuf = torch.empty(2 * N * C, device=x.device, dtype=torch.float32)
         ws = _norm_ws(x, N, C)
         check(lib.gz_norm_act_bwd(_p(gout), _p(x), _p(coef), _p(dx), _p(dgamma), _p(dbeta), _p(ws), _p(kbuf), N, C,
-                                  inner, 0, 0, act, slope, _stream()), "norm_act_bwd")
+                                  inner, 0, 0, 0, act, slope, _stream()), "norm_act_bwd")
         ctx.save_for_backward(gout, x, gamma, coef)
         ctx.cfg = cfg
         ctx.set_materialize_grads(False)
@@ -668,3 +668,246 @@ def clamp_(t, lo, hi):
     check(lib.gz_clamp_(_p(t), t.numel(), float(lo), float(hi), _stream()), "clamp_")
     invalidate(t)
     return t
+
+
+# ---------------------------------------------------------------------------
+# HoloGAN: 3-D transposed convolution family, AdaIN, dense layers with fused epilogue,
+# rigid-body resampling, spectral normalisation
+# ---------------------------------------------------------------------------
+_pack3_cache = {}
+
+
+def _packed3(w, kind):
+    key = (w.data_ptr(), kind)
+    cacheable = isinstance(w, torch.nn.Parameter)
+    if cacheable:
+        hit = _pack3_cache.get(key)
+        if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == tuple(w.shape):
+            return hit[3]
+    K, C, KS = w.shape[0], w.shape[1], w.shape[2]
+    if kind == "f":
+        wp = torch.empty(lib.gz_conv3d_pack_fwd_elems(K, C, KS), device=w.device, dtype=torch.float32)
+        check(lib.gz_conv3d_pack_fwd(_p(w), _p(wp), K, C, KS, _stream()), "conv3d_pack_fwd")
+    else:
+        wp = torch.empty(lib.gz_conv3d_pack_dgrad_elems(K, C, KS, 2), device=w.device, dtype=torch.float32)
+        check(lib.gz_conv3d_pack_dgrad(_p(w), _p(wp), K, C, KS, 2, 1, _stream()), "conv3d_pack_dgrad")
+    if cacheable:
+        _pack3_cache[key] = (weakref.ref(w), w._version, tuple(w.shape), wp)
+    return wp
+
+
+def _conv3d_fwd_raw(x, w, bias, act, slope):
+    N, C, D, H, W = x.shape
+    K, KS = w.shape[0], w.shape[2]
+    OD, OH, OW = D // 2, H // 2, W // 2
+    y = torch.empty((N, K, OD, OH, OW), device=x.device, dtype=torch.float32)
+    check(lib.gz_conv3d_fwd(_p(x), _p(_packed3(w, "f")), _p(bias), _p(y), N, C, D, H, W, K, OD, OH, OW, KS, 2, 1, act,
+                            slope, _stream()), "conv3d_fwd")
+    return y
+
+
+def _conv3d_dgrad_raw(g, w, bias, act, slope):
+    N, K, OD, OH, OW = g.shape
+    C, KS = w.shape[1], w.shape[2]
+    D, H, W = 2 * OD, 2 * OH, 2 * OW
+    x = torch.empty((N, C, D, H, W), device=g.device, dtype=torch.float32)
+    check(lib.gz_conv3d_dgrad(_p(g), _p(_packed3(w, "d")), _p(bias), _p(x), N, C, D, H, W, K, OD, OH, OW, KS, 2, 1,
+                              act, slope, _stream()), "conv3d_dgrad")
+    return x
+
+
+def _conv3d_wgrad_raw(x, g, ks):
+    N, C, D, H, W = x.shape
+    _, K, OD, OH, OW = g.shape
+    dw = torch.empty((K, C, ks, ks, ks), device=x.device, dtype=torch.float32)
+    nbytes = lib.gz_conv3d_wgrad_workspace_bytes(N, C, K, OD, OH, OW, ks)
+    ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+    check(lib.gz_conv3d_wgrad(_p(x), _p(g), _p(dw), _p(ws), nbytes, N, C, D, H, W, K, OD, OH, OW, ks, 2, 1, _stream()),
+          "conv3d_wgrad")
+    return dw
+
+
+class _Conv3DDg(torch.autograd.Function):
+    """x = conv_transpose3d(g, w) + bias   (k3, s2, p1, output_padding 1)"""
+
+    @staticmethod
+    def forward(ctx, g, w, bias):
+        g, w = _req(g, "g"), _req(w, "w")
+        ctx.save_for_backward(g, w)
+        ctx.has_bias = bias is not None
+        return _conv3d_dgrad_raw(g, w, bias, ACT_NONE, 0.0)
+
+    @staticmethod
+    def backward(ctx, v):
+        g, w = ctx.saved_tensors
+        v = _req(v)
+        dg = _Conv3DF.apply(v, w) if ctx.needs_input_grad[0] else None
+        dw = _Conv3DWg.apply(v, g, w.shape[2]) if ctx.needs_input_grad[1] else None
+        db = v.sum((0, 2, 3, 4)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dg, dw, db
+
+
+class _Conv3DF(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x, w = _req(x, "x"), _req(w, "w")
+        ctx.save_for_backward(x, w)
+        return _conv3d_fwd_raw(x, w, None, ACT_NONE, 0.0)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _req(gy)
+        dx = _Conv3DDg.apply(gy, w, None) if ctx.needs_input_grad[0] else None
+        dw = _Conv3DWg.apply(x, gy, w.shape[2]) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+class _Conv3DWg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, ks):
+        x, g = _req(x, "x"), _req(g, "g")
+        ctx.save_for_backward(x, g)
+        return _conv3d_wgrad_raw(x, g, ks)
+
+    @staticmethod
+    def backward(ctx, v):
+        x, g = ctx.saved_tensors
+        v = _req(v)
+        dx = _Conv3DDg.apply(g, v, None) if ctx.needs_input_grad[0] else None
+        dg = _Conv3DF.apply(x, v) if ctx.needs_input_grad[1] else None
+        return dx, dg, None
+
+
+def conv_transpose3d(x, w, bias=None):
+    """nn.ConvTranspose3d(kernel 3, stride 2, padding 1, output_padding 1); w [Cin, Cout, 3, 3, 3]."""
+    return _Conv3DDg.apply(x, w, bias)
+
+
+class _AdaINAct(torch.autograd.Function):
+    """act(scale[n,c] * (x - mean) * rsqrt(var_unbiased + eps) + bias[n,c]); reference AdaIn
+    (core/models/hologan_generator.py:333-345) followed by ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, scale, bias, eps, act, slope):
+        x, scale, bias = _req(x, "x"), _req(scale, "scale"), _req(bias, "bias")
+        N, C = x.shape[:2]
+        inner = x.numel() // (N * C)
+        coef = torch.empty(4 * N * C, device=x.device, dtype=torch.float32)
+        ws = _norm_ws(x, N, C)
+        st = _stream()
+        check(lib.gz_rownorm_stats(_p(x), _p(scale), _p(bias), _p(coef), _p(ws), N, C, inner, eps, 1, 1, st),
+              "rownorm_stats(adain)")
+        out = torch.empty_like(x)
+        check(lib.gz_norm_act_fwd(_p(x), _p(coef), _p(out), N, C, inner, 0, act, slope, st), "norm_act_fwd")
+        ctx.save_for_backward(x, coef)
+        ctx.cfg = (N, C, inner, act, slope)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        x, coef = ctx.saved_tensors
+        N, C, inner, act, slope = ctx.cfg
+        gout = _req(gout)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ds = torch.empty((N, C), device=x.device, dtype=torch.float32)
+        db = torch.empty((N, C), device=x.device, dtype=torch.float32)
+        kbuf = torch.empty(2 * N * C, device=x.device, dtype=torch.float32)
+        ws = _norm_ws(x, N, C)
+        check(lib.gz_norm_act_bwd(_p(gout), _p(x), _p(coef), _p(dx), _p(ds), _p(db), _p(ws), _p(kbuf), N, C, inner, 0,
+                                  1, 1, act, slope, _stream()), "norm_act_bwd(adain)")
+        return dx, ds, db, None, None, None
+
+
+def adain_act(x, scale, bias, eps=1e-8, act=ACT_RELU, slope=0.0):
+    return _AdaINAct.apply(x, scale, bias, eps, act, slope)
+
+
+class _LinearAct(torch.autograd.Function):
+    """act(x @ W^T + b) with bias and activation fused in the GEMM epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, slope):
+        x, weight = _req(x, "x"), _req(weight, "weight")
+        out = gemm(x, weight, bias, trans_b=True, act=act, slope=slope)
+        ctx.save_for_backward(x, weight, out if act != ACT_NONE else None)
+        ctx.act, ctx.slope, ctx.has_bias = act, slope, bias is not None
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, weight, out = ctx.saved_tensors
+        g = _req(g)
+        if ctx.act != ACT_NONE:
+            if g.numel() % 4 == 0:
+                g = _act_bwd_raw(g, out, ctx.act, ctx.slope)
+            else:   # odd tiny shapes
+                d = {ACT_RELU: (out > 0).float(), ACT_TANH: 1 - out * out}.get(ctx.act)
+                g = g * (d if d is not None else torch.where(out > 0, 1.0, ctx.slope))
+        dx = gemm(g, weight) if ctx.needs_input_grad[0] else None
+        dw = gemm(g, x, trans_a=True) if ctx.needs_input_grad[1] else None
+        db = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None, None
+
+
+def linear_act(x, weight, bias=None, act=ACT_NONE, slope=0.0):
+    return _LinearAct.apply(x, weight, bias, act, slope)
+
+
+class _RigidResample(torch.autograd.Function):
+    """[N,C,S,S,S] voxels + [N,16] inverse view matrices -> [N, C*S, S, S] projected feature map."""
+
+    @staticmethod
+    def forward(ctx, vox, minv):
+        vox, minv = _req(vox, "vox"), _req(minv, "minv")
+        N, C, S = vox.shape[0], vox.shape[1], vox.shape[2]
+        out = torch.empty((N, C * S, S, S), device=vox.device, dtype=torch.float32)
+        check(lib.gz_rigid_resample_fwd(_p(vox), _p(minv), _p(out), None, N, C, S, _stream()), "rigid_resample_fwd")
+        ctx.save_for_backward(minv)
+        ctx.shape = (N, C, S)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (minv,) = ctx.saved_tensors
+        N, C, S = ctx.shape
+        g = _req(g)
+        gv = torch.empty((N, C, S, S, S), device=g.device, dtype=torch.float32)
+        check(lib.gz_rigid_resample_bwd(_p(g), _p(minv), _p(gv), N, C, S, _stream()), "rigid_resample_bwd")
+        return gv, None
+
+
+def rigid_resample(vox, minv):
+    return _RigidResample.apply(vox, minv)
+
+
+def rigid_resample_indices(vox, minv):
+    """Debug / test hook: the int64 corner indices idx_a..idx_h the kernel uses, [8, N*S^3]."""
+    N, C, S = vox.shape[0], vox.shape[1], vox.shape[2]
+    out = torch.empty((N, C * S, S, S), device=vox.device, dtype=torch.float32)
+    idx = torch.empty((8, N * S ** 3), device=vox.device, dtype=torch.int64)
+    check(lib.gz_rigid_resample_fwd(_p(_req(vox)), _p(_req(minv)), _p(out), _p(idx), N, C, S, _stream()),
+          "rigid_resample_fwd")
+    return out, idx
+
+
+def spectral_normalize(weight_orig, u, v, training, eps=1e-12):
+    """torch.nn.utils.spectral_norm's weight: one power iteration (training: u, v updated in place),
+    then weight_orig / sigma with sigma = u^T W v differentiable w.r.t. weight_orig.  The two
+    matrix-vector products per iteration run on gz_coldot / gz_rowdot."""
+    w_mat = weight_orig.reshape(weight_orig.shape[0], -1)
+    if training:
+        with torch.no_grad():
+            wd = _req(w_mat.detach())
+            v_new = _coldot_raw(u, wd)                       # W^T u
+            v_new = v_new / v_new.norm().clamp_min(eps)
+            u_new = _rowdot_raw(wd, v_new, True)             # W v
+            u_new = u_new / u_new.norm().clamp_min(eps)
+            v.copy_(v_new)
+            u.copy_(u_new)
+    uc, vc = u.clone(), v.clone()
+    sigma = torch.dot(uc, _DotF.apply(w_mat, vc))
+    return weight_orig / sigma

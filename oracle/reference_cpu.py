@@ -233,6 +233,14 @@ class WGANGP(_StepBase):
             return loss
 
 
+class HOLOGAN(_StepBase):
+    """core/lightning_module.py:209-237 (restated in oracle/hologan_cpu.py)"""
+
+    def training_step(self, batch, batch_idx, optimizer_idx):
+        from .hologan_cpu import hologan_training_step
+        return hologan_training_step(self, batch, batch_idx, optimizer_idx)
+
+
 # --------------------------------------------------------------------------
 # harness semantics (Lightning's per-batch optimizer alternation + toggle)
 # --------------------------------------------------------------------------
@@ -269,6 +277,27 @@ class lightning_module:            # noqa: N801
     pass
 
 
+class utils:                       # noqa: N801
+    class hologan:                 # noqa: N801
+        pass
+
+
+def _wire_hologan():
+    from . import hologan_cpu as H
+
+    class hologan_generator:       # noqa: N801
+        Generator = H.Generator
+
+    class hologan_discriminator:   # noqa: N801
+        Discriminator = H.Discriminator
+
+    models.hologan_generator = hologan_generator
+    models.hologan_discriminator = hologan_discriminator
+    utils.hologan.create_hologan_lr_scheduler = staticmethod(H.create_hologan_lr_scheduler)
+
+
+_wire_hologan()
+lightning_module.HOLOGAN = HOLOGAN
 models.standard_networks.Generator = Generator
 models.standard_networks.Discriminator = Discriminator
 lightning_module.DCGAN = DCGAN

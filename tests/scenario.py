@@ -18,11 +18,19 @@ SIZES = {
     "full": (64, 8, 100),
 }
 STD_EXPTS = ("dc_gan", "wgan", "wgan_gp")
+ALL_EXPTS = STD_EXPTS + ("hologan",)
+
+
+def sizes(expt, size):
+    feats, bs, zdim = SIZES[size]
+    if expt == "hologan" and size == "full":
+        return 32, 4, 128        # in_planes 32 (reference default 64), z 128: keeps the CPU runs short
+    return feats, bs, zdim
 
 
 def make_inputs(expt, size, stable=False):
     """Deterministic scenario inputs.  ``stable``: reals in [0.1, 1] (see stabilise())."""
-    feats, bs, zdim = SIZES[size]
+    feats, bs, zdim = sizes(expt, size)
     uniform = expt == "hologan"
     inp = {}
     for pair in range(2):
@@ -120,6 +128,7 @@ def run_scenario(step, inputs, device="cpu", full=True, set_alpha=None, pairs=2,
     labels = torch.zeros(len(inputs["real_d0"]), dtype=torch.int64, device=dev)
 
     probe = copy.deepcopy(step)
+    np.random.seed(7000)            # HoloGAN draws its views from numpy's global generator
     with torch.no_grad():
         fake = probe.generator(inputs["z_d0"].to(dev))
         d_out = probe.discriminator(fake)
@@ -135,6 +144,7 @@ def run_scenario(step, inputs, device="cpu", full=True, set_alpha=None, pairs=2,
             if set_alpha is not None:
                 set_alpha(step, inputs[f"alpha{pair}"])
             _toggle(step, idx)
+            view_seed = 7001 + 2 * pair + idx
             if shadow is not None and pair >= 1:
                 for net in ("generator", "discriminator"):
                     sd = {k: v.detach().cpu() for k, v in getattr(step, net).state_dict().items()}
@@ -143,8 +153,10 @@ def run_scenario(step, inputs, device="cpu", full=True, set_alpha=None, pairs=2,
                 if set_alpha is not None:
                     set_alpha(shadow, inputs[f"alpha{pair}"])
                 _toggle(shadow, idx)
+                np.random.seed(view_seed)
                 sl = shadow.training_step((inputs[f"real_{tag}{pair}"], labels.cpu()), 2 * pair + idx, idx)
                 out[f"shadow_loss_{tag}{pair}"] = np.float64(sl.item())
+            np.random.seed(view_seed)
             loss = step.training_step((real, labels), 2 * pair + idx, idx)
             loss.backward()
             out[f"loss_{tag}{pair}"] = np.float64(loss.item())

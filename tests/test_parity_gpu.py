@@ -16,17 +16,17 @@ TOL = 1e-3
 
 
 def build_product_step(expt, size):
-    feats, bs, zdim = scenario.SIZES[size]
+    feats, bs, zdim = scenario.sizes(expt, size)
     cfg = make_cfg(expt, batch_size=bs, features=feats, noise_dim=zdim)
     torch.manual_seed(42)
     return locate(cfg.model.lm["_target_"])(cfg, logging_dir=None)
 
 
-LR = {"dc_gan": 2e-4, "wgan": 5e-5, "wgan_gp": 1e-4}
+LR = {"dc_gan": 2e-4, "wgan": 5e-5, "wgan_gp": 1e-4, "hologan": 1e-4}
 
 
 @pytest.mark.parametrize("size", ["tiny", "full"])
-@pytest.mark.parametrize("expt", scenario.STD_EXPTS)
+@pytest.mark.parametrize("expt", scenario.ALL_EXPTS)
 def test_product_matches_reference_fixture(expt, size):
     """Forward quantities at 1e-3 max-norm; gradient-side quantities at max(5e-3, 10 x the
     reference's own fp32-vs-fp64 discrepancy) in relative L2 -- see compare().  The plain 1e-3 bar
@@ -48,7 +48,9 @@ def test_product_matches_reference_fixture(expt, size):
     frac, n = update_agreement(out, golden, scenario.initial_params(build_oracle_step(expt, size), full),
                                LR[expt])
     print(f"{expt}/{size}: {frac:.3f} of {n} parameter updates agree")
-    assert frac >= 0.9 and n > 100
+    # HoloGAN: conv biases in front of AdaIN have an exactly-zero gradient and the second-pair gradients
+    # inherit the first pair's +-lr noise through AdaIN's 1/sigma, so fewer entries agree
+    assert frac >= (0.6 if expt == "hologan" else 0.9) and n > 100
 
 
 @pytest.mark.parametrize("expt", ["dc_gan", "wgan_gp"])
