@@ -22,7 +22,14 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-FLOP_PER_SAMPLE_PAIR = 4_929_880_064      # BASELINE.md section 3 (D step 2,054,389,760 + G step 2,875,490,304)
+# algorithmic conv/GEMM FLOP per sample per optimizer cycle (BASELINE.md section 3 / SURVEY.md 8-d)
+FLOP_PER_SAMPLE_CYCLE = {
+    "dc_gan": 4_929_880_064,              # D step 2,054,389,760 + G step 2,875,490,304
+    "wgan": 5 * 2_054_389_760 + 2_875_490_304,
+    "wgan_gp": 6_175_700_000,             # D step 3.3002 G (3 D fwd + GP double backward) + G step 2.8755 G
+    "hologan": 29_060_000_000,            # D + G + G at 64x64: 5.6244 G + 2 x 11.7195 G
+}
+DEFAULT_BATCH = {"dc_gan": 512, "wgan": 512, "wgan_gp": 256, "hologan": 64}
 PEAK_FP32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
 
 
@@ -126,12 +133,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch (BASELINE configs[1]: 512)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="per-GPU batch (default: BASELINE configs: dc_gan 512, wgan_gp 256, hologan 64)")
     ap.add_argument("--expt", default="dc_gan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bs128", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = DEFAULT_BATCH.get(args.expt, 128)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,7 +174,9 @@ def main():
     launches_per_pair = len(timer.records) // (args.steps + args.warmup) if timer.records else 0
     timer.records = timer.records[args.warmup * launches_per_pair:]
     ms_per_step = dt / args.steps * 1e3
-    value = 2 * args.batch * world * args.steps / dt
+    per_cycle = len(trainer.order)            # batches per optimizer cycle: 2 (dc_gan, wgan_gp), 6 (wgan), 3 (hologan)
+    value = per_cycle * args.batch * world * args.steps / dt
+    flop_cycle = FLOP_PER_SAMPLE_CYCLE[args.expt] * args.batch
 
     out = {
         "metric": "images/sec (G+D step) at 64x64",
@@ -179,10 +191,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "%s synthetic 64x64 bs=%d/GPU, G+D pair (Lightning alternation + toggle), Adam, fp32"
-                               % (args.expt, args.batch),
+        "config": {"workload": "%s synthetic 64x64 bs=%d/GPU, one optimizer cycle of %d batches (Lightning alternation "
+                               "+ toggle), reference optimizer, fp32" % (args.expt, args.batch, per_cycle),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                   "images_counted": "2*bs*n_gpus per pair (both batches)"},
+                   "images_counted": "%d*bs*n_gpus per step (every batch of the cycle)" % per_cycle},
     }
 
     if rank == 0:
@@ -200,21 +212,20 @@ def main():
                 "all_igemm": {k: {"launches": v[0], "ms": round(v[1], 2),
                                   "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in sorted(agg.items())},
                 "igemm_share_of_step": round(total_ms / (ms_per_step * args.steps), 3),
-                "whole_step": {"flop_per_pair": FLOP_PER_SAMPLE_PAIR * args.batch,
-                               "achieved": round(FLOP_PER_SAMPLE_PAIR * args.batch / (ms_per_step * 1e-3) / 1e12, 2),
-                               "frac": round(FLOP_PER_SAMPLE_PAIR * args.batch / (ms_per_step * 1e-3) / 1e12
-                                             / PEAK_FP32_MFMA_TFLOPS, 4)},
+                "whole_step": {"flop_per_step": flop_cycle,
+                               "achieved": round(flop_cycle / (ms_per_step * 1e-3) / 1e12, 2),
+                               "frac": round(flop_cycle / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
             }
-        if world == 1 and not args.no_bs128 and args.batch != 128:
+        if world == 1 and not args.no_bs128 and args.batch != 128 and args.expt == "dc_gan":
             # BASELINE.json's metric string quotes bs=128/GPU: report it beside the bs=512 headline
             del trainer, module
             torch.cuda.empty_cache()
             m2, t2 = build_trainer(args.expt, 128, device, 1)
             b2 = synthetic_batch(128, device, 0)
             dt2 = timed_pairs(t2, b2, args.steps, args.warmup, 1)
-            out["bs128"] = {"value": round(2 * 128 * args.steps / dt2, 1), "unit": "images/s",
+            out["bs128"] = {"value": round(per_cycle * 128 * args.steps / dt2, 1), "unit": "images/s",
                             "ms_per_step": round(dt2 / args.steps * 1e3, 3)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.expt == "dc_gan":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -175,26 +175,50 @@ static int dispatch_dgrad(const float* y, const float* wp, const float* bias, fl
 // ---------------------------------------------------------------------------
 // Wg
 // ---------------------------------------------------------------------------
-static int wgrad_splits(long long tiles, int chunks) {
-    if (tiles >= 256) return 1;
-    long long want = (512 + tiles - 1) / tiles;       // aim at ~2 workgroups per CU
+static int wg_target() {
+    static int t = -1;
+    if (t < 0) {
+        const char* e = getenv("GZ_WG_TARGET");
+        t = e ? atoi(e) : 1536;
+        if (t < 1) t = 1;
+    }
+    return t;
+}
+
+// Split-K so that ~4 workgroups per CU are in flight: the wgrad loaders are gather-heavy and only
+// reach the MFMA rate when several workgroups per SIMD overlap their load and MFMA phases.
+static int wgrad_splits(long long tiles, int chunks, bool big_tile = true) {
+    long long target = big_tile ? wg_target() : 512;   // narrow tiles (3-channel layers) are slab-traffic bound
+    if (tiles * 4 >= target * 3) return 1;
+    long long want = (target + tiles - 1) / tiles;
     long long cap = chunks / 8 > 0 ? chunks / 8 : 1;  // keep >= 8 chunks (128 pixels) per split
     long long s = want < cap ? want : cap;
     return (int)(s < 1 ? 1 : s);
 }
 
-template <class G, class Cfg>
-static int run_wgrad(const float* x, const float* y, float* dw, float* ws, size_t ws_bytes, const ConvShape& s,
-                     hipStream_t st) {
-    using AL = WgALoader<Cfg::BM>;
-    using BL = WgBLoader<Cfg::BN, G::kh, G::kw, G::s, G::p>;
-    const int KTOT = s.N * s.OH * s.OW;
-    const int NTOT = s.C * G::kh * G::kw;
-    typename AL::Params pa{y, s, make_fastdiv(s.OH * s.OW), KTOT};
-    typename BL::Params pb{x, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW), KTOT, NTOT};
+// can a 16-pixel K chunk be taken as whole row segments of one image? (see WgBLoaderRow)
+template <class G>
+static bool wg_row_geom(const ConvShape& s, WgRowGeom* g) {
+    int CW = s.OW < 16 ? s.OW : 16;
+    if (CW <= 0 || 16 % CW) return false;
+    int R = 16 / CW;
+    if (s.OW % CW || s.OH % R) return false;
+    auto mx = [](int a, int b) { return a > b ? a : b; };
+    if (G::s * R < mx(G::p, G::kh - 1 - G::p) || G::s * CW < mx(G::p, G::kw - 1 - G::p)) return false;
+    // a negative offset must never survive masking: the only negative cases are the flagged ones
+    g->CW = CW;
+    g->R = R;
+    g->div_ohw = make_fastdiv(s.OH * s.OW);
+    g->div_ow = make_fastdiv(s.OW);
+    return true;
+}
+
+template <class G, class Cfg, class AL, class BL>
+static int launch_wgrad(const typename AL::Params& pa, const typename BL::Params& pb, float* dw, float* ws,
+                        size_t ws_bytes, const ConvShape& s, int KTOT, int NTOT, hipStream_t st) {
     long long tiles = (long long)((s.K + Cfg::BM - 1) / Cfg::BM) * ((NTOT + Cfg::BN - 1) / Cfg::BN);
     int chunks = (KTOT + BK - 1) / BK;
-    int splits = wgrad_splits(tiles, chunks);
+    int splits = wgrad_splits(tiles, chunks, Cfg::BM * Cfg::BN >= 128 * 128);
     long long count = (long long)s.K * NTOT;
     if (splits > 1) {
         long long max_splits = (long long)(ws_bytes / 4) / count;
@@ -214,6 +238,27 @@ static int run_wgrad(const float* x, const float* y, float* dw, float* ws, size_
         rc = launch_status();
     }
     return rc;
+}
+
+template <class G, class Cfg>
+static int run_wgrad(const float* x, const float* y, float* dw, float* ws, size_t ws_bytes, const ConvShape& s,
+                     hipStream_t st) {
+    const int KTOT = s.N * s.OH * s.OW;
+    const int NTOT = s.C * G::kh * G::kw;
+    WgRowGeom rg;
+    static int generic_only = getenv("GZ_WG_GENERIC") ? 1 : 0;
+    if (!generic_only && wg_row_geom<G>(s, &rg)) {
+        using AL = WgALoaderRow<Cfg::BM>;
+        using BL = WgBLoaderRow<Cfg::BN, G::kh, G::kw, G::s, G::p>;
+        typename AL::Params pa{y, s, rg, KTOT};
+        typename BL::Params pb{x, s, rg, KTOT, NTOT};
+        return launch_wgrad<G, Cfg, AL, BL>(pa, pb, dw, ws, ws_bytes, s, KTOT, NTOT, st);
+    }
+    using AL = WgALoader<Cfg::BM>;
+    using BL = WgBLoader<Cfg::BN, G::kh, G::kw, G::s, G::p>;
+    typename AL::Params pa{y, s, make_fastdiv(s.OH * s.OW), KTOT};
+    typename BL::Params pb{x, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW), KTOT, NTOT};
+    return launch_wgrad<G, Cfg, AL, BL>(pa, pb, dw, ws, ws_bytes, s, KTOT, NTOT, st);
 }
 
 template <class G>

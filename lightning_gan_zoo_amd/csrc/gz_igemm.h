@@ -444,6 +444,129 @@ struct WgBLoader {
 };
 
 // ---------------------------------------------------------------------------
+// Row-aligned weight-gradient loaders.  When a K chunk (16 output pixels) is R = 16/CW whole
+// row segments of CW = min(OW, 16) pixels inside one image, the pixel -> (n, oy, ox) decode is
+// wave-uniform (scalar unit, once per chunk) and every lane's address is
+//     scalar chunk base + loop-invariant per-lane offset,
+// exactly like the forward loader; padding is a 4-bit (top, bottom, left, right) test against the
+// chunk's position.  Preconditions (checked by the launcher): OW % CW == 0, OH % R == 0,
+// S*R >= max(P, KH-1-P), S*CW >= max(P, KW-1-P).
+// ---------------------------------------------------------------------------
+struct WgRowGeom {
+    int CW, R;               // chunk = R rows x CW columns of output pixels
+    FastDiv div_ohw, div_ow;
+};
+
+template <int BM>
+struct WgALoaderRow {
+    struct Params {
+        const float* y;
+        ConvShape s;
+        WgRowGeom g;
+        int KTOT;
+    };
+    static constexpr int LD = BM + 2;
+    static constexpr int EPT = BM / 16;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[EPT];
+    int kl, m_l, OHW, OW, KOHW;
+    FastDiv div_ohw, div_ow;
+    float r[EPT];
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        const ConvShape& s = p.s;
+        rsrc = make_rsrc(p.y, (uint32_t)s.N * s.K * s.OH * s.OW * 4u);
+        kl = tid & 15;
+        m_l = tid >> 4;
+        OHW = s.OH * s.OW; OW = s.OW; KOHW = s.K * OHW;
+        div_ohw = p.g.div_ohw; div_ow = p.g.div_ow;
+        const int dy = kl / p.g.CW, dx = kl % p.g.CW;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            int ko = tile * BM + m_l + 16 * j;
+            voff[j] = ko < s.K ? (uint32_t)(ko * OHW + dy * OW + dx) * 4u : OOB;
+        }
+    }
+    __device__ __forceinline__ void issue(int kc) {
+        // wave-uniform decode of the chunk's first pixel
+        uint32_t p0 = (uint32_t)kc * BK;
+        uint32_t n = fdiv(p0, div_ohw);
+        uint32_t rem = p0 - n * (uint32_t)OHW;
+        uint32_t soff = (n * (uint32_t)KOHW + rem) * 4u;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) r[j] = bload(rsrc, voff[j], soff);
+    }
+    __device__ __forceinline__ void commit(float* dst) const {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) dst[kl * LD + m_l + 16 * j] = r[j];
+    }
+};
+
+template <int BN, int KH, int KW, int S, int P>
+struct WgBLoaderRow {
+    struct Params {
+        const float* x;
+        ConvShape s;
+        WgRowGeom g;
+        int KTOT, NTOT;
+    };
+    static constexpr int LD = BN + 2;
+    static constexpr int EPT = BN / 16;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[EPT];      // loop-invariant byte offset (may wrap for padded taps: those are masked)
+    uint32_t flags[EPT];     // bit0 top, bit1 bottom, bit2 left, bit3 right padding; bit4 column out of range
+    int kl, n_l, OHW, OW, OH, W, CHW, CW, R;
+    FastDiv div_ohw, div_ow;
+    float r[EPT];
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        const ConvShape& s = p.s;
+        // per-lane offsets of interior chunks can be negative (taps above / left of the chunk's first
+        // input pixel); voffset is unsigned, so the descriptor base is moved back by the largest
+        // negative offset and every voffset forward by the same amount (never dereferenced there:
+        // such taps are either inside the tensor or masked)
+        const int shift = P * s.W + P;
+        rsrc = make_rsrc(p.x - shift, (uint32_t)(s.N * s.C * s.H * s.W + shift) * 4u);
+        kl = tid & 15;
+        n_l = tid >> 4;
+        OHW = s.OH * s.OW; OW = s.OW; OH = s.OH; W = s.W; CHW = s.C * s.H * s.W;
+        CW = p.g.CW; R = p.g.R;
+        div_ohw = p.g.div_ohw; div_ow = p.g.div_ow;
+        const int dy = kl / CW, dx = kl % CW;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            int col = tile * BN + n_l + 16 * j;
+            int c = col / (KH * KW);
+            int tap = col - c * (KH * KW);
+            int ry = S * dy + tap / KW - P;          // input row relative to the chunk's first input row
+            int rx = S * dx + tap % KW - P;
+            voff[j] = (uint32_t)((c * s.H + ry) * W + rx + shift) * 4u;
+            uint32_t f = 0;
+            if (ry < 0) f |= 1u;
+            if (S * (OH - R) + ry >= s.H) f |= 2u;
+            if (rx < 0) f |= 4u;
+            if (S * (OW - CW) + rx >= W) f |= 8u;
+            if (col >= p.NTOT) f |= 16u;
+            flags[j] = f;
+        }
+    }
+    __device__ __forceinline__ void issue(int kc) {
+        uint32_t p0 = (uint32_t)kc * BK;
+        uint32_t n = fdiv(p0, div_ohw);
+        uint32_t rem = p0 - n * (uint32_t)OHW;
+        uint32_t oy0 = fdiv(rem, div_ow);
+        uint32_t ox0 = rem - oy0 * (uint32_t)OW;
+        uint32_t soff = (n * (uint32_t)CHW + (oy0 * S) * (uint32_t)W + ox0 * S) * 4u;
+        uint32_t cond = 16u | (oy0 == 0 ? 1u : 0u) | ((int)oy0 + R == OH ? 2u : 0u) | (ox0 == 0 ? 4u : 0u) |
+                        ((int)ox0 + CW == OW ? 8u : 0u);
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) r[j] = bload(rsrc, (flags[j] & cond) ? OOB : voff[j], soff);
+    }
+    __device__ __forceinline__ void commit(float* dst) const {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) dst[kl * LD + n_l + 16 * j] = r[j];
+    }
+};
+
+// ---------------------------------------------------------------------------
 // 3-D (cubic kernel KS, stride S, padding P) variants: HoloGAN's ConvTranspose3d(k3, s2, p1, op1)
 // x: [N, C, D, H, W] image side, y: [N, K, OD, OH, OW] feature side, w: [K, C, KS, KS, KS]
 // ---------------------------------------------------------------------------
