@@ -141,6 +141,96 @@ static int dispatch_fwd(const float* x, const float* wp, const float* bias, floa
 }
 
 // ---------------------------------------------------------------------------
+// Dg with <= 4 image channels (the generator's output layer, 128 -> 3 @ 32 -> 64, and the
+// discriminator's input gradient in the gradient penalty): an MFMA tile would waste 29 of 32
+// columns, and the layer is HBM-bound anyway (reads 268 MB, 6.4 GFLOP at bs 512).  Direct VALU
+// kernel: one lane per input position (n, a, b) produces the 2x2 output pixels of all channels
+// from the 3x3 neighbourhood of y; lanes run along b so loads and the 8-byte stores coalesce; the
+// per-(phase, ko, tap) weights are wave-uniform 16-byte rows of the packed dgrad image (scalar
+// loads).  k4 s2 p1 only.
+// ---------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void dgrad_smallc_k4s2p1_kernel(const float* __restrict__ y,
+                                                                  const float* __restrict__ wp,
+                                                                  const float* __restrict__ bias,
+                                                                  float* __restrict__ x, ConvShape s,
+                                                                  FastDiv div_ohw, FastDiv div_ow, int act,
+                                                                  float slope) {
+    const int OHW = s.OH * s.OW;
+    const uint32_t M = (uint32_t)s.N * OHW;
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    const bool m_ok = m < M;
+    const uint32_t n = fdiv(m, div_ohw);
+    const uint32_t pix = m - n * (uint32_t)OHW;
+    const int a = (int)fdiv(pix, div_ow);
+    const int b = (int)(pix - (uint32_t)a * (uint32_t)s.OW);
+    __amdgpu_buffer_rsrc_t rsrc = make_rsrc(y, (uint32_t)s.N * s.K * OHW * 4u);
+    uint32_t voff[3][3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            int oy = a + dy - 1, ox = b + dx - 1;
+            bool ok = m_ok && (unsigned)oy < (unsigned)s.OH && (unsigned)ox < (unsigned)s.OW;
+            voff[dy][dx] = ok ? (n * (uint32_t)(s.K * OHW) + (uint32_t)(oy * s.OW + ox)) * 4u : OOB;
+        }
+    float acc[2][2][C];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[i][j][c] = 0.f;
+    const long long phase_stride = (long long)s.K * 16;    // floats: K * 4 taps * ldc(4)
+    for (int ko = 0; ko < s.K; ++ko) {
+        float v[3][3];
+        const uint32_t soff = (uint32_t)ko * (uint32_t)OHW * 4u;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) v[dy][dx] = bload(rsrc, voff[dy][dx], soff);
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                const float* wrow = wp + (py * 2 + px) * phase_stride + (long long)ko * 16;
+#pragma unroll
+                for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < 2; ++tx) {
+                        // oy = a + (py+1)/2 - ty  -> neighbourhood row index (oy - a + 1)
+                        const float yv = v[(py + 1) / 2 - ty + 1][(px + 1) / 2 - tx + 1];
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wrow + (ty * 2 + tx) * 4);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[py][px][c] = fmaf(yv, w4[c], acc[py][px][c]);
+                    }
+            }
+    }
+    if (!m_ok) return;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+            f32x2 o;
+            o.x = act_fwd(acc[py][0][c] + bv, act, slope);
+            o.y = act_fwd(acc[py][1][c] + bv, act, slope);
+            float* dst = x + (((long long)n * C + c) * s.H + (2 * a + py)) * s.W + 2 * b;
+            *reinterpret_cast<f32x2*>(dst) = o;
+        }
+    }
+}
+
+template <int C>
+static int run_dgrad_smallc(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s, int act,
+                            float slope, hipStream_t st) {
+    long long M = (long long)s.N * s.OH * s.OW;
+    hipLaunchKernelGGL(dgrad_smallc_k4s2p1_kernel<C>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, y, wp, bias,
+                       x, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW), act, slope);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------
 // Dg
 // ---------------------------------------------------------------------------
 template <class G, class Cfg>
@@ -163,6 +253,15 @@ template <class G>
 static int dispatch_dgrad(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s,
                           int act, float slope, hipStream_t st) {
     if (s.H % G::s || s.W % G::s) return GZ_ERR_UNSUPPORTED;
+    if (G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1 && s.C <= 4 && s.H == 2 * s.OH && s.W == 2 * s.OW &&
+        (((uintptr_t)x & 7) == 0) && !getenv("GZ_NO_SMALLC")) {
+        switch (s.C) {
+            case 1: return run_dgrad_smallc<1>(y, wp, bias, x, s, act, slope, st);
+            case 2: return run_dgrad_smallc<2>(y, wp, bias, x, s, act, slope, st);
+            case 3: return run_dgrad_smallc<3>(y, wp, bias, x, s, act, slope, st);
+            default: return run_dgrad_smallc<4>(y, wp, bias, x, s, act, slope, st);
+        }
+    }
     long long M = (long long)s.N * (s.H / G::s) * (s.W / G::s);
     switch (pick_tile(M, s.C, G::s * G::s)) {
         case T128x128: return run_dgrad<G, Cfg128x128>(y, wp, bias, x, s, act, slope, st);
