@@ -33,14 +33,14 @@ DEFAULT_BATCH = {"dc_gan": 512, "wgan": 512, "wgan_gp": 256, "hologan": 64}
 PEAK_FP32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
 
 
-def build_trainer(expt, batch, device, world):
+def build_trainer(expt, batch, device, world, force_sync=False):
     from lightning_gan_zoo_amd.config import locate, make_cfg
     from lightning_gan_zoo_amd.ddp import GradSync
     from lightning_gan_zoo_amd.harness import Trainer
     cfg = make_cfg(expt, batch_size=batch)
     torch.manual_seed(42)                 # run_network.py:27, same seed on every rank
     module = locate(cfg.model.lm["_target_"])(cfg, None).to(device)
-    sync = GradSync(module) if world > 1 else None
+    sync = GradSync(module) if (world > 1 or force_sync) else None
     return module, Trainer(module, grad_sync=sync)
 
 
@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bs128", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--force-grad-sync", action="store_true",
+                    help="use the data-parallel gradient path (flat buffers, deferred step) even on one rank")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = DEFAULT_BATCH.get(args.expt, 128)
@@ -158,7 +160,9 @@ def main():
 
     # the host side of the step is launch-only; a big OpenMP team only burns the container's CPU quota
     torch.set_num_threads(min(8, torch.get_num_threads()))
-    module, trainer = build_trainer(args.expt, args.batch, device, world)
+    if args.force_grad_sync and world == 1 and not dist.is_initialized() and "RANK" in os.environ:
+        dist.init_process_group("nccl")
+    module, trainer = build_trainer(args.expt, args.batch, device, world, args.force_grad_sync)
     batch = synthetic_batch(args.batch, device, rank)
     timer = F.KernelTimer()
     # warm-up happens inside timed_pairs; the per-launch HIP events are recorded during the timed region
@@ -228,7 +232,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.expt == "dc_gan":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -17,6 +17,8 @@ MI355X-first shape of the same exchange:
 
 Works on any torch.distributed backend ("nccl" = RCCL on ROCm; "gloo" in the CPU tests).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -53,6 +55,8 @@ class GradSync:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.overlap = overlap
+        # test hook: issue the collective even on a single rank (exercises the RCCL call path)
+        self.always_reduce = bool(os.environ.get("GZ_DDP_ALWAYS_REDUCE")) and dist.is_initialized()
         self.nets = [module.discriminator, module.generator]     # optimizer_idx order
         self.flats = [_FlatGrads(list(n.parameters())) for n in self.nets]
         self.pending = [None, None]   # (work, optimizer)
@@ -72,7 +76,7 @@ class GradSync:
         fg = self.flats[optimizer_idx]
         fg.rebind()
         work = None
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             work = dist.all_reduce(fg.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.pending[optimizer_idx] = (work, optimizer)
         if not self.overlap:
