@@ -31,8 +31,18 @@ static int forced_tile() {
     return g_force_tile;
 }
 
-// Tile choice: the chip has 256 CUs and a workgroup keeps one CU's matrix pipes busy, so prefer the
-// largest tile that still yields >= ~1 workgroup per CU; narrow N gets narrow tiles.
+static int min_wgs() {
+    static int t = -1;
+    if (t < 0) {
+        const char* e = getenv("GZ_MIN_WGS");
+        t = e ? atoi(e) : 1536;
+    }
+    return t;
+}
+
+// Tile choice: the chip has 256 CUs and the kernels only approach the MFMA rate with ~3+ workgroups
+// per CU in flight (their load and MFMA phases overlap across workgroups), so prefer the largest
+// tile that still yields >= min_wgs() workgroups; narrow N gets narrow tiles.
 static TileId pick_tile(long long M, long long N, int ny) {
     int f = forced_tile();
     if (f >= 0 && f <= 3) {
@@ -40,9 +50,10 @@ static TileId pick_tile(long long M, long long N, int ny) {
     }
     if (N <= 32) return T128x32;
     auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * ny; };
-    if (N <= 64) return tiles(128, 64) >= 256 ? T128x64 : T64x64;
-    if (tiles(128, 128) >= 256) return T128x128;
-    if (tiles(128, 64) >= 256) return T128x64;
+    const long long want = min_wgs();
+    if (N <= 64) return tiles(128, 64) >= want ? T128x64 : T64x64;
+    if (tiles(128, 128) >= want) return T128x128;
+    if (tiles(128, 64) >= want) return T128x64;
     return T64x64;
 }
 
@@ -360,16 +371,12 @@ static int run_wgrad(const float* x, const float* y, float* dw, float* ws, size_
     return launch_wgrad<G, Cfg, AL, BL>(pa, pb, dw, ws, ws_bytes, s, KTOT, NTOT, st);
 }
 
+extern "C" int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S);
+
 template <class G>
 static int dispatch_wgrad(const float* x, const float* y, float* dw, float* ws, size_t ws_bytes,
                           const ConvShape& s, hipStream_t st) {
-    long long NTOT = (long long)s.C * G::kh * G::kw;
-    TileId t;
-    if (NTOT <= 32) t = T128x32;
-    else if (NTOT <= 64 || s.K <= 64) t = (s.K <= 64 ? T64x64 : T128x64);
-    else t = T128x128;
-    int f = forced_tile();
-    if (f >= 0 && f <= 3 && !(f == T128x128 && NTOT <= 64)) t = (TileId)f;
+    TileId t = (TileId)gz_conv2d_tile(2, s.N, s.C, s.H, s.W, s.K, s.OH, s.OW, G::kh, G::kw, G::s);
     switch (t) {
         case T128x128: return run_wgrad<G, Cfg128x128>(x, y, dw, ws, ws_bytes, s, st);
         case T128x64: return run_wgrad<G, Cfg128x64>(x, y, dw, ws, ws_bytes, s, st);
@@ -505,7 +512,12 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
     int t;
     if (NTOT <= 32) t = T128x32;
     else if (NTOT <= 64 || K <= 64) t = (K <= 64 ? T64x64 : T128x64);
-    else t = T128x128;
+    else {
+        // split-K supplies the parallelism; with few pixels per split (small batches) the narrower
+        // tile keeps more workgroups busy per slab byte
+        long long pixels = (long long)N * OH * OW;
+        t = pixels >= 65536 ? T128x128 : T128x64;
+    }
     int f = forced_tile();
     if (f >= 0 && f <= 3 && !(f == T128x128 && NTOT <= 64)) t = f;
     return t;
