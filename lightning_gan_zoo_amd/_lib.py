@@ -9,7 +9,7 @@ import re
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libgz_hip.so")
+LIB_PATH = os.environ.get("GZ_LIB") or os.path.join(HERE, "csrc", "libgz_hip.so")   # GZ_LIB: experimental builds
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "gz_ops.h")
 
 ERRORS = {-1: "bad shape / alignment", -2: "unsupported configuration", -3: "workspace too small",

@@ -36,19 +36,23 @@ def _newest_header():
     return t
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, extra_flags=None, suffix=""):
+    """``extra_flags`` / ``suffix`` build an experimental variant (libgz_hip<suffix>.so, own objects);
+    select it at run time with GZ_LIB=<path>."""
     hipcc = _hipcc()
+    extra_flags = list(extra_flags or [])
+    lib_path = LIB_PATH.replace(".so", suffix + ".so")
     hdr_t = _newest_header()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     jobs = []
     objs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, s.replace(".hip", suffix + ".o"))
         objs.append(obj)
         stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t)
         if stale:
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + extra_flags + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -61,12 +65,14 @@ def build(force=False, verbose=True):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    need_link = bool(jobs) or not os.path.exists(LIB_PATH) or any(
-        os.path.getmtime(o) > os.path.getmtime(LIB_PATH) for o in objs)
+    need_link = bool(jobs) or not os.path.exists(lib_path) or any(
+        os.path.getmtime(o) > os.path.getmtime(lib_path) for o in objs)
     if need_link:
-        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs)
-    return LIB_PATH
+        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_path] + objs)
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    flags = [a for a in sys.argv[1:] if a.startswith("-D")]
+    sfx = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--suffix=")), "")
+    print(build(force="--force" in sys.argv, extra_flags=flags, suffix=sfx))

@@ -935,8 +935,12 @@ struct GridMap {
     int chunks_per_split;      // grid.z = ceil(chunks / chunks_per_split)
 };
 
+#ifndef GZ_IGEMM_WAVES_PER_SIMD
+#define GZ_IGEMM_WAVES_PER_SIMD 1
+#endif
+
 template <class Cfg, class AL, class BL, class Epi>
-__global__ __launch_bounds__(NT) void igemm_kernel(typename AL::Params pa, typename BL::Params pb,
+__global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(typename AL::Params pa, typename BL::Params pb,
                                                    typename Epi::Params pe, GridMap gm) {
     constexpr int LDA = AL::LD, LDB = BL::LD;
     constexpr int TM = Cfg::TM, TN = Cfg::TN;
@@ -999,18 +1003,34 @@ __global__ __launch_bounds__(NT) void igemm_kernel(typename AL::Params pa, typen
         }
         const float* Ar = As + cur * BK * LDA + a_rd;
         const float* Br = Bs + cur * BK * LDB + b_rd;
+        // fragment double buffering in registers: the ds_reads of k-step s+1 are in flight while the
+        // TM*TN MFMAs of k-step s issue, so a wave does not depend on its SIMD neighbours to cover
+        // the LDS latency
+        float af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = Ar[i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = Br[j * 32];
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
-            float af[TM], bf[TN];
+            const int c = s & 1, n = c ^ 1;
+            if (s + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = Ar[2 * s * LDA + i * 32];
+                for (int i = 0; i < TM; ++i) af[n][i] = Ar[2 * (s + 1) * LDA + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Br[2 * s * LDB + j * 32];
+                for (int j = 0; j < TN; ++j) bf[n][j] = Br[2 * (s + 1) * LDB + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i], bf[c][j], acc[i][j], 0, 0, 0);
+            // pin the order "next step's LDS reads, then this step's MFMAs" (hipcc otherwise sinks the
+            // reads behind the MFMAs to save two registers)
+#ifndef GZ_IGEMM_NO_FRAG_PREFETCH
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);   // MFMA
+#endif
         }
         if (more) {
             al.commit(As + (cur ^ 1) * BK * LDA);
