@@ -33,20 +33,20 @@ DEFAULT_BATCH = {"dc_gan": 512, "wgan": 512, "wgan_gp": 256, "hologan": 64}
 PEAK_FP32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
 
 
-def build_trainer(expt, batch, device, world, force_sync=False):
+def build_trainer(expt, batch, device, world, force_sync=False, img_size=64):
     from lightning_gan_zoo_amd.config import locate, make_cfg
     from lightning_gan_zoo_amd.ddp import GradSync
     from lightning_gan_zoo_amd.harness import Trainer
-    cfg = make_cfg(expt, batch_size=batch)
+    cfg = make_cfg(expt, batch_size=batch, img_size=img_size)
     torch.manual_seed(42)                 # run_network.py:27, same seed on every rank
     module = locate(cfg.model.lm["_target_"])(cfg, None).to(device)
     sync = GradSync(module) if (world > 1 or force_sync) else None
     return module, Trainer(module, grad_sync=sync)
 
 
-def synthetic_batch(batch, device, rank):
+def synthetic_batch(batch, device, rank, img_size=64):
     g = torch.Generator().manual_seed(1234 + rank)
-    real = (torch.rand(batch, 3, 64, 64, generator=g) * 2 - 1).to(device)
+    real = (torch.rand(batch, 3, img_size, img_size, generator=g) * 2 - 1).to(device)
     return real, torch.zeros(batch, dtype=torch.int64, device=device)
 
 
@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None,
                     help="per-GPU batch (default: BASELINE configs: dc_gan 512, wgan_gp 256, hologan 64)")
     ap.add_argument("--expt", default="dc_gan")
+    ap.add_argument("--img-size", type=int, default=64, help="128 only with --expt hologan (EXT-128, not parity-pinned)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bs128", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -162,8 +163,8 @@ def main():
     torch.set_num_threads(min(8, torch.get_num_threads()))
     if args.force_grad_sync and world == 1 and not dist.is_initialized() and "RANK" in os.environ:
         dist.init_process_group("nccl")
-    module, trainer = build_trainer(args.expt, args.batch, device, world, args.force_grad_sync)
-    batch = synthetic_batch(args.batch, device, rank)
+    module, trainer = build_trainer(args.expt, args.batch, device, world, args.force_grad_sync, args.img_size)
+    batch = synthetic_batch(args.batch, device, rank, args.img_size)
     timer = F.KernelTimer()
     # warm-up happens inside timed_pairs; the per-launch HIP events are recorded during the timed region
     for _ in range(2):
@@ -181,6 +182,8 @@ def main():
     per_cycle = len(trainer.order)            # batches per optimizer cycle: 2 (dc_gan, wgan_gp), 6 (wgan), 3 (hologan)
     value = per_cycle * args.batch * world * args.steps / dt
     flop_cycle = FLOP_PER_SAMPLE_CYCLE[args.expt] * args.batch
+    if args.img_size != 64:
+        flop_cycle = float("nan")      # the reference cannot run this size; no traced FLOP count exists
 
     out = {
         "metric": "images/sec (G+D step) at 64x64",
@@ -195,8 +198,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "%s synthetic 64x64 bs=%d/GPU, one optimizer cycle of %d batches (Lightning alternation "
-                               "+ toggle), reference optimizer, fp32" % (args.expt, args.batch, per_cycle),
+        "config": {"workload": "%s synthetic %dx%d bs=%d/GPU, one optimizer cycle of %d batches (Lightning "
+                               "alternation + toggle), reference optimizer, fp32"
+                               % (args.expt, args.img_size, args.img_size, args.batch, per_cycle),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                    "images_counted": "%d*bs*n_gpus per step (every batch of the cycle)" % per_cycle},
     }

@@ -149,6 +149,9 @@ def make_cfg(expt, module_root=PRODUCT_ROOT, batch_size=None, features=None, img
                                           "transY_low": 0, "transY_high": 0,
                                           "transZ_low": 0, "transZ_high": 0,
                                           "batch_size": t["batch_size"]}}
+        if t["img_size"] == 128:     # EXT-128: the reference itself cannot run at 128
+            cfg["generator"]["ext128"] = True
+            cfg["discriminator"]["img_size"] = 128
     else:
         raise ValueError("unknown expt %r (hot path covers dc_gan, wgan, wgan_gp, hologan)" % expt)
     if batch_size is not None:

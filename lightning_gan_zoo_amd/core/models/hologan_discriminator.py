@@ -41,8 +41,11 @@ class BasicBlock(nn.Module):
 
 
 class Discriminator(nn.Module):
-    def __init__(self, in_planes, out_planes, z_planes):
+    def __init__(self, in_planes, out_planes, z_planes, img_size=64):
+        """``img_size`` other than 64 is the EXT-128 extension (heads sized for the 8x8 final map); the
+        reference hard-wires 4x4 (hologan_discriminator.py:41,45)."""
         super().__init__()
+        fmap = (img_size // 16) ** 2
         self.conv2d = nn.Conv2d(in_planes, out_planes, kernel_size=5, stride=2, padding=2)
         truncated_normal_initializer(self.conv2d.weight)
         nn.init.constant_(self.conv2d.bias, val=0.0)
@@ -51,10 +54,10 @@ class Discriminator(nn.Module):
             BasicBlock(out_planes * 1, out_planes * 2),
             BasicBlock(out_planes * 2, out_planes * 4),
             BasicBlock(out_planes * 4, out_planes * 8))
-        self.linear1 = nn.Linear(out_planes * 8 * 4 * 4, 1)
+        self.linear1 = nn.Linear(out_planes * 8 * fmap, 1)
         truncated_normal_initializer(self.linear1.weight)
         nn.init.constant_(self.linear1.bias, val=0.0)
-        self.linear2 = nn.Linear(out_planes * 8 * 4 * 4, 128)
+        self.linear2 = nn.Linear(out_planes * 8 * fmap, 128)
         truncated_normal_initializer(self.linear1.weight)     # sic (reference :46)
         nn.init.constant_(self.linear2.bias, val=0.0)
         self.linear3 = nn.Linear(128, z_planes)

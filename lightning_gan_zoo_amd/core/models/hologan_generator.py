@@ -90,7 +90,8 @@ def view_inverse_matrices(view, size=16, new_size=16):
 
 
 class Generator(nn.Module):
-    def __init__(self, in_planes, out_planes, z_planes, view_args, img_size, view_planes=6, gpu=True):
+    def __init__(self, in_planes, out_planes, z_planes, view_args, img_size, view_planes=6, gpu=True,
+                 ext128=False):
         super().__init__()
         # `gpu` is accepted for signature parity; the module follows its parameters' device (.to(device))
         tensor = (torch.randn(1, in_planes * 8, 4, 4, 4) - 0.5) / 0.5
@@ -107,9 +108,13 @@ class Generator(nn.Module):
         if img_size == 64:
             self.final_layer = nn.Conv2d(in_planes, out_planes, kernel_size=3, padding=1)
         elif img_size == 128:
-            # the reference's 128 branch (ConvTranspose2d k4 p1, stride 1) yields 65x65 and cannot feed its
-            # own discriminator; not supported on the HIP path
-            raise NotImplementedError("HoloGAN img_size=128 is broken in the reference; only 64 is supported")
+            # The reference's 128 branch (ConvTranspose2d k4 p1 with the default stride 1) yields 65x65 and
+            # cannot feed its own discriminator.  EXT-128 (opt-in, throughput-only,
+            # NOT parity-pinned) adopts the evident intent: stride 2, i.e. 64 -> 128.
+            if not ext128:
+                raise NotImplementedError("HoloGAN img_size=128 is broken in the reference (65x65 output); pass "
+                                          "ext128=True for the stride-2 extension (not parity-pinned)")
+            self.final_layer = nn.ConvTranspose2d(in_planes, out_planes, kernel_size=4, stride=2, padding=1)
         else:
             raise ValueError("img_size must be 64")
         nn.init.normal_(self.final_layer.weight, std=0.02)
@@ -151,4 +156,6 @@ class Generator(nn.Module):
         h = self.block3(h, z)
         h = self.block4(h, z)
         f = self.final_layer
+        if isinstance(f, nn.ConvTranspose2d):                          # EXT-128
+            return F.conv_transpose2d(h, f.weight, f.bias, F.K4S2P1, F.ACT_TANH)
         return F.conv2d(h, f.weight, f.bias, K3S1P1, F.ACT_TANH)

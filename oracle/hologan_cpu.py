@@ -161,7 +161,8 @@ def rigid_resample(vox, view, size=16, new_size=16):
 
 
 class Generator(nn.Module):
-    def __init__(self, in_planes, out_planes, z_planes, view_args, img_size, view_planes=6, gpu=True):
+    def __init__(self, in_planes, out_planes, z_planes, view_args, img_size, view_planes=6, gpu=True,
+                 ext128=False):
         super().__init__()
         self.x = nn.Parameter((torch.randn(1, in_planes * 8, 4, 4, 4) - 0.5) / 0.5)
         self.view_args = view_args
@@ -176,7 +177,9 @@ class Generator(nn.Module):
         if img_size == 64:
             self.final_layer = nn.Conv2d(in_planes, out_planes, kernel_size=3, padding=1)
         elif img_size == 128:
-            self.final_layer = nn.ConvTranspose2d(in_planes, out_planes, kernel_size=4, padding=1)
+            # reference: stride 1 (65x65, unusable); ext128: the stride-2 extension the product offers
+            self.final_layer = nn.ConvTranspose2d(in_planes, out_planes, kernel_size=4, padding=1,
+                                                  stride=2 if ext128 else 1)
         nn.init.normal_(self.final_layer.weight, std=0.02)
         nn.init.constant_(self.final_layer.bias, val=0.0)
 
@@ -227,7 +230,7 @@ class SNBlock(nn.Module):
 
 
 class Discriminator(nn.Module):
-    def __init__(self, in_planes, out_planes, z_planes):
+    def __init__(self, in_planes, out_planes, z_planes, img_size=64):
         super().__init__()
         self.conv2d = nn.Conv2d(in_planes, out_planes, kernel_size=5, stride=2, padding=2)
         truncated_normal_(self.conv2d.weight)
@@ -235,7 +238,7 @@ class Discriminator(nn.Module):
         self.lrelu = nn.LeakyReLU(0.2)
         self.blocks = nn.Sequential(SNBlock(out_planes, out_planes * 2), SNBlock(out_planes * 2, out_planes * 4),
                                     SNBlock(out_planes * 4, out_planes * 8))
-        feat = out_planes * 8 * 4 * 4
+        feat = out_planes * 8 * (img_size // 16) ** 2
         self.linear1 = nn.Linear(feat, 1)
         truncated_normal_(self.linear1.weight)
         nn.init.constant_(self.linear1.bias, val=0.0)

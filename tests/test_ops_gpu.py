@@ -322,3 +322,31 @@ def test_linear_act_fwd_bwd():
         out.pow(2).sum().backward()
         for got, want in ((out, ref), (xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
             assert rel(got, want) < TOL
+
+
+def test_hologan_ext128_matches_oracle_extension():
+    """EXT-128: the reference cannot run at 128x128; product and oracle implement the
+    same stride-2 extension, so this checks HIP-vs-CPU consistency only (no reference parity)."""
+    import numpy as np
+    from helpers import fill_closed_form
+    from lightning_gan_zoo_amd.config import make_cfg
+    from lightning_gan_zoo_amd.core.models import hologan_discriminator as PD, hologan_generator as PG
+    from oracle import hologan_cpu as H
+    va = make_cfg("hologan", features=8, batch_size=2, noise_dim=16).generator.view_args
+    torch.manual_seed(0)
+    gp, go = PG.Generator(8, 3, 16, va, 128, ext128=True), H.Generator(8, 3, 16, va, 128, ext128=True)
+    torch.manual_seed(0)
+    dp, do = PD.Discriminator(3, 8, 16, img_size=128), H.Discriminator(3, 8, 16, img_size=128)
+    for a, b in ((gp, go), (dp, do)):
+        fill_closed_form(a, 3)
+        fill_closed_form(b, 3)
+        b.load_state_dict(a.state_dict())
+    gp.cuda(), dp.cuda()
+    z = rnd(2, 16, seed=99)
+    np.random.seed(1)
+    view = go.sample_view(2)
+    img_p, img_o = gp(z.cuda(), view), go(z, view)
+    assert img_p.shape == (2, 3, 128, 128) and rel(img_p, img_o) < TOL
+    lp, zp = dp(img_p)
+    lo, zo = do(img_o)
+    assert rel(lp, lo) < TOL and rel(zp, zo) < TOL
