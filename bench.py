@@ -220,9 +220,10 @@ def main():
                 "all_igemm": {k: {"launches": v[0], "ms": round(v[1], 2),
                                   "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in sorted(agg.items())},
                 "igemm_share_of_step": round(total_ms / (ms_per_step * args.steps), 3),
-                "whole_step": {"flop_per_step": flop_cycle,
-                               "achieved": round(flop_cycle / (ms_per_step * 1e-3) / 1e12, 2),
-                               "frac": round(flop_cycle / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
+                "whole_step": None if flop_cycle != flop_cycle else {
+                    "flop_per_step": flop_cycle,
+                    "achieved": round(flop_cycle / (ms_per_step * 1e-3) / 1e12, 2),
+                    "frac": round(flop_cycle / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
             }
         if world == 1 and not args.no_bs128 and args.batch != 128 and args.expt == "dc_gan":
             # BASELINE.json's metric string quotes bs=128/GPU: report it beside the bs=512 headline

@@ -45,6 +45,24 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, uint32_t voff,
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+// LDS-DMA (buffer_load ... lds): the wave's 64 lanes land at lds_base + lane*size, no VGPR staging and no
+// ds_write; lds_base must be wave-uniform.  Out-of-range lanes write 0.
+#ifndef GZ_IGEMM_NO_DMA
+#define GZ_IGEMM_DMA 1
+#else
+#define GZ_IGEMM_DMA 0
+#endif
+__device__ __forceinline__ void bload_lds4(__amdgpu_buffer_rsrc_t r, float* lds_wave_base, uint32_t voff,
+                                           uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 4, voff, soff, 0,
+                                             0);
+}
+__device__ __forceinline__ void bload_lds16(__amdgpu_buffer_rsrc_t r, float* lds_wave_base, uint32_t voff,
+                                            uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff,
+                                             0, 0);
+}
+
 template <int WM_, int WN_, int TM_, int TN_>
 struct TileCfg {
     static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
@@ -67,11 +85,22 @@ struct MContigLoader {
     static constexpr int LD = BMN;
     static constexpr int EPT = BMN * BK / NT;
     static constexpr int STEP = NT / BMN;
+    static constexpr bool DMA = GZ_IGEMM_DMA;
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t col_off;
     int kb, mn_l, K, ld;
     bool col_ok;
-    float r[EPT];
+    float r[DMA ? 1 : EPT];
+    __device__ __forceinline__ void issue_lds(int kc, float* dst) {
+        float* wbase = dst + (mn_l - (int)(threadIdx.x & 63));
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            int kl = kb + STEP * j;
+            int k = kc * BK + kl;
+            uint32_t v = (col_ok && k < K) ? (uint32_t)k * (uint32_t)ld * 4u + col_off : OOB;
+            bload_lds4(rsrc, wbase + kl * LD, v, 0);
+        }
+    }
     __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
         rsrc = make_rsrc(p.base + (long long)y * p.batch_stride, (uint32_t)p.K * p.ld * 4u);
         mn_l = tid % BMN;
@@ -83,16 +112,20 @@ struct MContigLoader {
         ld = p.ld;
     }
     __device__ __forceinline__ void issue(int kc) {
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-            int k = kc * BK + kb + STEP * j;
-            uint32_t v = (col_ok && k < K) ? (uint32_t)k * (uint32_t)ld * 4u + col_off : OOB;
-            r[j] = bload(rsrc, v, 0);
+            for (int j = 0; j < EPT; ++j) {
+                int k = kc * BK + kb + STEP * j;
+                uint32_t v = (col_ok && k < K) ? (uint32_t)k * (uint32_t)ld * 4u + col_off : OOB;
+                r[j] = bload(rsrc, v, 0);
+            }
         }
     }
     __device__ __forceinline__ void commit(float* dst) const {
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int j = 0; j < EPT; ++j) dst[(kb + STEP * j) * LD + mn_l] = r[j];
+            for (int j = 0; j < EPT; ++j) dst[(kb + STEP * j) * LD + mn_l] = r[j];
+        }
     }
 };
 
@@ -104,11 +137,26 @@ struct MContigLoader4 {
     static constexpr int C4 = BMN / 4;                 // float4 columns
     static constexpr int ROWS = NT / C4;               // rows covered per pass
     static constexpr int PASSES = (BK + ROWS - 1) / ROWS;
+    static constexpr bool DMA = GZ_IGEMM_DMA;
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t col_off;
     int kb, c4, K, ld;
     bool col_ok;
-    f32x4 r[PASSES];
+    f32x4 r[DMA ? 1 : PASSES];
+    // a wave covers 64/C4 whole rows of the [k][BMN] image = one contiguous 1 KiB piece (LD == BMN)
+    __device__ __forceinline__ void issue_lds(int kc, float* dst) {
+        const int lane = threadIdx.x & 63;
+        const int kb0 = kb - lane / C4;           // first row of this wave (wave-uniform)
+#pragma unroll
+        for (int j = 0; j < PASSES; ++j) {
+            int kl = kb + ROWS * j;
+            if (kb0 + ROWS * j < BK) {            // wave-uniform: 64/C4 divides BK
+                int k = kc * BK + kl;
+                uint32_t v = (col_ok && k < K) ? (uint32_t)k * (uint32_t)ld * 4u + col_off : OOB;
+                bload_lds16(rsrc, dst + (kb0 + ROWS * j) * LD, v, 0);
+            }
+        }
+    }
     __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
         rsrc = make_rsrc(p.base + (long long)y * p.batch_stride, (uint32_t)p.K * p.ld * 4u);
         c4 = tid % C4;
@@ -120,20 +168,24 @@ struct MContigLoader4 {
         ld = p.ld;
     }
     __device__ __forceinline__ void issue(int kc) {
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int j = 0; j < PASSES; ++j) {
-            int kl = kb + ROWS * j;
-            int k = kc * BK + kl;
-            bool ok = col_ok && k < K && kl < BK;
-            uint32_t v = ok ? (uint32_t)k * (uint32_t)ld * 4u + col_off : OOB;
-            r[j] = bload4(rsrc, v, 0);
+            for (int j = 0; j < PASSES; ++j) {
+                int kl = kb + ROWS * j;
+                int k = kc * BK + kl;
+                bool ok = col_ok && k < K && kl < BK;
+                uint32_t v = ok ? (uint32_t)k * (uint32_t)ld * 4u + col_off : OOB;
+                r[j] = bload4(rsrc, v, 0);
+            }
         }
     }
     __device__ __forceinline__ void commit(float* dst) const {
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int j = 0; j < PASSES; ++j) {
-            int kl = kb + ROWS * j;
-            if (kl < BK) *reinterpret_cast<f32x4*>(dst + kl * LD + c4 * 4) = r[j];
+            for (int j = 0; j < PASSES; ++j) {
+                int kl = kb + ROWS * j;
+                if (kl < BK) *reinterpret_cast<f32x4*>(dst + kl * LD + c4 * 4) = r[j];
+            }
         }
     }
 };
@@ -149,6 +201,8 @@ struct KContigLoader {
         long long batch_stride;
     };
     static constexpr int LD = BMN + 2;
+    static constexpr bool DMA = false;
+    __device__ __forceinline__ void issue_lds(int, float*) {}
     static constexpr int EPT = BMN / 16;
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff[EPT];
@@ -199,12 +253,32 @@ struct ConvFwdALoader {
     static constexpr int EPT = BM * BK / NT;
     static constexpr int STEP = NT / BM;
     static constexpr bool FIXED = (KH * KW == BK);  // a chunk is exactly one input channel
+    static constexpr bool DMA = GZ_IGEMM_DMA;
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff[FIXED ? EPT : 1];
     uint32_t nbase;
     int kb, m_l, iy0, ix0, C, H, W;
     bool m_ok;
-    float r[EPT];
+    float r[DMA ? 1 : EPT];
+    __device__ __forceinline__ uint32_t tap_voff(int kc, int j) const {
+        if constexpr (FIXED) {
+            return voff[j];
+        } else {
+            int k = kc * BK + kb + STEP * j;
+            int c = k / (KH * KW);
+            int tap = k - c * (KH * KW);
+            int iy = iy0 + tap / KW, ix = ix0 + tap % KW;
+            bool ok = m_ok && c < C && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            return ok ? (nbase + (uint32_t)((c * H + iy) * W + ix)) * 4u : OOB;
+        }
+    }
+    // a wave's 64 lanes are 64 consecutive m of one k row: one contiguous 256-byte LDS piece
+    __device__ __forceinline__ void issue_lds(int kc, float* dst) {
+        float* wbase = dst + (m_l - (int)(threadIdx.x & 63));
+        const uint32_t soff = FIXED ? (uint32_t)kc * (uint32_t)(H * W) * 4u : 0u;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) bload_lds4(rsrc, wbase + (kb + STEP * j) * LD, tap_voff(kc, j), soff);
+    }
     __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
         const ConvShape& s = p.s;
         rsrc = make_rsrc(p.x, (uint32_t)s.N * s.C * s.H * s.W * 4u);
@@ -231,26 +305,17 @@ struct ConvFwdALoader {
         }
     }
     __device__ __forceinline__ void issue(int kc) {
-        if constexpr (FIXED) {
-            uint32_t soff = (uint32_t)kc * (uint32_t)(H * W) * 4u;
+        if constexpr (!DMA) {
+            const uint32_t soff = FIXED ? (uint32_t)kc * (uint32_t)(H * W) * 4u : 0u;
 #pragma unroll
-            for (int j = 0; j < EPT; ++j) r[j] = bload(rsrc, voff[j], soff);
-        } else {
-#pragma unroll
-            for (int j = 0; j < EPT; ++j) {
-                int k = kc * BK + kb + STEP * j;
-                int c = k / (KH * KW);
-                int tap = k - c * (KH * KW);
-                int iy = iy0 + tap / KW, ix = ix0 + tap % KW;
-                bool ok = m_ok && c < C && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                uint32_t v = ok ? (nbase + (uint32_t)((c * H + iy) * W + ix)) * 4u : OOB;
-                r[j] = bload(rsrc, v, 0);
-            }
+            for (int j = 0; j < EPT; ++j) r[j] = bload(rsrc, tap_voff(kc, j), soff);
         }
     }
     __device__ __forceinline__ void commit(float* dst) const {
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int j = 0; j < EPT; ++j) dst[(kb + STEP * j) * LD + m_l] = r[j];
+            for (int j = 0; j < EPT; ++j) dst[(kb + STEP * j) * LD + m_l] = r[j];
+        }
     }
 };
 
@@ -273,12 +338,34 @@ struct ConvDgALoader {
     static constexpr int EPT = BM * BK / NT;
     static constexpr int STEP = NT / BM;
     static constexpr bool FIXED = (BK % TAPS == 0);  // a chunk is BK/TAPS whole feature channels
+    static constexpr bool DMA = GZ_IGEMM_DMA;
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff[FIXED ? EPT : 1];
     uint32_t nbase;
     int kb, m_l, oy0, ox0, K, OH, OW;
     bool m_ok;
-    float r[EPT];
+    float r[DMA ? 1 : EPT];
+    __device__ __forceinline__ uint32_t tap_voff(int kc, int j) const {
+        if constexpr (FIXED) {
+            // feature channels past K only occur in a partial last chunk; their weights are zero-padded
+            // but the reads must stay inside the tensor: the soffset is not range checked.
+            int kol = (kb + STEP * j) / TAPS;
+            return kc * (BK / TAPS) + kol < K ? voff[j] : OOB;
+        } else {
+            int k = kc * BK + kb + STEP * j;
+            int ko = k / TAPS;
+            int tap = k - ko * TAPS;
+            int oy = oy0 - tap / TX, ox = ox0 - tap % TX;
+            bool ok = m_ok && ko < K && (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
+            return ok ? (nbase + (uint32_t)((ko * OH + oy) * OW + ox)) * 4u : OOB;
+        }
+    }
+    __device__ __forceinline__ void issue_lds(int kc, float* dst) {
+        float* wbase = dst + (m_l - (int)(threadIdx.x & 63));
+        const uint32_t soff = FIXED ? (uint32_t)kc * (uint32_t)((BK / TAPS) * OH * OW) * 4u : 0u;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) bload_lds4(rsrc, wbase + (kb + STEP * j) * LD, tap_voff(kc, j), soff);
+    }
     __device__ __forceinline__ void init(const Params& p, int tile, int phase, int tid) {
         const ConvShape& s = p.s;
         rsrc = make_rsrc(p.y, (uint32_t)s.N * s.K * s.OH * s.OW * 4u);
@@ -307,32 +394,17 @@ struct ConvDgALoader {
         }
     }
     __device__ __forceinline__ void issue(int kc) {
-        if constexpr (FIXED) {
-            uint32_t soff = (uint32_t)kc * (uint32_t)((BK / TAPS) * OH * OW) * 4u;
-            // feature channels past K only occur in a partial last chunk; their weights are zero-padded
-            // but the reads must stay inside the tensor: the soffset is not range checked.
-            int ko_base = kc * (BK / TAPS);
+        if constexpr (!DMA) {
+            const uint32_t soff = FIXED ? (uint32_t)kc * (uint32_t)((BK / TAPS) * OH * OW) * 4u : 0u;
 #pragma unroll
-            for (int j = 0; j < EPT; ++j) {
-                int kol = (kb + STEP * j) / TAPS;
-                r[j] = bload(rsrc, ko_base + kol < K ? voff[j] : OOB, soff);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < EPT; ++j) {
-                int k = kc * BK + kb + STEP * j;
-                int ko = k / TAPS;
-                int tap = k - ko * TAPS;
-                int oy = oy0 - tap / TX, ox = ox0 - tap % TX;
-                bool ok = m_ok && ko < K && (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
-                uint32_t v = ok ? (nbase + (uint32_t)((ko * OH + oy) * OW + ox)) * 4u : OOB;
-                r[j] = bload(rsrc, v, 0);
-            }
+            for (int j = 0; j < EPT; ++j) r[j] = bload(rsrc, tap_voff(kc, j), soff);
         }
     }
     __device__ __forceinline__ void commit(float* dst) const {
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int j = 0; j < EPT; ++j) dst[(kb + STEP * j) * LD + m_l] = r[j];
+            for (int j = 0; j < EPT; ++j) dst[(kb + STEP * j) * LD + m_l] = r[j];
+        }
     }
 };
 
@@ -347,6 +419,8 @@ struct WgALoader {
         int KTOT;  // N*OH*OW
     };
     static constexpr int LD = BM + 2;
+    static constexpr bool DMA = false;
+    __device__ __forceinline__ void issue_lds(int, float*) {}
     static constexpr int EPT = BM / 16;
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t koff[EPT];
@@ -396,6 +470,8 @@ struct WgBLoader {
         int KTOT, NTOT;  // N*OH*OW, C*KH*KW
     };
     static constexpr int LD = BN + 2;
+    static constexpr bool DMA = false;
+    __device__ __forceinline__ void issue_lds(int, float*) {}
     static constexpr int EPT = BN / 16;
     __amdgpu_buffer_rsrc_t rsrc;
     int toff[EPT];   // (c*H + ky - P)*W + kx - P, or INT_MIN when the column is out of range
@@ -466,6 +542,8 @@ struct WgALoaderRow {
         int KTOT;
     };
     static constexpr int LD = BM + 2;
+    static constexpr bool DMA = false;
+    __device__ __forceinline__ void issue_lds(int, float*) {}
     static constexpr int EPT = BM / 16;
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff[EPT];
@@ -510,6 +588,8 @@ struct WgBLoaderRow {
         int KTOT, NTOT;
     };
     static constexpr int LD = BN + 2;
+    static constexpr bool DMA = false;
+    __device__ __forceinline__ void issue_lds(int, float*) {}
     static constexpr int EPT = BN / 16;
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff[EPT];      // loop-invariant byte offset (may wrap for padded taps: those are masked)
@@ -583,6 +663,8 @@ struct Conv3DFwdALoader {
         FastDiv div_odhw, div_ohw, div_ow;
     };
     static constexpr int LD = BM;
+    static constexpr bool DMA = false;
+    __device__ __forceinline__ void issue_lds(int, float*) {}
     static constexpr int EPT = BM * BK / NT;
     static constexpr int STEP = NT / BM;
     static constexpr int T3 = KS * KS * KS;
@@ -640,6 +722,8 @@ struct Conv3DDgALoader {
         FastDiv div_adhw, div_ahw, div_aw;
     };
     static constexpr int LD = BM;
+    static constexpr bool DMA = false;
+    __device__ __forceinline__ void issue_lds(int, float*) {}
     static constexpr int EPT = BM * BK / NT;
     static constexpr int STEP = NT / BM;
     static_assert(BK % TAPS == 0, "a chunk must hold whole feature channels");
@@ -700,6 +784,8 @@ struct Wg3DBLoader {
         int KTOT, NTOT;
     };
     static constexpr int LD = BN + 2;
+    static constexpr bool DMA = false;
+    __device__ __forceinline__ void issue_lds(int, float*) {}
     static constexpr int EPT = BN / 16;
     static constexpr int T3 = KS * KS * KS;
     __amdgpu_buffer_rsrc_t rsrc;
@@ -857,23 +943,43 @@ struct EpiPhase {
                                                  int n_base, int lane, int y, int z) {
         const int col_l = lane & 31, half = lane >> 5;
         const int py = y / S, px = y % S;
+        const bool quad = (p.AW & 3) == 0;      // 4 consecutive rows = 4 consecutive b of one (n, a)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m >= p.M) continue;
-                uint32_t n = fdiv((uint32_t)m, p.div_ahw);
-                uint32_t pix = (uint32_t)m - n * (uint32_t)(p.AH * p.AW);
-                uint32_t a = fdiv(pix, p.div_aw);
-                uint32_t b = pix - a * (uint32_t)p.AW;
-                long long o = ((long long)n * p.C * p.H + (S * a + py)) * p.W + (S * b + px);
+            for (int g = 0; g < 4; ++g) {
+                const int m0 = m_base + i * 32 + 8 * g + 4 * half;
+                long long o0 = 0;
+                if (quad) {
+                    if (m0 >= p.M) continue;
+                    uint32_t n = fdiv((uint32_t)m0, p.div_ahw);
+                    uint32_t pix = (uint32_t)m0 - n * (uint32_t)(p.AH * p.AW);
+                    uint32_t a = fdiv(pix, p.div_aw);
+                    uint32_t b = pix - a * (uint32_t)p.AW;
+                    o0 = ((long long)n * p.C * p.H + (S * a + py)) * p.W + (S * b + px);
+                }
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    int c = n_base + j * 32 + col_l;
-                    if (c < p.C) {
-                        float bv = p.bias ? p.bias[c] : 0.f;
-                        p.out[o + (long long)c * p.H * p.W] = act_fwd(acc[i][j][r] + bv, p.act, p.slope);
+                for (int q = 0; q < 4; ++q) {
+                    long long o;
+                    if (quad) {
+                        o = o0 + S * q;
+                    } else {
+                        int m = m0 + q;
+                        if (m >= p.M) continue;
+                        uint32_t n = fdiv((uint32_t)m, p.div_ahw);
+                        uint32_t pix = (uint32_t)m - n * (uint32_t)(p.AH * p.AW);
+                        uint32_t a = fdiv(pix, p.div_aw);
+                        uint32_t b = pix - a * (uint32_t)p.AW;
+                        o = ((long long)n * p.C * p.H + (S * a + py)) * p.W + (S * b + px);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        int c = n_base + j * 32 + col_l;
+                        if (c < p.C) {
+                            float bv = p.bias ? p.bias[c] : 0.f;
+                            p.out[o + (long long)c * p.H * p.W] =
+                                act_fwd(acc[i][j][4 * g + q] + bv, p.act, p.slope);
+                        }
                     }
                 }
             }
@@ -987,20 +1093,28 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
     const int b_rd = half * LDB + wn * TN * 32 + l32;
 
     if (kc0 < kc1) {
-        al.issue(kc0);
-        bl.issue(kc0);
+        if constexpr (AL::DMA) al.issue_lds(kc0, As); else al.issue(kc0);
+        if constexpr (BL::DMA) bl.issue_lds(kc0, Bs); else bl.issue(kc0);
         al.commit(As);
         bl.commit(Bs);
     }
-    __syncthreads();
+    __syncthreads();     // (waits for outstanding LDS-DMA too: hipcc emits vmcnt(0) in front of the barrier)
 
     for (int kc = kc0; kc < kc1; ++kc) {
         const int cur = (kc - kc0) & 1;
         const bool more = kc + 1 < kc1;
+#if !defined(GZ_EXP_NOLOAD) && !defined(GZ_EXP_NOISSUE)   // timing experiments only (wrong results)
         if (more) {
-            al.issue(kc + 1);
-            bl.issue(kc + 1);
+            // the other LDS buffer was last read in the previous iteration, behind its closing barrier
+#ifdef GZ_EXP_SAMECHUNK      // timing experiment: always re-load chunk kc0 (cache-resident)
+            if constexpr (AL::DMA) al.issue_lds(kc0, As + (cur ^ 1) * BK * LDA); else al.issue(kc0);
+            if constexpr (BL::DMA) bl.issue_lds(kc0, Bs + (cur ^ 1) * BK * LDB); else bl.issue(kc0);
+#else
+            if constexpr (AL::DMA) al.issue_lds(kc + 1, As + (cur ^ 1) * BK * LDA); else al.issue(kc + 1);
+            if constexpr (BL::DMA) bl.issue_lds(kc + 1, Bs + (cur ^ 1) * BK * LDB); else bl.issue(kc + 1);
+#endif
         }
+#endif
         const float* Ar = As + cur * BK * LDA + a_rd;
         const float* Br = Bs + cur * BK * LDB + b_rd;
         // fragment double buffering in registers: the ds_reads of k-step s+1 are in flight while the
@@ -1032,11 +1146,15 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);   // MFMA
 #endif
         }
+#if !defined(GZ_EXP_NOLOAD) && !defined(GZ_EXP_NOCOMMIT)
         if (more) {
             al.commit(As + (cur ^ 1) * BK * LDA);
             bl.commit(Bs + (cur ^ 1) * BK * LDB);
         }
+#endif
+#ifndef GZ_EXP_NOBARRIER
         __syncthreads();
+#endif
     }
 
     Epi::template store<TM, TN>(pe, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32,
