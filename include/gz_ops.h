@@ -98,7 +98,7 @@ int gz_conv3d_wgrad(const float* x, const float* y, float* dw, float* workspace,
  * int64 [8][N*S^3], the clamped corner indices in the reference's idx_a..idx_h order. */
 int gz_rigid_resample_fwd(const float* vox, const float* minv, float* out2d, long long* idx_out, int N, int C, int S,
                           hipStream_t stream);
-/* gvox [N,C,S,S,S] = scatter-add adjoint of the above (zeroed inside) */
+/* gvox [N,C,S,S,S] = adjoint of the above (accumulated in LDS per (sample, channel pair); every element written) */
 int gz_rigid_resample_bwd(const float* gout2d, const float* minv, float* gvox, int N, int C, int S,
                           hipStream_t stream);
 
