@@ -9,6 +9,8 @@
 // (SURVEY.md appendix C), so these three close the gradient-penalty double backward.
 // Replaces, for the hot path, the aten ops behind torch.nn.Conv2d / ConvTranspose2d at
 // reference core/models/standard_networks.py:20-24,36-43,60-73,80-87.
+#include <type_traits>
+
 #include "gz_igemm.h"
 #include "../../include/gz_ops.h"
 
@@ -129,7 +131,12 @@ static bool too_large(long long elems) { return elems * 4 >= (1ll << 31); }
 template <class G, class Cfg>
 static int run_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvShape& s, int act,
                    float slope, hipStream_t st) {
+#ifndef GZ_NO_K4V
+    using AL = std::conditional_t<G::kh == 4 && G::kw == 4, ConvFwdALoaderK4V<Cfg::BM, G::s, G::p>,
+                                  ConvFwdALoader<Cfg::BM, G::kh, G::kw, G::s, G::p>>;
+#else
     using AL = ConvFwdALoader<Cfg::BM, G::kh, G::kw, G::s, G::p>;
+#endif
     using BL = MContigLoader4<Cfg::BN>;
     typename AL::Params pa{x, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW)};
     int Kg = s.C * G::kh * G::kw;

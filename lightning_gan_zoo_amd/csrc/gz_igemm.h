@@ -319,6 +319,72 @@ struct ConvFwdALoader {
     }
 };
 
+// Forward loader for KW == 4, KH*KW == 16 (the k4 s2 p1 layers): the four kx taps of one (c, ky) are four
+// consecutive floats of an input row, so each lane gathers them with ONE 16-byte load (dword aligned)
+// instead of four 4-byte loads -- a chunk (one input channel) needs 2 vector loads per lane instead of 8.
+// Columns that fall into the horizontal padding are zeroed in registers (per-lane 4-bit mask); rows in
+// the vertical padding are dropped by the descriptor's range check (which is per dword, so a vector that
+// straddles the end of the tensor is safe).  Lanes whose first tap lies left of the image (ox = 0, P = 1)
+// load from column 0 and rotate the vector by one in registers: nothing is ever read in front of the
+// tensor (an address before a page-aligned allocation faults even if the value is discarded).
+template <int BM, int S, int P>
+struct ConvFwdALoaderK4V {
+    using Params = typename ConvFwdALoader<BM, 4, 4, S, P>::Params;
+    static constexpr int LD = BM;
+    static constexpr bool DMA = false;
+    static constexpr int VPT = BM * 4 / NT;        // vector loads per lane per chunk (2 for BM=128, 1 for 64)
+    static constexpr int KYSTEP = NT / BM;         // 2 or 4
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[VPT];
+    static_assert(P <= 1, "left padding wider than one column is not handled");
+    int kyb, m_l, HW;
+    uint32_t colmask;                              // bit kx set -> column is inside the image
+    bool lshift;                                   // first tap is the left padding column
+    f32x4 r[VPT];
+    __device__ __forceinline__ void issue_lds(int, float*) {}
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        const ConvShape& s = p.s;
+        rsrc = make_rsrc(p.x, (uint32_t)(s.N * s.C * s.H * s.W) * 4u);
+        m_l = tid % BM;
+        kyb = tid / BM;
+        uint32_t m = (uint32_t)tile * BM + m_l;
+        const bool m_ok = m < (uint32_t)s.N * s.OH * s.OW;
+        uint32_t n = fdiv(m, p.div_ohw);
+        uint32_t pix = m - n * (uint32_t)(s.OH * s.OW);
+        uint32_t oy = fdiv(pix, p.div_ow);
+        uint32_t ox = pix - oy * (uint32_t)s.OW;
+        const int iy0 = (int)oy * S - P, ix0 = (int)ox * S - P;
+        HW = s.H * s.W;
+        colmask = 0;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx)
+            if ((unsigned)(ix0 + kx) < (unsigned)s.W) colmask |= 1u << kx;
+        lshift = ix0 < 0;
+        const int ixs = lshift ? 0 : ix0;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            int iy = iy0 + kyb + KYSTEP * j;
+            bool ok = m_ok && (unsigned)iy < (unsigned)s.H;
+            voff[j] = ok ? (n * (uint32_t)(s.C * HW) + (uint32_t)(iy * s.W + ixs)) * 4u : OOB;
+        }
+    }
+    __device__ __forceinline__ void issue(int kc) {
+        const uint32_t soff = (uint32_t)kc * (uint32_t)HW * 4u;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) r[j] = bload4(rsrc, voff[j], soff);
+    }
+    __device__ __forceinline__ void commit(float* dst) const {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int krow = (kyb + KYSTEP * j) * 4;
+            f32x4 v = r[j];
+            if (lshift) v = f32x4{0.f, v.x, v.y, v.z};
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) dst[(krow + kx) * LD + m_l] = (colmask >> kx) & 1u ? v[kx] : 0.f;
+        }
+    }
+};
+
 // Transposed convolution / data gradient, decomposed into S*S output phases.
 // Phase (py, px) produces x[n][c][S*a+py][S*b+px]; along each axis it uses the taps
 //   t = 0..T-1 :  ky = ((py + P) % S) + S*t ,  oy = a + (py + P)/S - t
