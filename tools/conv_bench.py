@@ -1,5 +1,5 @@
 import torch, sys, os
-sys.path.insert(0,'.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from lightning_gan_zoo_amd import functional as F
 g=F.K4S2P1
 bs=int(sys.argv[1]) if len(sys.argv)>1 else 512
