@@ -83,6 +83,8 @@ struct MContigLoader {
         long long batch_stride;  // elements, indexed by blockIdx.y
     };
     static constexpr int LD = BMN;
+    static constexpr int NPARTS = 0;
+    __device__ __forceinline__ void issue_lds_part(int, float*, int) {}
     static constexpr int EPT = BMN * BK / NT;
     static constexpr int STEP = NT / BMN;
     static constexpr bool DMA = GZ_IGEMM_DMA;
@@ -143,6 +145,17 @@ struct MContigLoader4 {
     int kb, c4, K, ld;
     bool col_ok;
     f32x4 r[DMA ? 1 : PASSES];
+    static constexpr int NPARTS = PASSES;
+    __device__ __forceinline__ void issue_lds_part(int kc, float* dst, int j) {
+        const int lane = threadIdx.x & 63;
+        const int kb0 = kb - lane / C4;
+        int kl = kb + ROWS * j;
+        if (kb0 + ROWS * j < BK) {
+            int k = kc * BK + kl;
+            uint32_t v = (col_ok && k < K) ? (uint32_t)k * (uint32_t)ld * 4u + col_off : OOB;
+            bload_lds16(rsrc, dst + (kb0 + ROWS * j) * LD, v, 0);
+        }
+    }
     // a wave covers 64/C4 whole rows of the [k][BMN] image = one contiguous 1 KiB piece (LD == BMN)
     __device__ __forceinline__ void issue_lds(int kc, float* dst) {
         const int lane = threadIdx.x & 63;
@@ -201,6 +214,8 @@ struct KContigLoader {
         long long batch_stride;
     };
     static constexpr int LD = BMN + 2;
+    static constexpr int NPARTS = 0;
+    __device__ __forceinline__ void issue_lds_part(int, float*, int) {}
     static constexpr bool DMA = false;
     __device__ __forceinline__ void issue_lds(int, float*) {}
     static constexpr int EPT = BMN / 16;
@@ -272,6 +287,12 @@ struct ConvFwdALoader {
             return ok ? (nbase + (uint32_t)((c * H + iy) * W + ix)) * 4u : OOB;
         }
     }
+    static constexpr int NPARTS = EPT;
+    __device__ __forceinline__ void issue_lds_part(int kc, float* dst, int j) {
+        float* wbase = dst + (m_l - (int)(threadIdx.x & 63));
+        const uint32_t soff = FIXED ? (uint32_t)kc * (uint32_t)(H * W) * 4u : 0u;
+        bload_lds4(rsrc, wbase + (kb + STEP * j) * LD, tap_voff(kc, j), soff);
+    }
     // a wave's 64 lanes are 64 consecutive m of one k row: one contiguous 256-byte LDS piece
     __device__ __forceinline__ void issue_lds(int kc, float* dst) {
         float* wbase = dst + (m_l - (int)(threadIdx.x & 63));
@@ -331,6 +352,8 @@ template <int BM, int S, int P>
 struct ConvFwdALoaderK4V {
     using Params = typename ConvFwdALoader<BM, 4, 4, S, P>::Params;
     static constexpr int LD = BM;
+    static constexpr int NPARTS = 0;
+    __device__ __forceinline__ void issue_lds_part(int, float*, int) {}
     static constexpr bool DMA = false;
     static constexpr int VPT = BM * 4 / NT;        // vector loads per lane per chunk (2 for BM=128, 1 for 64)
     static constexpr int KYSTEP = NT / BM;         // 2 or 4
@@ -426,6 +449,12 @@ struct ConvDgALoader {
             return ok ? (nbase + (uint32_t)((ko * OH + oy) * OW + ox)) * 4u : OOB;
         }
     }
+    static constexpr int NPARTS = EPT;
+    __device__ __forceinline__ void issue_lds_part(int kc, float* dst, int j) {
+        float* wbase = dst + (m_l - (int)(threadIdx.x & 63));
+        const uint32_t soff = FIXED ? (uint32_t)kc * (uint32_t)((BK / TAPS) * OH * OW) * 4u : 0u;
+        bload_lds4(rsrc, wbase + (kb + STEP * j) * LD, tap_voff(kc, j), soff);
+    }
     __device__ __forceinline__ void issue_lds(int kc, float* dst) {
         float* wbase = dst + (m_l - (int)(threadIdx.x & 63));
         const uint32_t soff = FIXED ? (uint32_t)kc * (uint32_t)((BK / TAPS) * OH * OW) * 4u : 0u;
@@ -485,6 +514,8 @@ struct WgALoader {
         int KTOT;  // N*OH*OW
     };
     static constexpr int LD = BM + 2;
+    static constexpr int NPARTS = 0;
+    __device__ __forceinline__ void issue_lds_part(int, float*, int) {}
     static constexpr bool DMA = false;
     __device__ __forceinline__ void issue_lds(int, float*) {}
     static constexpr int EPT = BM / 16;
@@ -536,6 +567,8 @@ struct WgBLoader {
         int KTOT, NTOT;  // N*OH*OW, C*KH*KW
     };
     static constexpr int LD = BN + 2;
+    static constexpr int NPARTS = 0;
+    __device__ __forceinline__ void issue_lds_part(int, float*, int) {}
     static constexpr bool DMA = false;
     __device__ __forceinline__ void issue_lds(int, float*) {}
     static constexpr int EPT = BN / 16;
@@ -608,6 +641,8 @@ struct WgALoaderRow {
         int KTOT;
     };
     static constexpr int LD = BM + 2;
+    static constexpr int NPARTS = 0;
+    __device__ __forceinline__ void issue_lds_part(int, float*, int) {}
     static constexpr bool DMA = false;
     __device__ __forceinline__ void issue_lds(int, float*) {}
     static constexpr int EPT = BM / 16;
@@ -654,6 +689,8 @@ struct WgBLoaderRow {
         int KTOT, NTOT;
     };
     static constexpr int LD = BN + 2;
+    static constexpr int NPARTS = 0;
+    __device__ __forceinline__ void issue_lds_part(int, float*, int) {}
     static constexpr bool DMA = false;
     __device__ __forceinline__ void issue_lds(int, float*) {}
     static constexpr int EPT = BN / 16;
@@ -729,6 +766,8 @@ struct Conv3DFwdALoader {
         FastDiv div_odhw, div_ohw, div_ow;
     };
     static constexpr int LD = BM;
+    static constexpr int NPARTS = 0;
+    __device__ __forceinline__ void issue_lds_part(int, float*, int) {}
     static constexpr bool DMA = false;
     __device__ __forceinline__ void issue_lds(int, float*) {}
     static constexpr int EPT = BM * BK / NT;
@@ -788,6 +827,8 @@ struct Conv3DDgALoader {
         FastDiv div_adhw, div_ahw, div_aw;
     };
     static constexpr int LD = BM;
+    static constexpr int NPARTS = 0;
+    __device__ __forceinline__ void issue_lds_part(int, float*, int) {}
     static constexpr bool DMA = false;
     __device__ __forceinline__ void issue_lds(int, float*) {}
     static constexpr int EPT = BM * BK / NT;
@@ -850,6 +891,8 @@ struct Wg3DBLoader {
         int KTOT, NTOT;
     };
     static constexpr int LD = BN + 2;
+    static constexpr int NPARTS = 0;
+    __device__ __forceinline__ void issue_lds_part(int, float*, int) {}
     static constexpr bool DMA = false;
     __device__ __forceinline__ void issue_lds(int, float*) {}
     static constexpr int EPT = BN / 16;
@@ -1107,6 +1150,9 @@ struct GridMap {
     int chunks_per_split;      // grid.z = ceil(chunks / chunks_per_split)
 };
 
+#ifndef GZ_IGEMM_INTERLEAVE
+#define GZ_IGEMM_INTERLEAVE 0
+#endif
 #ifndef GZ_IGEMM_WAVES_PER_SIMD
 #define GZ_IGEMM_WAVES_PER_SIMD 1
 #endif
@@ -1170,7 +1216,8 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
         const int cur = (kc - kc0) & 1;
         const bool more = kc + 1 < kc1;
 #if !defined(GZ_EXP_NOLOAD) && !defined(GZ_EXP_NOISSUE)   // timing experiments only (wrong results)
-        if (more) {
+        constexpr bool INTERLEAVE = GZ_IGEMM_INTERLEAVE && AL::DMA && BL::DMA;
+        if (more && !INTERLEAVE) {
             // the other LDS buffer was last read in the previous iteration, behind its closing barrier
 #ifdef GZ_EXP_SAMECHUNK      // timing experiment: always re-load chunk kc0 (cache-resident)
             if constexpr (AL::DMA) al.issue_lds(kc0, As + (cur ^ 1) * BK * LDA); else al.issue(kc0);
@@ -1207,9 +1254,27 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i], bf[c][j], acc[i][j], 0, 0, 0);
             // pin the order "next step's LDS reads, then this step's MFMAs" (hipcc otherwise sinks the
             // reads behind the MFMAs to save two registers)
+            if constexpr (INTERLEAVE) {
+                // spread the staging loads of chunk kc+1 over the k-steps so that no wave has a long
+                // MFMA-free stretch at the top of the chunk (co-resident workgroups run in lockstep)
+                if (more) {
+                    if constexpr (AL::NPARTS > 0) {
+                        constexpr int PER = (AL::NPARTS + BK / 2 - 1) / (BK / 2);
+#pragma unroll
+                        for (int q = 0; q < PER; ++q)
+                            if (s * PER + q < AL::NPARTS) al.issue_lds_part(kc + 1, As + (cur ^ 1) * BK * LDA, s * PER + q);
+                    }
+                    if constexpr (BL::NPARTS > 0) {
+                        constexpr int STRIDE = (BK / 2) / BL::NPARTS;
+                        if (s % STRIDE == 0 && s / STRIDE < BL::NPARTS)
+                            bl.issue_lds_part(kc + 1, Bs + (cur ^ 1) * BK * LDB, s / STRIDE);
+                    }
+                }
+            }
 #ifndef GZ_IGEMM_NO_FRAG_PREFETCH
             __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // DS read
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);   // MFMA
+            if constexpr (INTERLEAVE) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);   // VMEM reads of this step
 #endif
         }
 #if !defined(GZ_EXP_NOLOAD) && !defined(GZ_EXP_NOCOMMIT)
