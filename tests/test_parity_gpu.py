@@ -77,3 +77,48 @@ def test_logits_within_1e3_of_cpu_reference():
         logits = step.discriminator(step.generator(inputs["z_d0"].cuda())).reshape(-1).cpu().numpy()
     ref = golden["probe/logits"]
     assert np.abs(logits - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(img_size=32, channels_img=1, features=8, bs=3, nz=7, norm="batch_norm"),      # MNIST-like, ragged everything
+    dict(img_size=128, channels_img=3, features=4, bs=2, nz=10, norm="batch_norm"),    # deeper stacks (5 blocks)
+    dict(img_size=64, channels_img=2, features=12, bs=5, nz=33, norm="instance_norm2d"),
+    dict(img_size=64, channels_img=3, features=8, bs=1, nz=16, norm="identity"),       # batch of one, no norm in D
+])
+def test_standard_networks_other_shapes_match_oracle(cfg):
+    """Shapes outside the benchmark configs (image sizes 32 / 128, 1-2 image channels, odd batch sizes,
+    batch 1, identity norm): forward, input gradient and every parameter gradient vs the CPU oracle."""
+    from helpers import fill_closed_form, rel_err
+    from lightning_gan_zoo_amd.core.models import standard_networks as P
+    from oracle import reference_cpu as O
+    c = cfg
+    torch.manual_seed(1)
+    gp, go = (m.Generator(c["nz"], c["channels_img"], c["features"], c["img_size"]) for m in (P, O))
+    dp, do = (m.Discriminator(c["channels_img"], c["features"], c["norm"], c["img_size"], False) for m in (P, O))
+    for a, b in ((gp, go), (dp, do)):
+        fill_closed_form(a, 5)
+        with torch.no_grad():      # keep the ReLU / LeakyReLU masks behind the norms away from the threshold
+            for n, p in a.named_parameters():
+                if n.endswith(("batch_norm.bias", "instance_norm2d.bias")):
+                    p.add_(8.0)
+        b.load_state_dict(a.state_dict())
+    gp.cuda(), dp.cuda()
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(c["bs"], c["nz"], generator=g)
+    zp, zo = z.cuda().requires_grad_(), z.clone().requires_grad_()
+    outs = []
+    for G, D, zz in ((gp, dp, zp), (go, do, zo)):
+        fake = G(zz)
+        score = D(fake)
+        (score.sum() + 0.1 * fake.pow(2).sum()).backward()
+        outs.append((fake.detach().cpu(), score.detach().cpu(), zz.grad.cpu(),
+                     {n: p.grad.cpu() for n, p in list(G.named_parameters()) + list(D.named_parameters())}))
+    (fp, sp, gzp, pgp), (fo, so, gzo, pgo) = outs
+    assert fp.shape == (c["bs"], c["channels_img"], c["img_size"], c["img_size"])
+    assert rel_err(fp.numpy(), fo.numpy()) < TOL and rel_err(sp.numpy(), so.numpy()) < TOL
+    # gradients: relative L2 (ReLU masks at rounding level, see test_oracle_golden.compare)
+    def l2(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    assert l2(gzp, gzo) < 5e-3
+    worst = max((l2(pgp[n], pgo[n]), n) for n in pgo)
+    assert worst[0] < 5e-3, worst
