@@ -1288,6 +1288,9 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
 #endif
     }
 
+#ifdef GZ_EXP_NOSTORE   // timing experiment: keep one store so the accumulators stay live
+    if (acc[0][0][0] == 123456.789f)
+#endif
     Epi::template store<TM, TN>(pe, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32,
                                 lane, y, z);
 }
