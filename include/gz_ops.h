@@ -155,6 +155,17 @@ int gz_coldot(const float* g, const float* x, float* out, float* workspace, size
 /* p = clamp(p, lo, hi) in place (core/lightning_module.py:160-162) */
 int gz_clamp_(float* p, long long count, float lo, float hi, hipStream_t stream);
 
+/* ---- fused multi-tensor optimizer steps (the `optimiser` nodes of conf/expt/*.yaml) -------------------------
+ * `count` <= GZ_OPT_MAX_TENSORS tensors per call (host arrays of device pointers and element counts);
+ * grads are multiplied by grad_scale first (1/world for data-parallel means).  Formulas are torch.optim's
+ * single-tensor ones (no weight decay, no amsgrad / momentum / centered). */
+#define GZ_OPT_MAX_TENSORS 24
+int gz_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                 float* const* exp_avg_sq, const long long* numel, float lr, float beta1, float beta2, float eps,
+                 int step, float grad_scale, hipStream_t stream);
+int gz_rmsprop_step(int count, float* const* params, const float* const* grads, float* const* square_avg,
+                    const long long* numel, float lr, float alpha, float eps, float grad_scale, hipStream_t stream);
+
 /* text of the last HIP error seen by a launcher on the calling thread ("" if none) */
 const char* gz_last_error(void);
 

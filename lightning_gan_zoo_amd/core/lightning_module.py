@@ -65,8 +65,16 @@ class BaseGAN(LightningModule):
         return {"real": real}
 
     def configure_optimizers(self):
-        opt_disc = instantiate(self.cfg.disc_optimiser, self.discriminator.parameters())
-        opt_gen = instantiate(self.cfg.gen_optimiser, self.generator.parameters())
+        # the reference's nodes target torch.optim.Adam / RMSprop (conf/expt/*.yaml); on the GPU they are
+        # served by the fused HIP implementations with the same arguments and state layout
+        # (lightning_gan_zoo_amd.optim); `fused_optimizer: false` in the config keeps torch's own
+        d_params, g_params = list(self.discriminator.parameters()), list(self.generator.parameters())
+        d_node, g_node = self.cfg.disc_optimiser, self.cfg.gen_optimiser
+        if self.cfg.get("fused_optimizer", True):
+            from ..optim import fused_node
+            d_node, g_node = fused_node(d_node, d_params), fused_node(g_node, g_params)
+        opt_disc = instantiate(d_node, d_params)
+        opt_gen = instantiate(g_node, g_params)
         scheduler_disc = instantiate(self.cfg.optimisation.lr_scheduler, optimizer=opt_disc)
         scheduler_gen = instantiate(self.cfg.optimisation.lr_scheduler, optimizer=opt_gen)
         return ({"optimizer": opt_disc, "lr_scheduler": scheduler_disc,

@@ -1,0 +1,125 @@
+// Fused multi-tensor optimizer steps: the update that follows every backward in the
+// reference's harness (torch.optim.Adam for dc_gan / wgan_gp / hologan, torch.optim.RMSprop for wgan;
+// conf/expt/*.yaml `optimiser` nodes).  One launch walks up to GZ_OPT_MAX_TENSORS parameter tensors; each
+// element is read and written once (Adam: p, g, m, v in / p, m, v out = 28 B per parameter) instead of
+// the ~14 passes of the foreach implementation.  Arithmetic follows torch's single-tensor formulas
+// (lerp for the first moment, bias corrections folded the same way) so results agree to rounding.
+#include "gz_common.h"
+#include "../../include/gz_ops.h"
+
+namespace gz {
+
+constexpr int OPT_MAX = GZ_OPT_MAX_TENSORS;
+constexpr int OPT_THREADS = 256;
+constexpr int OPT_CHUNK = 4096;     // elements per workgroup
+
+struct OptTable {
+    float* p[OPT_MAX];
+    const float* g[OPT_MAX];
+    float* m[OPT_MAX];
+    float* v[OPT_MAX];
+    long long n[OPT_MAX];
+    int first_block[OPT_MAX + 1];   // prefix sum of chunk counts
+    int count;
+};
+
+__device__ __forceinline__ int find_tensor(const OptTable& t, int block) {
+    int k = 0;
+    while (k + 1 < t.count && block >= t.first_block[k + 1]) ++k;
+    return k;
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void adam_kernel(OptTable t, float lr, float beta1, float beta2, float eps,
+                                                           float bc1, float bc2_sqrt, float grad_scale) {
+    const int k = find_tensor(t, blockIdx.x);
+    const long long base = (long long)(blockIdx.x - t.first_block[k]) * OPT_CHUNK;
+    float* p = t.p[k];
+    const float* g = t.g[k];
+    float* m = t.m[k];
+    float* v = t.v[k];
+    const long long n = t.n[k];
+    const float step_size = lr / bc1;
+    for (int i = threadIdx.x; i < OPT_CHUNK; i += OPT_THREADS) {
+        long long e = base + i;
+        if (e >= n) break;
+        float gv = g[e] * grad_scale;
+        float mv = m[e];
+        mv = mv + (gv - mv) * (1.f - beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
+        float vv = v[e] * beta2 + (1.f - beta2) * gv * gv;   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        float denom = sqrtf(vv) / bc2_sqrt + eps;
+        p[e] = p[e] - step_size * (mv / denom);              // param.addcdiv_(exp_avg, denom, value=-step_size)
+        m[e] = mv;
+        v[e] = vv;
+    }
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void rmsprop_kernel(OptTable t, float lr, float alpha, float eps,
+                                                              float grad_scale) {
+    const int k = find_tensor(t, blockIdx.x);
+    const long long base = (long long)(blockIdx.x - t.first_block[k]) * OPT_CHUNK;
+    float* p = t.p[k];
+    const float* g = t.g[k];
+    float* v = t.v[k];
+    const long long n = t.n[k];
+    for (int i = threadIdx.x; i < OPT_CHUNK; i += OPT_THREADS) {
+        long long e = base + i;
+        if (e >= n) break;
+        float gv = g[e] * grad_scale;
+        float vv = v[e] * alpha + (1.f - alpha) * gv * gv;   // square_avg.mul_(alpha).addcmul_(grad, grad, 1 - alpha)
+        p[e] = p[e] - lr * (gv / (sqrtf(vv) + eps));         // param.addcdiv_(grad, avg, value=-lr)
+        v[e] = vv;
+    }
+}
+
+static int fill_table(OptTable& t, int count, float* const* p, const float* const* g, float* const* m,
+                      float* const* v, const long long* n) {
+    if (count <= 0 || count > OPT_MAX) return GZ_ERR_BAD_SHAPE;
+    t.count = count;
+    int blocks = 0;
+    for (int k = 0; k < count; ++k) {
+        if (n[k] <= 0) return GZ_ERR_BAD_SHAPE;
+        t.p[k] = p[k];
+        t.g[k] = g[k];
+        t.m[k] = m ? m[k] : nullptr;
+        t.v[k] = v[k];
+        t.n[k] = n[k];
+        t.first_block[k] = blocks;
+        blocks += (int)((n[k] + OPT_CHUNK - 1) / OPT_CHUNK);
+    }
+    t.first_block[count] = blocks;
+    return blocks;
+}
+
+}  // namespace gz
+
+using namespace gz;
+
+extern "C" {
+
+int gz_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                 float* const* exp_avg_sq, const long long* numel, float lr, float beta1, float beta2, float eps,
+                 int step, float grad_scale, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (step < 1) return GZ_ERR_BAD_SHAPE;
+    OptTable t;
+    int blocks = fill_table(t, count, params, grads, exp_avg, exp_avg_sq, numel);
+    if (blocks < 0) return blocks;
+    // bias corrections in double, as torch does with Python floats
+    double bc1 = 1.0 - pow((double)beta1, (double)step);
+    double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(OPT_THREADS), 0, stream, t, lr, beta1, beta2, eps, (float)bc1,
+                       (float)sqrt(bc2), grad_scale);
+    return launch_status();
+}
+
+int gz_rmsprop_step(int count, float* const* params, const float* const* grads, float* const* square_avg,
+                    const long long* numel, float lr, float alpha, float eps, float grad_scale, hipStream_t stream) {
+    gz::clear_stale_error();
+    OptTable t;
+    int blocks = fill_table(t, count, params, grads, nullptr, square_avg, numel);
+    if (blocks < 0) return blocks;
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(blocks), dim3(OPT_THREADS), 0, stream, t, lr, alpha, eps, grad_scale);
+    return launch_status();
+}
+
+}  // extern "C"

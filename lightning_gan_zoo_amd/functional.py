@@ -122,8 +122,9 @@ def clear_pack_cache():
 def invalidate(w):
     """Forget the packed images of `w` after its memory was rewritten without a version bump
     (raw in-place kernels: clamp_, the fused optimizers)."""
-    _pack_cache.pop((w.data_ptr(), "f"), None)
-    _pack_cache.pop((w.data_ptr(), "d"), None)
+    for cache in (_pack_cache, _pack3_cache):
+        cache.pop((w.data_ptr(), "f"), None)
+        cache.pop((w.data_ptr(), "d"), None)
 
 
 # ---------------------------------------------------------------------------

@@ -1,0 +1,124 @@
+"""Fused multi-tensor Adam / RMSprop on the HIP kernels (csrc/gz_optim.hip), drop-in for the
+``torch.optim.Adam`` / ``torch.optim.RMSprop`` objects the reference instantiates from its ``optimiser``
+config nodes (conf/expt/dc_gan.yaml:12-15, wgan.yaml:24-26, wgan_gp.yaml:26-29, hologan.yaml:21-24).
+
+Same constructor arguments, same ``param_groups`` keys and the same per-parameter state entries
+(``step``, ``exp_avg``, ``exp_avg_sq`` / ``square_avg``), so optimizer ``state_dict``s interchange with
+torch's and LR schedulers work unchanged.  Only the configurations the reference uses are supported
+(no weight decay, amsgrad, momentum or centering); anything else raises.
+"""
+import ctypes
+
+import torch
+
+from . import functional as F
+from ._lib import check, lib
+
+MAX_TENSORS = 24
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _check_tensor(p):
+    if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+        raise RuntimeError("fused optimizers need contiguous float32 GPU parameters")
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **unused):
+        if weight_decay or amsgrad:
+            raise NotImplementedError("fused Adam: weight_decay / amsgrad are outside the reference's configs")
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False,
+                        foreach=None, capturable=False, differentiable=False, fused=None)
+        super().__init__(params, defaults)
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = closure() if closure is not None else None
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for group in self.param_groups:
+            beta1, beta2 = group["betas"]
+            by_step = {}
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                _check_tensor(p)
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                by_step.setdefault(int(st["step"].item()), []).append(p)
+            for step, plist in by_step.items():
+                for i in range(0, len(plist), MAX_TENSORS):
+                    chunk = plist[i:i + MAX_TENSORS]
+                    grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in chunk]
+                    numel = (ctypes.c_longlong * len(chunk))(*[p.numel() for p in chunk])
+                    check(lib.gz_adam_step(len(chunk), _ptr_array(chunk), _ptr_array(grads),
+                                           _ptr_array([self.state[p]["exp_avg"] for p in chunk]),
+                                           _ptr_array([self.state[p]["exp_avg_sq"] for p in chunk]), numel,
+                                           float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), step,
+                                           float(grad_scale), stream), "adam_step")
+                for p in plist:
+                    F.invalidate(p)         # packed conv weights of p are stale now
+        return loss
+
+
+class RMSprop(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0, momentum=0, centered=False, **unused):
+        if weight_decay or momentum or centered:
+            raise NotImplementedError("fused RMSprop: weight_decay / momentum / centered are outside the "
+                                      "reference's configs")
+        defaults = dict(lr=lr, momentum=0, alpha=alpha, eps=eps, centered=False, weight_decay=0, capturable=False,
+                        foreach=None, maximize=False, differentiable=False)
+        super().__init__(params, defaults)
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = closure() if closure is not None else None
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for group in self.param_groups:
+            plist = []
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                _check_tensor(p)
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["square_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                plist.append(p)
+            for i in range(0, len(plist), MAX_TENSORS):
+                chunk = plist[i:i + MAX_TENSORS]
+                grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in chunk]
+                numel = (ctypes.c_longlong * len(chunk))(*[p.numel() for p in chunk])
+                check(lib.gz_rmsprop_step(len(chunk), _ptr_array(chunk), _ptr_array(grads),
+                                          _ptr_array([self.state[p]["square_avg"] for p in chunk]), numel,
+                                          float(group["lr"]), float(group["alpha"]), float(group["eps"]),
+                                          float(grad_scale), stream), "rmsprop_step")
+            for p in plist:
+                F.invalidate(p)
+        return loss
+
+
+FUSED_TARGETS = {"torch.optim.Adam": "lightning_gan_zoo_amd.optim.Adam",
+                 "torch.optim.RMSprop": "lightning_gan_zoo_amd.optim.RMSprop",
+                 "torch.optim.adam.Adam": "lightning_gan_zoo_amd.optim.Adam",
+                 "torch.optim.rmsprop.RMSprop": "lightning_gan_zoo_amd.optim.RMSprop"}
+
+
+def fused_node(node, params):
+    """Map an ``optimiser`` config node that targets torch's Adam / RMSprop onto the fused classes when
+    every parameter lives on the GPU and the node uses only supported options; otherwise return it as is."""
+    target = node.get("_target_")
+    if target not in FUSED_TARGETS or not all(p.is_cuda for p in params):
+        return node
+    if any(node.get(k) for k in ("weight_decay", "amsgrad", "momentum", "centered")):
+        return node
+    out = dict(node)
+    out["_target_"] = FUSED_TARGETS[target]
+    return out

@@ -350,3 +350,40 @@ def test_hologan_ext128_matches_oracle_extension():
     lp, zp = dp(img_p)
     lo, zo = do(img_o)
     assert rel(lp, lo) < TOL and rel(zp, zo) < TOL
+
+
+@pytest.mark.parametrize("kind", ["adam", "adam_b0", "rmsprop"])
+def test_fused_optimizers_match_torch(kind):
+    """Fused multi-tensor Adam / RMSprop vs torch.optim on the same GPU tensors over 5 steps; state_dicts
+    interchange."""
+    from lightning_gan_zoo_amd import optim as O
+    torch.manual_seed(0)
+    shapes = [(64, 3, 4, 4), (128,), (100, 1024, 4, 4), (7,), (1, 512, 4, 4)]
+    pa = [torch.nn.Parameter(torch.randn(s, device="cuda") * 0.05) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    if kind == "rmsprop":
+        oa, ob = O.RMSprop(pa, lr=5e-5), torch.optim.RMSprop(pb, lr=5e-5)
+    else:
+        betas = (0.0, 0.9) if kind == "adam_b0" else (0.5, 0.999)
+        oa, ob = O.Adam(pa, lr=2e-4, betas=betas), torch.optim.Adam(pb, lr=2e-4, betas=betas)
+    for step in range(5):
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a) * (0.1 + step)
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for a, b in zip(pa, pb):
+        assert rel(a, b) < 1e-6
+    # a fresh fused optimizer continues from TORCH's state_dict (same keys / shapes) and keeps matching torch
+    pc = [torch.nn.Parameter(b.detach().clone()) for b in pb]
+    oc = type(oa)(pc, **{k: v for k, v in ob.param_groups[0].items() if k in ("lr", "betas", "alpha", "eps")})
+    import copy
+    oc.load_state_dict(copy.deepcopy(ob.state_dict()))    # (load_state_dict would alias torch's CPU `step` tensors)
+    assert set(oa.state_dict()["state"][0]) == set(ob.state_dict()["state"][0])
+    for c, b in zip(pc, pb):
+        g = torch.randn_like(b)
+        c.grad, b.grad = g.clone(), g.clone()
+    oc.step()
+    ob.step()
+    for c, b in zip(pc, pb):
+        assert rel(c, b) < 1e-6
