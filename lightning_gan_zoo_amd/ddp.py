@@ -89,10 +89,16 @@ class GradSync:
         self.pending[idx] = None
         work, optimizer = item
         fg = self.flats[idx]
+        scale = 1.0
         if work is not None:
             work.wait()
-            fg.flat.mul_(1.0 / self.world)
-        optimizer.step()
+            scale = 1.0 / self.world
+        if scale != 1.0 and getattr(optimizer, "accepts_grad_scale", False):
+            optimizer.step(grad_scale=scale)      # the fused optimizers fold the 1/world into their single pass
+        else:
+            if scale != 1.0:
+                fg.flat.mul_(scale)
+            optimizer.step()
         fg.flat.zero_()          # == optimizer.zero_grad(set_to_none=False), one memset
 
     def flush(self):

@@ -27,6 +27,8 @@ def _check_tensor(p):
 
 
 class Adam(torch.optim.Optimizer):
+    accepts_grad_scale = True
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **unused):
         if weight_decay or amsgrad:
             raise NotImplementedError("fused Adam: weight_decay / amsgrad are outside the reference's configs")
@@ -68,6 +70,8 @@ class Adam(torch.optim.Optimizer):
 
 
 class RMSprop(torch.optim.Optimizer):
+    accepts_grad_scale = True
+
     def __init__(self, params, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0, momentum=0, centered=False, **unused):
         if weight_decay or momentum or centered:
             raise NotImplementedError("fused RMSprop: weight_decay / momentum / centered are outside the "
