@@ -155,6 +155,24 @@ int gz_coldot(const float* g, const float* x, float* out, float* workspace, size
 /* p = clamp(p, lo, hi) in place (core/lightning_module.py:160-162) */
 int gz_clamp_(float* p, long long count, float lo, float hi, hipStream_t stream);
 
+/* ---- R1-regularised ResNet path ------------------------------------------------------------
+ * HBM-bound linear maps of reference core/submodules/gan_stability/models/resnet.py; every fwd/bwd pair is also
+ * its own double-backward pair (the adjoint of the adjoint is the forward). count % 4 == 0. */
+/* y = act(x): the pre-activation `actvn` (resnet.py:131-133) */
+int gz_act_fwd(const float* x, float* y, long long count, int act, float slope, hipStream_t stream);
+/* out = alpha*a + beta*b (b may be NULL); act_out (may be NULL) = act(out) written in the same pass:
+ * the residual tail `x_s + 0.1*dx` (resnet.py:121-122) together with the next block's `actvn(x)` */
+int gz_axpby(const float* a, float alpha, const float* b, float beta, float* out, float* act_out, long long count,
+             int act, float slope, hipStream_t stream);
+/* nn.AvgPool2d(3, stride=2, padding=1) (count_include_pad) over `planes` = N*C maps (resnet.py:72) and its
+ * adjoint; OH = (H-1)/2 + 1 */
+int gz_avgpool3s2_fwd(const float* x, float* y, long long planes, int H, int W, int OH, int OW, hipStream_t stream);
+int gz_avgpool3s2_bwd(const float* gy, float* gx, long long planes, int H, int W, int OH, int OW,
+                      hipStream_t stream);
+/* nn.Upsample(scale_factor=2) (nearest, resnet.py:31) [planes,H,W] -> [planes,2H,2W] and its adjoint */
+int gz_upsample2_fwd(const float* x, float* y, long long planes, int H, int W, hipStream_t stream);
+int gz_upsample2_bwd(const float* gy, float* gx, long long planes, int H, int W, hipStream_t stream);
+
 /* ---- fused multi-tensor optimizer steps (the `optimiser` nodes of conf/expt/*.yaml) -------------------------
  * `count` <= GZ_OPT_MAX_TENSORS tensors per call (host arrays of device pointers and element counts);
  * grads are multiplied by grad_scale first (1/world for data-parallel means).  Formulas are torch.optim's

@@ -152,8 +152,22 @@ def make_cfg(expt, module_root=PRODUCT_ROOT, batch_size=None, features=None, img
         if t["img_size"] == 128:     # EXT-128: the reference itself cannot run at 128
             cfg["generator"]["ext128"] = True
             cfg["discriminator"]["img_size"] = 128
+    elif expt == "gan_stability_r1":                      # conf/expt/gan_stability_r1.yaml
+        cfg["model"]["lm"]["_target_"] = lm + "GANStabilityR1"
+        cfg["model"]["noise_dim"] = noise_dim or 256
+        t.update(batch_size=64, img_size=img_size or 128)
+        cfg["optimisation"].update(lr=1e-4, disc_freq=1, lr_anneal=1.0, anneal_every=150000)
+        cfg["optimiser"] = {"_target_": "torch.optim.RMSprop", "lr": 1e-4}
+        cfg["loss_weight"] = {"reg": 10}
+        # Only the keys the ResNet classes accept: the root config would also merge `img_size` (and
+        # `final_sigmoid` for D, conf/config.yaml:35-40), which resnet.Discriminator.__init__ (resnet.py:55)
+        # rejects -- the reference's own composition of this experiment cannot construct its discriminator.
+        for net in ("generator", "discriminator"):
+            cfg[net] = {"_target_": module_root + ".submodules.gan_stability.models.resnet." + net.capitalize(),
+                        "z_dim": cfg["model"]["noise_dim"], "nlabels": 1, "size": t["img_size"],
+                        "nfilter": features or 16, "nfilter_max": 512, "embed_size": 1}
     else:
-        raise ValueError("unknown expt %r (hot path covers dc_gan, wgan, wgan_gp, hologan)" % expt)
+        raise ValueError("unknown expt %r (covered: dc_gan, wgan, wgan_gp, hologan, gan_stability_r1)" % expt)
     if batch_size is not None:
         t["batch_size"] = batch_size
         if expt == "hologan":

@@ -16,7 +16,7 @@ import torch
 from .. import functional as F
 from ..config import instantiate
 from ..harness import LightningModule, draw_on_host
-from .utils.utils import gradient_penalty
+from .utils.utils import compute_grad2, gradient_penalty
 
 
 class _Identity:
@@ -98,6 +98,31 @@ class DCGAN(BaseGAN):
             return loss_disc
 
         if optimizer_idx == 1:      # generator (reference :124-128)
+            output = self.discriminator(fake).reshape(-1)
+            loss_gen = self.criterion(output, torch.ones_like(output))
+            self.log("train/g_loss", loss_gen)
+            return loss_gen
+
+
+class GANStabilityR1(BaseGAN):
+    """reference core/lightning_module.py:130-156"""
+
+    def training_step(self, batch, batch_idx, optimizer_idx):
+        real, _ = batch
+        fake = self.generator(self.sample_noise(len(real)))
+
+        if optimizer_idx == 0:
+            real.requires_grad_()
+            disc_real = self.discriminator(real).reshape(-1)
+            loss_disc_real = self.criterion(disc_real, torch.ones_like(disc_real))
+            disc_fake = self.discriminator(fake.detach()).reshape(-1)
+            loss_disc_fake = self.criterion(disc_fake, torch.zeros_like(disc_fake))
+            r1_reg = self.cfg.loss_weight.reg * compute_grad2(disc_real, real).mean()
+            loss_disc = r1_reg + (loss_disc_real + loss_disc_fake)
+            self.log("train/d_loss", loss_disc)
+            return loss_disc
+
+        if optimizer_idx == 1:
             output = self.discriminator(fake).reshape(-1)
             loss_gen = self.criterion(output, torch.ones_like(output))
             self.log("train/g_loss", loss_gen)

@@ -912,3 +912,188 @@ def spectral_normalize(weight_orig, u, v, training, eps=1e-12):
     uc, vc = u.clone(), v.clone()
     sigma = torch.dot(uc, _DotF.apply(w_mat, vc))
     return weight_orig / sigma
+
+
+# ---------------------------------------------------------------------------
+# R1-regularised ResNet path (reference core/submodules/gan_stability/models/resnet.py).
+# Every op here is linear or piecewise linear, so forward/adjoint pairs close under differentiation and
+# compute_grad2's create_graph=True (core/utils/utils.py:60-69) works to any order.
+# ---------------------------------------------------------------------------
+K3S1P1 = Geom(3, 3, 1, 1)
+K1S1P0 = Geom(1, 1, 1, 0)
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        x = _req(x, "x")
+        y = torch.empty_like(x)
+        check(lib.gz_act_fwd(_p(x), _p(y), x.numel(), act, slope, _stream()), "act_fwd")
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return _ActBwd.apply(g, y, ctx.act, ctx.slope), None, None
+
+
+def activation(x, act=ACT_LRELU, slope=0.2):
+    return _Act.apply(x, act, slope)
+
+
+def _axpby_raw(a, alpha, b, beta, act_out=None, act=ACT_NONE, slope=0.0):
+    out = torch.empty_like(a)
+    check(lib.gz_axpby(_p(a), alpha, _p(b), beta, _p(out), _p(act_out), a.numel(), act, slope, _stream()), "axpby")
+    return out
+
+
+class _Scale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, alpha):
+        ctx.alpha = alpha
+        return _axpby_raw(_req(a, "a"), alpha, None, 0.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Scale.apply(g, ctx.alpha), None
+
+
+class _AddScaled(torch.autograd.Function):
+    """out = a + beta*b (the residual tail, resnet.py:121-122)."""
+
+    @staticmethod
+    def forward(ctx, a, b, beta):
+        ctx.beta = beta
+        return _axpby_raw(_req(a, "a"), 1.0, _req(b, "b"), beta)
+
+    @staticmethod
+    def backward(ctx, g):
+        ga = g if ctx.needs_input_grad[0] else None
+        gb = _Scale.apply(g, ctx.beta) if ctx.needs_input_grad[1] else None
+        return ga, gb, None
+
+
+class _AddScaledAct(torch.autograd.Function):
+    """(out, act(out)) with out = a + beta*b: the residual tail and the next block's pre-activation in one pass."""
+
+    @staticmethod
+    def forward(ctx, a, b, beta, act, slope):
+        a, b = _req(a, "a"), _req(b, "b")
+        act_out = torch.empty_like(a)
+        out = _axpby_raw(a, 1.0, b, beta, act_out, act, slope)
+        ctx.beta, ctx.act, ctx.slope = beta, act, slope
+        ctx.save_for_backward(act_out)
+        return out, act_out
+
+    @staticmethod
+    def backward(ctx, g_out, g_act):
+        (act_out,) = ctx.saved_tensors
+        g = None
+        if g_act is not None:
+            g = _ActBwd.apply(g_act, act_out, ctx.act, ctx.slope)
+        if g_out is not None:
+            g = g_out if g is None else _AddScaled.apply(g_out, g, 1.0)
+        ga = g if ctx.needs_input_grad[0] else None
+        gb = _Scale.apply(g, ctx.beta) if ctx.needs_input_grad[1] else None
+        return ga, gb, None, None, None
+
+
+def scale(a, alpha):
+    return _Scale.apply(a, alpha)
+
+
+def add_scaled(a, b, beta):
+    return _AddScaled.apply(a, b, beta)
+
+
+def add_scaled_act(a, b, beta, act=ACT_LRELU, slope=0.2):
+    return _AddScaledAct.apply(a, b, beta, act, slope)
+
+
+def _planes(x):
+    if x.dim() != 4:
+        raise RuntimeError("lightning_gan_zoo_amd: expected an NCHW tensor, got shape %s" % (tuple(x.shape),))
+    return x.shape[0] * x.shape[1]
+
+
+def _avgpool_fwd_raw(x):
+    N, C, H, W = x.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((N, C, OH, OW), device=x.device, dtype=torch.float32)
+    check(lib.gz_avgpool3s2_fwd(_p(x), _p(y), _planes(x), H, W, OH, OW, _stream()), "avgpool3s2_fwd")
+    return y
+
+
+def _avgpool_bwd_raw(gy, hw):
+    N, C, OH, OW = gy.shape
+    H, W = hw
+    gx = torch.empty((N, C, H, W), device=gy.device, dtype=torch.float32)
+    check(lib.gz_avgpool3s2_bwd(_p(gy), _p(gx), _planes(gy), H, W, OH, OW, _stream()), "avgpool3s2_bwd")
+    return gx
+
+
+class _AvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = tuple(x.shape[2:])
+        return _avgpool_fwd_raw(_req(x, "x"))
+
+    @staticmethod
+    def backward(ctx, g):
+        return _AvgPoolT.apply(g, ctx.hw)
+
+
+class _AvgPoolT(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, hw):
+        return _avgpool_bwd_raw(_req(g, "g"), hw)
+
+    @staticmethod
+    def backward(ctx, v):
+        return _AvgPool.apply(v), None
+
+
+def avg_pool3s2(x):
+    """nn.AvgPool2d(3, stride=2, padding=1) (resnet.py:72)."""
+    return _AvgPool.apply(x)
+
+
+def _upsample_fwd_raw(x):
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    check(lib.gz_upsample2_fwd(_p(x), _p(y), _planes(x), H, W, _stream()), "upsample2_fwd")
+    return y
+
+
+def _upsample_bwd_raw(gy):
+    N, C, H2, W2 = gy.shape
+    gx = torch.empty((N, C, H2 // 2, W2 // 2), device=gy.device, dtype=torch.float32)
+    check(lib.gz_upsample2_bwd(_p(gy), _p(gx), _planes(gy), H2 // 2, W2 // 2, _stream()), "upsample2_bwd")
+    return gx
+
+
+class _Upsample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _upsample_fwd_raw(_req(x, "x"))
+
+    @staticmethod
+    def backward(ctx, g):
+        return _UpsampleT.apply(g)
+
+
+class _UpsampleT(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g):
+        return _upsample_bwd_raw(_req(g, "g"))
+
+    @staticmethod
+    def backward(ctx, v):
+        return _Upsample.apply(v)
+
+
+def upsample2(x):
+    """nn.Upsample(scale_factor=2), nearest (resnet.py:31)."""
+    return _Upsample.apply(x)

@@ -17,6 +17,7 @@ Reference citations (relative to /root/reference):
   DCGAN / WGAN / WGANGP steps .... core/lightning_module.py:104-128,158-207
   configure_optimizers ........... core/lightning_module.py:75-87
   gradient_penalty ............... core/utils/utils.py:39-58
+  GANStabilityR1 + ResNet G/D .... oracle/resnet_cpu.py
 """
 import math
 from collections import OrderedDict
@@ -233,6 +234,14 @@ class WGANGP(_StepBase):
             return loss
 
 
+class GANStabilityR1(_StepBase):
+    """core/lightning_module.py:130-156 (restated in oracle/resnet_cpu.py)"""
+
+    def training_step(self, batch, batch_idx, optimizer_idx):
+        from .resnet_cpu import r1_training_step
+        return r1_training_step(self, batch, batch_idx, optimizer_idx)
+
+
 class HOLOGAN(_StepBase):
     """core/lightning_module.py:209-237 (restated in oracle/hologan_cpu.py)"""
 
@@ -296,7 +305,30 @@ def _wire_hologan():
     utils.hologan.create_hologan_lr_scheduler = staticmethod(H.create_hologan_lr_scheduler)
 
 
+def _wire_resnet():
+    from . import resnet_cpu as R
+
+    class resnet:                  # noqa: N801
+        Generator = R.Generator
+        Discriminator = R.Discriminator
+
+    class _models:                 # noqa: N801
+        pass
+
+    class gan_stability:           # noqa: N801
+        models = _models
+
+    _models.resnet = resnet
+    submodules.gan_stability = gan_stability
+
+
+class submodules:                  # noqa: N801
+    pass
+
+
 _wire_hologan()
+_wire_resnet()
+lightning_module.GANStabilityR1 = GANStabilityR1
 lightning_module.HOLOGAN = HOLOGAN
 models.standard_networks.Generator = Generator
 models.standard_networks.Discriminator = Discriminator

@@ -46,8 +46,7 @@ class _TorchProxy:
 
 def build_reference_step(expt, size):
     ns = ref_import.load_reference()
-    feats, bs, zdim = scenario.sizes(expt, size)
-    cfg = make_cfg(expt, module_root="core", batch_size=bs, features=feats, noise_dim=zdim)
+    cfg = make_cfg(expt, module_root="core", **scenario.cfg_kwargs(expt, size))
     cfg = ref_import.to_attr(cfg)
     if expt == "hologan":
         cfg.generator["gpu"] = False
@@ -58,8 +57,7 @@ def build_reference_step(expt, size):
 
 def build_oracle_step(expt, size):
     from lightning_gan_zoo_amd.config import locate
-    feats, bs, zdim = scenario.sizes(expt, size)
-    cfg = make_cfg(expt, module_root="oracle.reference_cpu", batch_size=bs, features=feats, noise_dim=zdim)
+    cfg = make_cfg(expt, module_root="oracle.reference_cpu", **scenario.cfg_kwargs(expt, size))
     torch.manual_seed(42)
     return locate(cfg.model.lm["_target_"])(cfg, logging_dir=None)
 

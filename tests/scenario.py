@@ -19,13 +19,35 @@ SIZES = {
 }
 STD_EXPTS = ("dc_gan", "wgan", "wgan_gp")
 ALL_EXPTS = STD_EXPTS + ("hologan",)
+R1_EXPT = "gan_stability_r1"      # SURVEY.md 8-f4 ('next' row): ResNet G/D + R1 regulariser
 
 
 def sizes(expt, size):
     feats, bs, zdim = SIZES[size]
     if expt == "hologan" and size == "full":
         return 32, 4, 128        # in_planes 32 (reference default 64), z 128: keeps the CPU runs short
+    if expt == R1_EXPT:
+        return (4, 4, 16) if size == "tiny" else (16, 4, 256)   # full: the shipped nfilter / noise_dim at 128x128
     return feats, bs, zdim
+
+
+def img_size(expt, size):
+    if expt == R1_EXPT:
+        return 32 if size == "tiny" else 128
+    return 64
+
+
+def cfg_kwargs(expt, size):
+    """make_cfg keyword arguments of one scenario size."""
+    feats, bs, zdim = sizes(expt, size)
+    kw = dict(batch_size=bs, features=feats, noise_dim=zdim)
+    if expt == R1_EXPT:
+        kw["img_size"] = img_size(expt, size)
+        # conf/expt/gan_stability_r1.yaml ships reg=10; on these weights / inputs that leaves the R1 term at
+        # 1e-2 (tiny) .. 1e-4 (full) of the parameter gradients.  Chosen so that the regulariser and the BCE
+        # terms contribute comparably and a 1e-3 gradient comparison checks both.
+        kw["loss_weight__reg"] = 300.0 if size == "tiny" else 3.0e4
+    return kw
 
 
 def make_inputs(expt, size, stable=False):
@@ -34,8 +56,8 @@ def make_inputs(expt, size, stable=False):
     uniform = expt == "hologan"
     inp = {}
     for pair in range(2):
-        inp[f"real_d{pair}"] = synthetic_real(bs, seed=100 + pair)
-        inp[f"real_g{pair}"] = synthetic_real(bs, seed=200 + pair)
+        inp[f"real_d{pair}"] = synthetic_real(bs, size=img_size(expt, size), seed=100 + pair)
+        inp[f"real_g{pair}"] = synthetic_real(bs, size=img_size(expt, size), seed=200 + pair)
         if stable:
             for k in (f"real_d{pair}", f"real_g{pair}"):
                 inp[k] = inp[k].abs() * 0.9 + 0.1
@@ -66,6 +88,26 @@ def stabilise(step):
                 p.mul_(0.1)
 
 
+@torch.no_grad()
+def rescale_r1(step):
+    """R1 scenario only: bring every conv / linear weight to std 1/sqrt(fan_in).  With the 0.028-amplitude
+    closed-form fill the ResNet discriminator's input gradient is ~1e-4, the R1 term `reg * |dD/dx|^2` then
+    changes the parameter gradients by < 1e-5 relative and the double backward would go untested."""
+    for net in (step.generator, step.discriminator):
+        for p in net.parameters():
+            if p.ndim >= 2:
+                p.mul_(1.0 / (p[0].numel() ** 0.5 * 0.02 * 2 ** 0.5))
+
+
+def _prepare(step, stable):
+    fill_closed_form(step.generator, 1)
+    fill_closed_form(step.discriminator, 2)
+    if step.cfg["name"] == R1_EXPT:
+        rescale_r1(step)
+    if stable:
+        stabilise(step)
+
+
 def _toggle(step, idx):
     for p in step.discriminator.parameters():
         p.requires_grad_(idx == 0)
@@ -92,10 +134,7 @@ def _buffers(prefix, step, out):
 
 def initial_params(step, full=True, stable=False):
     """The closed-form starting point in the same format as run_scenario's ``final/`` entries."""
-    fill_closed_form(step.generator, 1)
-    fill_closed_form(step.discriminator, 2)
-    if stable:
-        stabilise(step)
+    _prepare(step, stable)
     out = {}
     _dump("final/generator", step.generator.named_parameters(), out, full)
     _dump("final/discriminator", step.discriminator.named_parameters(), out, full)
@@ -115,10 +154,7 @@ def run_scenario(step, inputs, device="cpu", full=True, set_alpha=None, pairs=2,
     (Adam turns rounding-level gradient differences into +-lr parameter differences), but they
     can be compared with the oracle evaluated on the very same parameters."""
     dev = torch.device(device)
-    fill_closed_form(step.generator, 1)
-    fill_closed_form(step.discriminator, 2)
-    if stable:
-        stabilise(step)
+    _prepare(step, stable)
     step.to(dev)
     if dtype != torch.float32:
         step.to(dtype)
@@ -139,7 +175,7 @@ def run_scenario(step, inputs, device="cpu", full=True, set_alpha=None, pairs=2,
 
     for pair in range(pairs):
         for idx, tag in ((0, "d"), (1, "g")):
-            real = inputs[f"real_{tag}{pair}"].to(dev)
+            real = inputs[f"real_{tag}{pair}"].detach().clone().to(dev)   # R1 sets requires_grad on its batch
             step.noise_distn = FixedNoise(inputs[f"z_{tag}{pair}"])
             if set_alpha is not None:
                 set_alpha(step, inputs[f"alpha{pair}"])
@@ -154,7 +190,7 @@ def run_scenario(step, inputs, device="cpu", full=True, set_alpha=None, pairs=2,
                     set_alpha(shadow, inputs[f"alpha{pair}"])
                 _toggle(shadow, idx)
                 np.random.seed(view_seed)
-                sl = shadow.training_step((inputs[f"real_{tag}{pair}"], labels.cpu()), 2 * pair + idx, idx)
+                sl = shadow.training_step((inputs[f"real_{tag}{pair}"].detach().clone(), labels.cpu()), 2 * pair + idx, idx)
                 out[f"shadow_loss_{tag}{pair}"] = np.float64(sl.item())
             np.random.seed(view_seed)
             loss = step.training_step((real, labels), 2 * pair + idx, idx)

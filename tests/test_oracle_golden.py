@@ -15,8 +15,7 @@ ORACLE_ROOT = "oracle.reference_cpu"
 
 
 def build_oracle_step(expt, size):
-    feats, bs, zdim = scenario.sizes(expt, size)
-    cfg = make_cfg(expt, module_root=ORACLE_ROOT, batch_size=bs, features=feats, noise_dim=zdim)
+    cfg = make_cfg(expt, module_root=ORACLE_ROOT, **scenario.cfg_kwargs(expt, size))
     torch.manual_seed(42)
     return locate(cfg.model.lm["_target_"])(cfg, logging_dir=None)
 
@@ -131,7 +130,7 @@ def set_alpha(step, alpha):
 
 
 @pytest.mark.parametrize("size", ["tiny", "full"])
-@pytest.mark.parametrize("expt", scenario.ALL_EXPTS)
+@pytest.mark.parametrize("expt", scenario.ALL_EXPTS + (scenario.R1_EXPT,))
 def test_oracle_matches_reference_fixture(expt, size):
     torch.set_num_threads(4)
     inputs, golden, _ = load_golden(expt, size)
@@ -142,7 +141,10 @@ def test_oracle_matches_reference_fixture(expt, size):
     _, _, cond = load_golden(expt, size)
     noise = {k: v for k, v in cond.items() if v > 1.0}
     compare({k: v for k, v in out.items() if k not in noise}, {k: v for k, v in golden.items() if k not in noise},
-            1e-5, f"oracle {expt}/{size}", atol_scale=scale,
+            # R1: the regulariser's parameter gradients are a second-order quantity whose own fp32-vs-fp64
+            # sensitivity is ~2.5e-5 (cond/ in the fixture); the CPU kernels' summation order depends on the
+            # thread count, which alone moves them by ~1.2e-5
+            5e-5 if expt == scenario.R1_EXPT else 1e-5, f"oracle {expt}/{size}", atol_scale=scale,
             # HoloGAN has parameters whose exact gradient is 0 (conv biases in front of AdaIN): Adam moves
             # them by +-lr on rounding noise
             final_tol=2e-2 if expt == "hologan" else 2e-4)
@@ -169,3 +171,11 @@ def test_oracle_state_dict_names_match_reference_listing():
     assert {"disc.conv_in.weight", "disc.block3.batch_norm.running_var", "disc.conv_out.weight"} <= d
     step = build_oracle_step("wgan_gp", "tiny")
     assert "disc.block2.instance_norm2d.weight" in set(step.discriminator.state_dict())
+    # R1 ResNets (reference core/submodules/gan_stability/models/resnet.py; listing recorded by make_golden.py)
+    step = build_oracle_step(scenario.R1_EXPT, "tiny")
+    g, d = list(step.generator.state_dict()), list(step.discriminator.state_dict())
+    assert g[:2] == ["fc.weight", "fc.bias"] and g[-2:] == ["conv_img.weight", "conv_img.bias"]
+    assert {"resnet.0.conv_0.weight", "resnet.0.conv_s.weight", "resnet.6.conv_1.bias"} <= set(g)
+    assert not any(k.startswith("resnet.1.") for k in g)          # Upsample holds no state
+    assert d[:2] == ["conv_img.weight", "conv_img.bias"] and d[-2:] == ["fc.weight", "fc.bias"]
+    assert {"resnet.0.conv_0.bias", "resnet.2.conv_s.weight", "resnet.6.conv_1.weight"} <= set(d)

@@ -16,13 +16,12 @@ TOL = 1e-3
 
 
 def build_product_step(expt, size):
-    feats, bs, zdim = scenario.sizes(expt, size)
-    cfg = make_cfg(expt, batch_size=bs, features=feats, noise_dim=zdim)
+    cfg = make_cfg(expt, **scenario.cfg_kwargs(expt, size))
     torch.manual_seed(42)
     return locate(cfg.model.lm["_target_"])(cfg, logging_dir=None)
 
 
-LR = {"dc_gan": 2e-4, "wgan": 5e-5, "wgan_gp": 1e-4, "hologan": 1e-4}
+LR = {"dc_gan": 2e-4, "wgan": 5e-5, "wgan_gp": 1e-4, "hologan": 1e-4, "gan_stability_r1": 1e-4}
 
 
 @pytest.mark.parametrize("size", ["tiny", "full"])
@@ -51,6 +50,29 @@ def test_product_matches_reference_fixture(expt, size):
     # HoloGAN: conv biases in front of AdaIN have an exactly-zero gradient and the second-pair gradients
     # inherit the first pair's +-lr noise through AdaIN's 1/sigma, so fewer entries agree
     assert frac >= (0.6 if expt == "hologan" else 0.9) and n > 100
+
+
+@pytest.mark.parametrize("size", ["tiny", "full"])
+def test_r1_resnet_path_matches_reference_fixture(size):
+    """GANStabilityR1.training_step on the ResNet G/D (full = the shipped nfilter 16 at
+    128x128) against the fixture generated from the unmodified reference.  No ReLU here (LeakyReLU masks only,
+    cond <= 3e-5 in the fixture), so gradients are held to the plain 1e-3 bar."""
+    expt = scenario.R1_EXPT
+    inputs, golden, cond = load_golden(expt, size)
+    step = build_product_step(expt, size)
+    full = size == "tiny"
+    out = scenario.run_scenario(step, inputs, "cuda", full=full, shadow=build_oracle_step(expt, size))
+    scale = float(np.abs(golden["probe/logits"]).max())
+    worst = compare(out, golden, TOL, f"hip {expt}/{size}", atol_scale=scale, cond=cond,
+                    final_abs=2 * 2 * 10 * LR[expt], grad_floor=TOL)   # RMSprop's first steps are ~10 lr
+    print(f"{expt}/{size}: worst {worst[3]} err {worst[1]:.2e} (bar {worst[2]:.2e})")
+    for tag in ("d", "g"):
+        got, ref = out[f"loss_{tag}1"], out[f"shadow_loss_{tag}1"]
+        assert abs(got - ref) <= TOL * max(abs(ref), scale), (tag, got, ref)
+    frac, n = update_agreement(out, golden, scenario.initial_params(build_oracle_step(expt, size), full),
+                               LR[expt])
+    print(f"{expt}/{size}: {frac:.3f} of {n} parameter updates agree")
+    assert frac >= 0.9 and n > 100
 
 
 @pytest.mark.parametrize("expt", ["dc_gan", "wgan_gp"])
