@@ -28,8 +28,12 @@ FLOP_PER_SAMPLE_CYCLE = {
     "wgan": 5 * 2_054_389_760 + 2_875_490_304,
     "wgan_gp": 6_175_700_000,             # D step 3.3002 G (3 D fwd + GP double backward) + G step 2.8755 G
     "hologan": 29_060_000_000,            # D + G + G at 64x64: 5.6244 G + 2 x 11.7195 G
+    # SURVEY 8-f4, conf/expt/gan_stability_r1.yaml (ResNet nfilter 16, 128x128): D step 4,682,563,584 (3 D fwd-size
+    # passes + the R1 double backward) + G step 2,354,610,176, traced on the oracle as PyTorch autograd executes it
+    "gan_stability_r1": 7_037_173_760,
 }
-DEFAULT_BATCH = {"dc_gan": 512, "wgan": 512, "wgan_gp": 256, "hologan": 64}
+NATIVE_IMG_SIZE = {"gan_stability_r1": 128}
+DEFAULT_BATCH = {"dc_gan": 512, "wgan": 512, "wgan_gp": 256, "hologan": 64, "gan_stability_r1": 64}
 PEAK_FP32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
 
 
@@ -136,7 +140,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None,
                     help="per-GPU batch (default: BASELINE configs: dc_gan 512, wgan_gp 256, hologan 64)")
     ap.add_argument("--expt", default="dc_gan")
-    ap.add_argument("--img-size", type=int, default=64, help="128 only with --expt hologan (EXT-128, not parity-pinned)")
+    ap.add_argument("--img-size", type=int, default=None,
+                    help="default 64 (128 for gan_stability_r1); 128 with --expt hologan is EXT-128, not parity-pinned")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bs128", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -145,6 +150,8 @@ def main():
     args = ap.parse_args()
     if args.batch is None:
         args.batch = DEFAULT_BATCH.get(args.expt, 128)
+    if args.img_size is None:
+        args.img_size = NATIVE_IMG_SIZE.get(args.expt, 64)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,11 +189,11 @@ def main():
     per_cycle = len(trainer.order)            # batches per optimizer cycle: 2 (dc_gan, wgan_gp), 6 (wgan), 3 (hologan)
     value = per_cycle * args.batch * world * args.steps / dt
     flop_cycle = FLOP_PER_SAMPLE_CYCLE[args.expt] * args.batch
-    if args.img_size != 64:
+    if args.img_size != NATIVE_IMG_SIZE.get(args.expt, 64):
         flop_cycle = float("nan")      # the reference cannot run this size; no traced FLOP count exists
 
     out = {
-        "metric": "images/sec (G+D step) at 64x64",
+        "metric": "images/sec (G+D step) at %dx%d" % (args.img_size, args.img_size),
         "value": round(value, 1),
         "unit": "images/s",
         "n_gpus": world,

@@ -52,14 +52,23 @@ int gz_conv2d_pack_dgrad(const float* w, float* wpack, int K, int C, int KH, int
 
 /* y = act(conv2d(x, w) + bias).  Replaces aten::convolution for nn.Conv2d forward
  * (standard_networks.py:20-24,36-43) and the input gradient of nn.ConvTranspose2d. */
-int gz_conv2d_fwd(const float* x, const float* wpack, const float* bias, float* y, int N, int C, int H, int W,
-                  int K, int OH, int OW, int KH, int KW, int S, int P, int act, float slope, hipStream_t stream);
+int gz_conv2d_fwd(const float* x, const float* wpack, const float* bias, float* y, float* workspace, size_t ws_bytes,
+                  int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, int act,
+                  float slope, hipStream_t stream);
+/* Split-K scratch of gz_conv2d_fwd / gz_conv2d_dgrad / gz_gemm: launches whose output has too few tiles to fill
+ * the 256 CUs (deep 4x4 / 8x8 maps at small batch, nn.Linear heads with K = 8192) cut the reduction instead and
+ * sum the partial tiles in a second pass.  0 = not split.  A NULL / too small workspace is not an error: the
+ * launch then runs unsplit. */
+size_t gz_conv2d_fwd_workspace_bytes(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P);
+size_t gz_conv2d_dgrad_workspace_bytes(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S,
+                                       int P);
+size_t gz_gemm_workspace_bytes(int M, int N, int K);
 
 /* x = act(conv_transpose2d(y, w) + bias).  Replaces nn.ConvTranspose2d forward
  * (standard_networks.py:60-73,80-87) and aten::convolution_backward's grad_input for nn.Conv2d. */
-int gz_conv2d_dgrad(const float* y, const float* wpack, const float* bias, float* x, int N, int C, int H, int W,
-                    int K, int OH, int OW, int KH, int KW, int S, int P, int act, float slope,
-                    hipStream_t stream);
+int gz_conv2d_dgrad(const float* y, const float* wpack, const float* bias, float* x, float* workspace,
+                    size_t ws_bytes, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P,
+                    int act, float slope, hipStream_t stream);
 
 /* dw[K,C,KH,KW] = weight gradient.  Replaces aten::convolution_backward's grad_weight. */
 size_t gz_conv2d_wgrad_workspace_bytes(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW);
@@ -72,8 +81,9 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
 /* c[M,N] = act(op(a) . op(b) + bias[n]); trans_a: a stored [K][M]; trans_b: b stored [N][K].
  * Replaces the 1x1 -> 4x4 ConvTranspose2d of the generator's first block (standard_networks.py:60),
  * its weight gradient, and nn.Linear. */
-int gz_gemm(const float* a, const float* b, const float* bias, float* c, int M, int N, int K, int lda, int ldb,
-            int ldc, int trans_a, int trans_b, int act, float slope, hipStream_t stream);
+int gz_gemm(const float* a, const float* b, const float* bias, float* c, float* workspace, size_t ws_bytes, int M,
+            int N, int K, int lda, int ldb, int ldc, int trans_a, int trans_b, int act, float slope,
+            hipStream_t stream);
 
 /* ---- cubic 3-D convolution family (HoloGAN ConvTranspose3d k3 s2 p1 op1, hologan_generator.py:29-30) ------
  * x [N,C,D,H,W] image side, y [N,K,OD,OH,OW] feature side, w [K,C,KS,KS,KS]; only (KS,S,P) = (3,2,1). */

@@ -59,6 +59,43 @@ static TileId pick_tile(long long M, long long N, int ny) {
     return T64x64;
 }
 
+// Split-K for F / Dg / GEMM launches whose output has too few tiles to fill 256 CUs (deep 4x4 / 8x8 feature
+// maps at small batch, the nn.Linear heads: M = batch rows, K = 8192).  Such a launch runs one workgroup per
+// CU or less and is bound by the per-chunk load -> LDS -> barrier latency, which only other resident workgroups
+// can hide.  Keep the tile pick_tile chose and cut the reduction so that ~1024 workgroups are in flight, each
+// with >= 8 chunks (128 reduction steps); the raw partial tiles go to workspace slabs, splitk_finish_kernel
+// sums them in a fixed order and applies the epilogue.
+struct SplitPlan {
+    TileId tile;
+    int splits;
+};
+
+static long long tile_count(TileId t, long long M, long long N, int ny) {
+    const int bm = t == T64x64 ? 64 : 128;
+    const int bn = t == T128x128 ? 128 : (t == T128x32 ? 32 : 64);
+    return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * ny;
+}
+
+static SplitPlan plan_split(long long M, long long N, int Kdim, int ny, TileId normal) {
+    SplitPlan none{normal, 1};
+    static int off = getenv("GZ_NO_SPLITK") ? 1 : 0;
+    static int target = getenv("GZ_SPLIT_TARGET") ? atoi(getenv("GZ_SPLIT_TARGET")) : 1024;
+    static int below = getenv("GZ_SPLIT_BELOW") ? atoi(getenv("GZ_SPLIT_BELOW")) : 512;
+    if (off) return none;
+    const int chunks = (Kdim + BK - 1) / BK;
+    const long long tiles = tile_count(normal, M, N, ny);
+    if (chunks < 16 || tiles >= below) return none;
+    long long want = (target + tiles - 1) / tiles, cap = chunks / 8;
+    int splits = (int)(want < cap ? want : cap);
+    if (splits < 2) return none;
+    return SplitPlan{normal, splits};
+}
+
+static size_t split_bytes(const SplitPlan& sp, long long M, long long N, int Kdim, int ny) {
+    if (sp.splits <= 1) return 0;
+    return (size_t)split_nz(Kdim, sp.splits) * ny * M * N * 4;
+}
+
 // ---------------------------------------------------------------------------
 // weight packing
 // ---------------------------------------------------------------------------
@@ -100,14 +137,45 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict
     }
 }
 
-// out[i] = sum_s slab[s][i]
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out,
-                                                           int S, long long count) {
+// out[i] = sum_s slab[s][i].  Small weight tensors reach here with hundreds of slabs (split-K over a 1M-long
+// reduction), so the slabs are spread over the 16 wavefronts of a workgroup (64 outputs per workgroup, fixed
+// summation order) instead of being walked by one thread.
+__global__ __launch_bounds__(256) void reduce_few_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                               int S, long long count) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     float acc = 0.f;
     for (int s = 0; s < S; ++s) acc += slab[(long long)s * count + i];
     out[i] = acc;
+}
+
+constexpr int RS_WAVES = 16;
+__global__ __launch_bounds__(64 * RS_WAVES) void reduce_slabs_kernel(const float* __restrict__ slab,
+                                                                     float* __restrict__ out, int S,
+                                                                     long long count) {
+    __shared__ float part[RS_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + lane;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < count) {
+        const float* p = slab + i;
+        int s = wave;
+        for (; s + 3 * RS_WAVES < S; s += 4 * RS_WAVES) {
+            a0 += p[(long long)s * count];
+            a1 += p[(long long)(s + RS_WAVES) * count];
+            a2 += p[(long long)(s + 2 * RS_WAVES) * count];
+            a3 += p[(long long)(s + 3 * RS_WAVES) * count];
+        }
+        for (; s < S; s += RS_WAVES) a0 += p[(long long)s * count];
+    }
+    part[wave][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wave == 0 && i < count) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) acc += part[w][lane];
+        out[i] = acc;
+    }
 }
 
 static inline int round4(int v) { return (v + 3) & ~3; }
@@ -130,7 +198,7 @@ static bool too_large(long long elems) { return elems * 4 >= (1ll << 31); }
 // ---------------------------------------------------------------------------
 template <class G, class Cfg>
 static int run_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvShape& s, int act,
-                   float slope, hipStream_t st) {
+                   float slope, hipStream_t st, int splits = 1, float* slab = nullptr) {
 #ifndef GZ_NO_K4V
     using AL = std::conditional_t<G::kh == 4 && G::kw == 4, ConvFwdALoaderK4V<Cfg::BM, G::s, G::p>,
                                   ConvFwdALoader<Cfg::BM, G::kh, G::kw, G::s, G::p>>;
@@ -143,18 +211,32 @@ static int run_fwd(const float* x, const float* wp, const float* bias, float* y,
     typename BL::Params pb{wp, Kg, round4(s.K), round4(s.K), 0};
     int M = s.N * s.OH * s.OW;
     EpiNCHW::Params pe{y, M, s.K, s.OH * s.OW, make_fastdiv(s.OH * s.OW), bias, act, slope};
-    return launch_igemm<Cfg, AL, BL, EpiNCHW>(pa, pb, pe, M, s.K, Kg, 1, 1, st);
+    return launch_igemm<Cfg, AL, BL, EpiNCHW>(pa, pb, pe, M, s.K, Kg, 1, splits, st, slab);
+}
+
+template <class G>
+static SplitPlan fwd_plan(const ConvShape& s) {
+    long long M = (long long)s.N * s.OH * s.OW;
+    return plan_split(M, s.K, s.C * G::kh * G::kw, 1, pick_tile(M, s.K, 1));
+}
+
+template <class G>
+static size_t fwd_ws_bytes(const ConvShape& s) {
+    return split_bytes(fwd_plan<G>(s), (long long)s.N * s.OH * s.OW, s.K, s.C * G::kh * G::kw, 1);
 }
 
 template <class G>
 static int dispatch_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvShape& s,
-                        int act, float slope, hipStream_t st) {
+                        int act, float slope, float* ws, size_t ws_bytes, hipStream_t st) {
     long long M = (long long)s.N * s.OH * s.OW;
-    switch (pick_tile(M, s.K, 1)) {
-        case T128x128: return run_fwd<G, Cfg128x128>(x, wp, bias, y, s, act, slope, st);
-        case T128x64: return run_fwd<G, Cfg128x64>(x, wp, bias, y, s, act, slope, st);
-        case T128x32: return run_fwd<G, Cfg128x32>(x, wp, bias, y, s, act, slope, st);
-        default: return run_fwd<G, Cfg64x64>(x, wp, bias, y, s, act, slope, st);
+    SplitPlan sp = fwd_plan<G>(s);
+    if (sp.splits > 1 && (!ws || ws_bytes < fwd_ws_bytes<G>(s))) sp = SplitPlan{pick_tile(M, s.K, 1), 1};
+    float* slab = sp.splits > 1 ? ws : nullptr;
+    switch (sp.tile) {
+        case T128x128: return run_fwd<G, Cfg128x128>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
+        case T128x64: return run_fwd<G, Cfg128x64>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
+        case T128x32: return run_fwd<G, Cfg128x32>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
+        default: return run_fwd<G, Cfg64x64>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
     }
 }
 
@@ -253,7 +335,7 @@ static int run_dgrad_smallc(const float* y, const float* wp, const float* bias, 
 // ---------------------------------------------------------------------------
 template <class G, class Cfg>
 static int run_dgrad(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s, int act,
-                     float slope, hipStream_t st) {
+                     float slope, hipStream_t st, int splits = 1, float* slab = nullptr) {
     using AL = ConvDgALoader<Cfg::BM, G::kh, G::kw, G::s, G::p>;
     using BL = MContigLoader4<Cfg::BN>;
     using Epi = EpiPhase<G::s>;
@@ -264,15 +346,34 @@ static int run_dgrad(const float* y, const float* wp, const float* bias, float* 
     typename BL::Params pb{wp, Kg, ldc, ldc, (long long)Kg * ldc};
     int M = s.N * AH * AW;
     typename Epi::Params pe{x, M, s.C, s.H, s.W, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW), bias, act, slope};
-    return launch_igemm<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kg, G::s * G::s, 1, st);
+    return launch_igemm<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kg, G::s * G::s, splits, st, slab);
+}
+
+template <class G>
+static bool dgrad_direct(const float* x, const ConvShape& s) {
+    return G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1 && s.C <= 4 && s.H == 2 * s.OH && s.W == 2 * s.OW &&
+           (((uintptr_t)x & 7) == 0) && !getenv("GZ_NO_SMALLC");
+}
+
+template <class G>
+static SplitPlan dgrad_plan(const ConvShape& s) {
+    constexpr int TAPS = ((G::kh + G::s - 1) / G::s) * ((G::kw + G::s - 1) / G::s);
+    long long M = (long long)s.N * (s.H / G::s) * (s.W / G::s);
+    return plan_split(M, s.C, s.K * TAPS, G::s * G::s, pick_tile(M, s.C, G::s * G::s));
+}
+
+template <class G>
+static size_t dgrad_ws_bytes(const ConvShape& s) {
+    constexpr int TAPS = ((G::kh + G::s - 1) / G::s) * ((G::kw + G::s - 1) / G::s);
+    if (s.H % G::s || s.W % G::s || dgrad_direct<G>(nullptr, s)) return 0;
+    return split_bytes(dgrad_plan<G>(s), (long long)s.N * (s.H / G::s) * (s.W / G::s), s.C, s.K * TAPS, G::s * G::s);
 }
 
 template <class G>
 static int dispatch_dgrad(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s,
-                          int act, float slope, hipStream_t st) {
+                          int act, float slope, float* ws, size_t ws_bytes, hipStream_t st) {
     if (s.H % G::s || s.W % G::s) return GZ_ERR_UNSUPPORTED;
-    if (G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1 && s.C <= 4 && s.H == 2 * s.OH && s.W == 2 * s.OW &&
-        (((uintptr_t)x & 7) == 0) && !getenv("GZ_NO_SMALLC")) {
+    if (dgrad_direct<G>(x, s)) {
         switch (s.C) {
             case 1: return run_dgrad_smallc<1>(y, wp, bias, x, s, act, slope, st);
             case 2: return run_dgrad_smallc<2>(y, wp, bias, x, s, act, slope, st);
@@ -281,11 +382,14 @@ static int dispatch_dgrad(const float* y, const float* wp, const float* bias, fl
         }
     }
     long long M = (long long)s.N * (s.H / G::s) * (s.W / G::s);
-    switch (pick_tile(M, s.C, G::s * G::s)) {
-        case T128x128: return run_dgrad<G, Cfg128x128>(y, wp, bias, x, s, act, slope, st);
-        case T128x64: return run_dgrad<G, Cfg128x64>(y, wp, bias, x, s, act, slope, st);
-        case T128x32: return run_dgrad<G, Cfg128x32>(y, wp, bias, x, s, act, slope, st);
-        default: return run_dgrad<G, Cfg64x64>(y, wp, bias, x, s, act, slope, st);
+    SplitPlan sp = dgrad_plan<G>(s);
+    if (sp.splits > 1 && (!ws || ws_bytes < dgrad_ws_bytes<G>(s))) sp = SplitPlan{pick_tile(M, s.C, G::s * G::s), 1};
+    float* slab = sp.splits > 1 ? ws : nullptr;
+    switch (sp.tile) {
+        case T128x128: return run_dgrad<G, Cfg128x128>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
+        case T128x64: return run_dgrad<G, Cfg128x64>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
+        case T128x32: return run_dgrad<G, Cfg128x32>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
+        default: return run_dgrad<G, Cfg64x64>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
     }
 }
 
@@ -350,8 +454,12 @@ static int launch_wgrad(const typename AL::Params& pa, const typename BL::Params
     int rc = launch_igemm<Cfg, AL, BL, EpiRowMajor>(pa, pb, pe, s.K, NTOT, KTOT, 1, splits, st);
     if (rc != GZ_OK) return rc;
     if (nz > 1) {
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws, dw, nz,
-                           count);
+        if (nz <= 8)
+            hipLaunchKernelGGL(reduce_few_slabs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws, dw,
+                               nz, count);
+        else
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64 * RS_WAVES), 0, st, ws,
+                               dw, nz, count);
         rc = launch_status();
     }
     return rc;
@@ -397,29 +505,29 @@ static int dispatch_wgrad(const float* x, const float* y, float* dw, float* ws, 
 // ---------------------------------------------------------------------------
 template <class Cfg, class AL, class BL>
 static int run_gemm(const float* a, const float* b, const float* bias, float* c, int M, int N, int K, int lda,
-                    int ldb, int ldc, int act, float slope, hipStream_t st) {
+                    int ldb, int ldc, int act, float slope, hipStream_t st, int splits, float* slab) {
     typename AL::Params pa{a, K, M, lda, 0};
     typename BL::Params pb{b, K, N, ldb, 0};
     EpiRowMajor::Params pe{c, M, N, ldc, 0, bias, act, slope};
-    return launch_igemm<Cfg, AL, BL, EpiRowMajor>(pa, pb, pe, M, N, K, 1, 1, st);
+    return launch_igemm<Cfg, AL, BL, EpiRowMajor>(pa, pb, pe, M, N, K, 1, splits, st, slab);
 }
 
 template <class Cfg>
 static int gemm_ops(const float* a, const float* b, const float* bias, float* c, int M, int N, int K, int lda,
-                    int ldb, int ldc, int ta, int tb, int act, float slope, hipStream_t st) {
+                    int ldb, int ldc, int ta, int tb, int act, float slope, hipStream_t st, int splits, float* slab) {
     // ta == 0: A is [M][K] row-major (k contiguous);  ta == 1: A is stored [K][M] (m contiguous)
     // tb == 0: B is [K][N] row-major (n contiguous);  tb == 1: B is stored [N][K] (k contiguous)
     const bool b_vec = !tb && (ldb % 4 == 0) && (N % 4 == 0) && (((uintptr_t)b & 15) == 0);
     if (!ta && !tb) {
-        if (b_vec) return run_gemm<Cfg, KContigLoader<Cfg::BM>, MContigLoader4<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st);
-        return run_gemm<Cfg, KContigLoader<Cfg::BM>, MContigLoader<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st);
+        if (b_vec) return run_gemm<Cfg, KContigLoader<Cfg::BM>, MContigLoader4<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st, splits, slab);
+        return run_gemm<Cfg, KContigLoader<Cfg::BM>, MContigLoader<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st, splits, slab);
     }
     if (ta && !tb) {
-        if (b_vec) return run_gemm<Cfg, MContigLoader<Cfg::BM>, MContigLoader4<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st);
-        return run_gemm<Cfg, MContigLoader<Cfg::BM>, MContigLoader<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st);
+        if (b_vec) return run_gemm<Cfg, MContigLoader<Cfg::BM>, MContigLoader4<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st, splits, slab);
+        return run_gemm<Cfg, MContigLoader<Cfg::BM>, MContigLoader<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st, splits, slab);
     }
-    if (!ta && tb) return run_gemm<Cfg, KContigLoader<Cfg::BM>, KContigLoader<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st);
-    return run_gemm<Cfg, MContigLoader<Cfg::BM>, KContigLoader<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st);
+    if (!ta && tb) return run_gemm<Cfg, KContigLoader<Cfg::BM>, KContigLoader<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st, splits, slab);
+    return run_gemm<Cfg, MContigLoader<Cfg::BM>, KContigLoader<Cfg::BN>>(a, b, bias, c, M, N, K, lda, ldb, ldc, act, slope, st, splits, slab);
 }
 
 }  // namespace gz
@@ -431,12 +539,13 @@ typedef Geo<5, 5, 2, 2> G5522;
 typedef Geo<3, 3, 1, 1> G3311;
 typedef Geo<1, 1, 1, 0> G1110;
 
-#define GZ_GEOM_DISPATCH(CALL)                                          \
+#define GZ_GEOM_DISPATCH_OR(CALL, ELSE)                                 \
     if (KH == 4 && KW == 4 && S == 2 && P == 1) return CALL(G4421);     \
     if (KH == 5 && KW == 5 && S == 2 && P == 2) return CALL(G5522);     \
     if (KH == 3 && KW == 3 && S == 1 && P == 1) return CALL(G3311);     \
     if (KH == 1 && KW == 1 && S == 1 && P == 0) return CALL(G1110);     \
-    return GZ_ERR_UNSUPPORTED;
+    return ELSE;
+#define GZ_GEOM_DISPATCH(CALL) GZ_GEOM_DISPATCH_OR(CALL, GZ_ERR_UNSUPPORTED)
 
 extern "C" {
 
@@ -466,27 +575,45 @@ int gz_conv2d_pack_dgrad(const float* w, float* wp, int K, int C, int KH, int KW
     return launch_status();
 }
 
-int gz_conv2d_fwd(const float* x, const float* wpack, const float* bias, float* y, int N, int C, int H, int W,
-                  int K, int OH, int OW, int KH, int KW, int S, int P, int act, float slope, hipStream_t stream) {
+size_t gz_conv2d_fwd_workspace_bytes(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P) {
+    ConvShape s{N, C, H, W, K, OH, OW};
+    if (!shape_ok(s, KH, KW, S, P)) return 0;
+#define CALL(G) fwd_ws_bytes<G>(s)
+    GZ_GEOM_DISPATCH_OR(CALL, 0)
+#undef CALL
+}
+
+size_t gz_conv2d_dgrad_workspace_bytes(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S,
+                                       int P) {
+    ConvShape s{N, C, H, W, K, OH, OW};
+    if (!shape_ok(s, KH, KW, S, P)) return 0;
+#define CALL(G) dgrad_ws_bytes<G>(s)
+    GZ_GEOM_DISPATCH_OR(CALL, 0)
+#undef CALL
+}
+
+int gz_conv2d_fwd(const float* x, const float* wpack, const float* bias, float* y, float* workspace, size_t ws_bytes,
+                  int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, int act,
+                  float slope, hipStream_t stream) {
     gz::clear_stale_error();
     ConvShape s{N, C, H, W, K, OH, OW};
     if (!shape_ok(s, KH, KW, S, P)) return GZ_ERR_BAD_SHAPE;
     if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
     if (((uintptr_t)wpack & 15) || ((uintptr_t)y & 15)) return GZ_ERR_BAD_SHAPE;
-#define CALL(G) dispatch_fwd<G>(x, wpack, bias, y, s, act, slope, stream)
+#define CALL(G) dispatch_fwd<G>(x, wpack, bias, y, s, act, slope, workspace, ws_bytes, stream)
     GZ_GEOM_DISPATCH(CALL)
 #undef CALL
 }
 
-int gz_conv2d_dgrad(const float* y, const float* wpack, const float* bias, float* x, int N, int C, int H, int W,
-                    int K, int OH, int OW, int KH, int KW, int S, int P, int act, float slope,
-                    hipStream_t stream) {
+int gz_conv2d_dgrad(const float* y, const float* wpack, const float* bias, float* x, float* workspace,
+                    size_t ws_bytes, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P,
+                    int act, float slope, hipStream_t stream) {
     gz::clear_stale_error();
     ConvShape s{N, C, H, W, K, OH, OW};
     if (!shape_ok(s, KH, KW, S, P)) return GZ_ERR_BAD_SHAPE;
     if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
     if ((uintptr_t)wpack & 15) return GZ_ERR_BAD_SHAPE;
-#define CALL(G) dispatch_dgrad<G>(y, wpack, bias, x, s, act, slope, stream)
+#define CALL(G) dispatch_dgrad<G>(y, wpack, bias, x, s, act, slope, workspace, ws_bytes, stream)
     GZ_GEOM_DISPATCH(CALL)
 #undef CALL
 }
@@ -530,16 +657,25 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
     return t;
 }
 
-int gz_gemm(const float* a, const float* b, const float* bias, float* c, int M, int N, int K, int lda, int ldb,
-            int ldc, int trans_a, int trans_b, int act, float slope, hipStream_t stream) {
+size_t gz_gemm_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return split_bytes(plan_split(M, N, K, 1, pick_tile(M, N, 1)), M, N, K, 1);
+}
+
+int gz_gemm(const float* a, const float* b, const float* bias, float* c, float* workspace, size_t ws_bytes, int M,
+            int N, int K, int lda, int ldb, int ldc, int trans_a, int trans_b, int act, float slope,
+            hipStream_t stream) {
     gz::clear_stale_error();
     if (M <= 0 || N <= 0 || K <= 0) return GZ_ERR_BAD_SHAPE;
     if (too_large((long long)M * K) || too_large((long long)K * N) || too_large((long long)M * N)) return GZ_ERR_TOO_LARGE;
-    switch (pick_tile(M, N, 1)) {
-        case T128x128: return gemm_ops<Cfg128x128>(a, b, bias, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, slope, stream);
-        case T128x64: return gemm_ops<Cfg128x64>(a, b, bias, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, slope, stream);
-        case T128x32: return gemm_ops<Cfg128x32>(a, b, bias, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, slope, stream);
-        default: return gemm_ops<Cfg64x64>(a, b, bias, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, slope, stream);
+    SplitPlan sp = plan_split(M, N, K, 1, pick_tile(M, N, 1));
+    if (sp.splits > 1 && (!workspace || ws_bytes < split_bytes(sp, M, N, K, 1))) sp = SplitPlan{pick_tile(M, N, 1), 1};
+    float* slab = sp.splits > 1 ? workspace : nullptr;
+    switch (sp.tile) {
+        case T128x128: return gemm_ops<Cfg128x128>(a, b, bias, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, slope, stream, sp.splits, slab);
+        case T128x64: return gemm_ops<Cfg128x64>(a, b, bias, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, slope, stream, sp.splits, slab);
+        case T128x32: return gemm_ops<Cfg128x32>(a, b, bias, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, slope, stream, sp.splits, slab);
+        default: return gemm_ops<Cfg64x64>(a, b, bias, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, act, slope, stream, sp.splits, slab);
     }
 }
 

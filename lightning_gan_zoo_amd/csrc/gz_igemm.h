@@ -1148,7 +1148,32 @@ struct GridMap {
     int tiles_m, tiles_n, ny;  // grid.x = tiles_m * tiles_n * ny (ny = dgrad phases / batches, fastest)
     int chunks;                // total K chunks
     int chunks_per_split;      // grid.z = ceil(chunks / chunks_per_split)
+    // split-K of an op with a structured epilogue (F / Dg / GEMM with few output tiles): every (y, z)
+    // workgroup writes its raw accumulators to slab[y * gridDim.z + z][slab_m][slab_n] (row-major) and
+    // splitk_finish_kernel<Epi> sums the slabs and applies the real epilogue.  Null: Epi::store directly.
+    float* slab;
+    int slab_m, slab_n;
 };
+
+template <int TM, int TN>
+__device__ __forceinline__ void store_slab(const GridMap& gm, f32x16 (&acc)[TM][TN], int m_base, int n_base, int lane,
+                                           int slab_idx) {
+    float* c = gm.slab + (long long)slab_idx * gm.slab_m * gm.slab_n;
+    const int col_l = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int n = n_base + j * 32 + col_l;
+        if (n >= gm.slab_n) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < gm.slab_m) c[(long long)m * gm.slab_n + n] = acc[i][j][r];
+            }
+        }
+    }
+}
 
 #ifndef GZ_IGEMM_INTERLEAVE
 #define GZ_IGEMM_INTERLEAVE 0
@@ -1291,15 +1316,71 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
 #ifdef GZ_EXP_NOSTORE   // timing experiment: keep one store so the accumulators stay live
     if (acc[0][0][0] == 123456.789f)
 #endif
-    Epi::template store<TM, TN>(pe, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32,
-                                lane, y, z);
+    if (gm.slab)
+        store_slab<TM, TN>(gm, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32, lane,
+                           y * (int)gridDim.z + z);
+    else
+        Epi::template store<TM, TN>(pe, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32,
+                                    lane, y, z);
 }
 
+// Second pass of a split-K launch: a workgroup owns one 32x32 output block; its four wavefronts each sum every
+// fourth slab into the accumulator image Epi::store expects (the MFMA C/D layout), the partial images meet in
+// LDS in a fixed order, and wavefront 0 runs the op's own epilogue (bias, activation, NCHW / phase scatter).
+template <class Epi>
+__global__ __launch_bounds__(NT) void splitk_finish_kernel(const float* __restrict__ slab, int nz, int M, int N,
+                                                           typename Epi::Params pe, int tiles_n, int ny) {
+    __shared__ float part[3][16][64];
+    int bid = blockIdx.x;
+    const int y = bid % ny;
+    bid /= ny;
+    const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m_base = tile_m * 32, n_base = tile_n * 32;
+    const int col = n_base + (lane & 31), half = lane >> 5;
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    if (col < N) {
+        for (int z = wave; z < nz; z += 4) {
+            const float* c = slab + (long long)(y * nz + z) * M * N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < M) acc[0][0][r] += c[(long long)m * N + col];
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[wave - 1][r][lane] = acc[0][0][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += (part[0][r][lane] + part[1][r][lane]) + part[2][r][lane];
+        Epi::template store<1, 1>(pe, acc, m_base, n_base, lane, y, 0);
+    }
+}
+
+inline int split_nz(int K, int splits) {
+    int chunks = (K + BK - 1) / BK;
+    if (splits < 1) splits = 1;
+    int per = (chunks + splits - 1) / splits;
+    int nz = (chunks + per - 1) / per;
+    return nz < 1 ? 1 : nz;
+}
+
+// `slab` != null: split-K through raw-accumulator slabs + splitk_finish_kernel<Epi> (needs
+// ny * split_nz(K, splits) * M * N floats); null with splits > 1: the epilogue itself is slab-aware (Wg).
 template <class Cfg, class AL, class BL, class Epi>
 inline int launch_igemm(const typename AL::Params& pa, const typename BL::Params& pb,
                         const typename Epi::Params& pe, int M, int N, int K, int ny, int splits,
-                        hipStream_t stream) {
+                        hipStream_t stream, float* slab = nullptr) {
     GridMap gm;
+    gm.slab = nullptr;
+    gm.slab_m = M;
+    gm.slab_n = N;
     gm.tiles_m = (M + Cfg::BM - 1) / Cfg::BM;
     gm.tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
     gm.chunks = (K + BK - 1) / BK;
@@ -1309,7 +1390,13 @@ inline int launch_igemm(const typename AL::Params& pa, const typename BL::Params
     if (nz < 1) nz = 1;
     gm.ny = ny;
     dim3 grid(gm.tiles_m * gm.tiles_n * ny, 1, nz);
+    if (slab && nz > 1) gm.slab = slab;
     hipLaunchKernelGGL((igemm_kernel<Cfg, AL, BL, Epi>), grid, dim3(NT), 0, stream, pa, pb, pe, gm);
+    if (gm.slab) {
+        const int fm = (M + 31) / 32, fn = (N + 31) / 32;
+        hipLaunchKernelGGL((splitk_finish_kernel<Epi>), dim3(fm * fn * ny), dim3(NT), 0, stream, slab, nz, M, N, pe, fn,
+                           ny);
+    }
     return launch_status();
 }
 

@@ -51,8 +51,9 @@ def out_size(n, g):
 # on, around each implicit-GEMM launch.  Off by default; costs nothing when off.
 # ---------------------------------------------------------------------------
 class KernelTimer:
-    def __init__(self):
+    def __init__(self, detail=False):
         self.records = []      # (label, flops, start_event, end_event)
+        self.detail = detail   # per-shape labels, and the 3-D convolutions / plain GEMMs are timed too
 
     def summary(self):
         """{label: (launches, total_ms, total_flops)} -- call after a device synchronize."""
@@ -78,12 +79,25 @@ def _timed(op, shape, geom, flops, launch):
     N, C, H, W, K, OH, OW = shape
     tile = lib.gz_conv2d_tile(op, N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride)
     label = "igemm<%s,%s>" % (("F", "Dg", "Wg")[op], _TILES.get(tile, "?"))
+    if _timer.detail:
+        label += " k%ds%dp%d N%d C%d H%d K%d OH%d" % (geom.kh, geom.stride, geom.pad, N, C, H, K, OH)
+    return _timed_as(label, flops, launch)
+
+
+def _timed_as(label, flops, launch):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     r = launch()
     e.record()
     _timer.records.append((label, flops, s, e))
     return r
+
+
+def _timed_detail(label_fn, flops, launch):
+    """Ops outside the 2-D convolution family: timed only by a detail timer (tools/layer_times.py)."""
+    if _timer is None or not _timer.detail:
+        return launch()
+    return _timed_as(label_fn(), flops, launch)
 
 
 # ---------------------------------------------------------------------------
@@ -130,15 +144,24 @@ def invalidate(w):
 # ---------------------------------------------------------------------------
 # raw (non-differentiable) launchers
 # ---------------------------------------------------------------------------
+def _scratch(nbytes, device):
+    """Split-K scratch of one launch (include/gz_ops.h: gz_*_workspace_bytes); None when the op is not split."""
+    if not nbytes:
+        return None, 0
+    return torch.empty(nbytes // 4, device=device, dtype=torch.float32), nbytes
+
+
 def _conv_fwd_raw(x, w, bias, geom, act, slope):
     N, C, H, W = x.shape
     K = w.shape[0]
     OH, OW = out_size(H, geom), out_size(W, geom)
     y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
     wp = _packed(w, "f", geom)
+    ws, nbytes = _scratch(lib.gz_conv2d_fwd_workspace_bytes(N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
+                                                            geom.pad), x.device)
     _timed(0, (N, C, H, W, K, OH, OW), geom, 2.0 * N * OH * OW * K * C * geom.kh * geom.kw, lambda: check(
-        lib.gz_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(y), N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
-                          geom.pad, act, slope, _stream()), "conv2d_fwd"))
+        lib.gz_conv2d_fwd(_p(x), _p(wp), _p(bias), _p(y), _p(ws), nbytes, N, C, H, W, K, OH, OW, geom.kh, geom.kw,
+                          geom.stride, geom.pad, act, slope, _stream()), "conv2d_fwd"))
     return y
 
 
@@ -148,9 +171,11 @@ def _conv_dgrad_raw(g, w, bias, geom, hw, act, slope):
     H, W = hw
     x = torch.empty((N, C, H, W), device=g.device, dtype=torch.float32)
     wp = _packed(w, "d", geom)
+    ws, nbytes = _scratch(lib.gz_conv2d_dgrad_workspace_bytes(N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
+                                                              geom.pad), g.device)
     _timed(1, (N, C, H, W, K, OH, OW), geom, 2.0 * N * OH * OW * K * C * geom.kh * geom.kw, lambda: check(
-        lib.gz_conv2d_dgrad(_p(g), _p(wp), _p(bias), _p(x), N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
-                            geom.pad, act, slope, _stream()), "conv2d_dgrad"))
+        lib.gz_conv2d_dgrad(_p(g), _p(wp), _p(bias), _p(x), _p(ws), nbytes, N, C, H, W, K, OH, OW, geom.kh, geom.kw,
+                            geom.stride, geom.pad, act, slope, _stream()), "conv2d_dgrad"))
     return x
 
 
@@ -178,8 +203,11 @@ def gemm(a, b, bias=None, trans_a=False, trans_b=False, act=ACT_NONE, slope=0.0)
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
     N = b.shape[0] if trans_b else b.shape[1]
     c = torch.empty((M, N), device=a.device, dtype=torch.float32)
-    check(lib.gz_gemm(_p(a), _p(b), _p(bias), _p(c), M, N, K, a.shape[1], b.shape[1], N, int(trans_a), int(trans_b),
-                      act, slope, _stream()), "gemm")
+    ws, nbytes = _scratch(lib.gz_gemm_workspace_bytes(M, N, K), a.device)
+    _timed_detail(lambda: "gemm %s%s M%d N%d K%d" % ("T" if trans_a else "N", "T" if trans_b else "N", M, N, K),
+                  2.0 * M * N * K,
+                  lambda: check(lib.gz_gemm(_p(a), _p(b), _p(bias), _p(c), _p(ws), nbytes, M, N, K, a.shape[1],
+                                            b.shape[1], N, int(trans_a), int(trans_b), act, slope, _stream()), "gemm"))
     return c
 
 
@@ -702,8 +730,10 @@ def _conv3d_fwd_raw(x, w, bias, act, slope):
     K, KS = w.shape[0], w.shape[2]
     OD, OH, OW = D // 2, H // 2, W // 2
     y = torch.empty((N, K, OD, OH, OW), device=x.device, dtype=torch.float32)
-    check(lib.gz_conv3d_fwd(_p(x), _p(_packed3(w, "f")), _p(bias), _p(y), N, C, D, H, W, K, OD, OH, OW, KS, 2, 1, act,
-                            slope, _stream()), "conv3d_fwd")
+    wp = _packed3(w, "f")
+    _timed_detail(lambda: "igemm3d<F> N%d C%d D%d K%d" % (N, C, D, K), 2.0 * N * OD * OH * OW * K * C * KS ** 3,
+                  lambda: check(lib.gz_conv3d_fwd(_p(x), _p(wp), _p(bias), _p(y), N, C, D, H, W, K, OD, OH, OW, KS, 2, 1,
+                                                  act, slope, _stream()), "conv3d_fwd"))
     return y
 
 
@@ -712,8 +742,10 @@ def _conv3d_dgrad_raw(g, w, bias, act, slope):
     C, KS = w.shape[1], w.shape[2]
     D, H, W = 2 * OD, 2 * OH, 2 * OW
     x = torch.empty((N, C, D, H, W), device=g.device, dtype=torch.float32)
-    check(lib.gz_conv3d_dgrad(_p(g), _p(_packed3(w, "d")), _p(bias), _p(x), N, C, D, H, W, K, OD, OH, OW, KS, 2, 1,
-                              act, slope, _stream()), "conv3d_dgrad")
+    wp = _packed3(w, "d")
+    _timed_detail(lambda: "igemm3d<Dg> N%d C%d D%d K%d" % (N, C, D, K), 2.0 * N * OD * OH * OW * K * C * KS ** 3,
+                  lambda: check(lib.gz_conv3d_dgrad(_p(g), _p(wp), _p(bias), _p(x), N, C, D, H, W, K, OD, OH, OW, KS, 2,
+                                                    1, act, slope, _stream()), "conv3d_dgrad"))
     return x
 
 
@@ -723,8 +755,9 @@ def _conv3d_wgrad_raw(x, g, ks):
     dw = torch.empty((K, C, ks, ks, ks), device=x.device, dtype=torch.float32)
     nbytes = lib.gz_conv3d_wgrad_workspace_bytes(N, C, K, OD, OH, OW, ks)
     ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
-    check(lib.gz_conv3d_wgrad(_p(x), _p(g), _p(dw), _p(ws), nbytes, N, C, D, H, W, K, OD, OH, OW, ks, 2, 1, _stream()),
-          "conv3d_wgrad")
+    _timed_detail(lambda: "igemm3d<Wg> N%d C%d D%d K%d" % (N, C, D, K), 2.0 * N * OD * OH * OW * K * C * ks ** 3,
+                  lambda: check(lib.gz_conv3d_wgrad(_p(x), _p(g), _p(dw), _p(ws), nbytes, N, C, D, H, W, K, OD, OH, OW,
+                                                    ks, 2, 1, _stream()), "conv3d_wgrad"))
     return dw
 
 

@@ -501,3 +501,53 @@ def test_resnet_r1_regulariser_matches_oracle(cfg):
     assert fp.shape == (cfg["bs"], 3, cfg["size"], cfg["size"]) and rel(fp, fo) < TOL and l2(gzp, gzo) < TOL
     worst = max((l2(pgp[n], pgo[n]), n) for n in pgo)
     assert worst[0] < TOL, worst
+
+
+# ---------------------------------------------------------------------------
+# split-K of F / Dg / GEMM (few output tiles, long reduction)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("geom,case", [
+    ("k3s1p1", (64, 512, 4, 512)),     # R1 ResNet 512->512 @ 4x4, bs 64
+    ("k3s1p1", (16, 96, 8, 200)),      # ragged channels
+    ("k5s2p2", (64, 256, 8, 512)),     # HoloGAN discriminator block 3, bs 64
+    ("k4s2p1", (32, 256, 8, 512)),     # DCGAN D.block3 at a small batch
+    ("k1s1p0", (8, 512, 4, 512)),
+])
+def test_conv_split_k(geom, case):
+    F = _F()
+    from lightning_gan_zoo_amd._lib import lib
+    k, s, p = GEOMS[geom]
+    N, C, H, K = case
+    g = F.Geom(k, k, s, p)
+    OH = (H + 2 * p - k) // s + 1
+    assert lib.gz_conv2d_fwd_workspace_bytes(N, C, H, H, K, OH, OH, k, k, s, p) > 0, "case no longer splits"
+    assert lib.gz_conv2d_dgrad_workspace_bytes(N, C, H, H, K, OH, OH, k, k, s, p) > 0
+    x = rnd(N, C, H, H, seed=41)
+    w = rnd(K, C, k, k, seed=42, scale=0.05)
+    b = rnd(K, seed=43)
+    y_ref = TF.leaky_relu(TF.conv2d(x, w, b, s, p), 0.2)
+    gy = rnd(*y_ref.shape, seed=44)
+    bc = rnd(C, seed=45)
+    dx_ref = torch.tanh(TF.conv_transpose2d(gy, w, bc, s, p, output_padding=H - ((OH - 1) * s - 2 * p + k)))
+    y = F._conv_fwd_raw(x.cuda(), w.cuda(), b.cuda(), g, F.ACT_LRELU, 0.2)
+    assert rel(y, y_ref) < TOL
+    dx = F._conv_dgrad_raw(gy.cuda(), w.cuda(), bc.cuda(), g, (H, H), F.ACT_TANH, 0.0)
+    assert rel(dx, dx_ref) < TOL
+    # same launch twice: the slab sum order is fixed, so the result is bit-reproducible
+    assert torch.equal(y, F._conv_fwd_raw(x.cuda(), w.cuda(), b.cuda(), g, F.ACT_LRELU, 0.2))
+
+
+@pytest.mark.parametrize("shape", [(64, 8192, 128), (64, 8192, 1), (3, 4100, 70), (200, 2048, 130)])
+@pytest.mark.parametrize("tb", [False, True])
+def test_gemm_split_k(shape, tb):
+    F = _F()
+    from lightning_gan_zoo_amd._lib import lib
+    M, K, N = shape
+    assert lib.gz_gemm_workspace_bytes(M, N, K) > 0, "case no longer splits"
+    a, b, bias = rnd(M, K, seed=51), rnd(K, N, seed=52, scale=0.05), rnd(N, seed=53)
+    ref = torch.relu(a.double() @ b.double() + bias.double())
+    bd = b.t().contiguous().cuda() if tb else b.cuda()
+    c = F.gemm(a.cuda(), bd, bias.cuda(), trans_b=tb, act=F.ACT_RELU)
+    assert rel(c, ref) < TOL
+    c2 = F.gemm(a.t().contiguous().cuda(), bd, bias.cuda(), trans_a=True, trans_b=tb, act=F.ACT_RELU)
+    assert rel(c2, ref) < TOL
