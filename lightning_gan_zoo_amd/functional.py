@@ -54,6 +54,7 @@ class KernelTimer:
     def __init__(self, detail=False):
         self.records = []      # (label, flops, start_event, end_event)
         self.detail = detail   # per-shape labels, and the 3-D convolutions / plain GEMMs are timed too
+        self.enabled = True    # bench.py samples every few cycles: two event records per launch cost ~5 % of a step
 
     def summary(self):
         """{label: (launches, total_ms, total_flops)} -- call after a device synchronize."""
@@ -74,7 +75,7 @@ def set_kernel_timer(timer):
 
 
 def _timed(op, shape, geom, flops, launch):
-    if _timer is None:
+    if _timer is None or not _timer.enabled:
         return launch()
     N, C, H, W, K, OH, OW = shape
     tile = lib.gz_conv2d_tile(op, N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride)
@@ -95,7 +96,7 @@ def _timed_as(label, flops, launch):
 
 def _timed_detail(label_fn, flops, launch):
     """Ops outside the 2-D convolution family: timed only by a detail timer (tools/layer_times.py)."""
-    if _timer is None or not _timer.detail:
+    if _timer is None or not _timer.detail or not _timer.enabled:
         return launch()
     return _timed_as(label_fn(), flops, launch)
 
