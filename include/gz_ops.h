@@ -92,12 +92,16 @@ long long gz_conv3d_pack_dgrad_elems(int K, int C, int KS, int S);
 int gz_conv3d_pack_fwd(const float* w, float* wpack, int K, int C, int KS, hipStream_t stream);
 int gz_conv3d_pack_dgrad(const float* w, float* wpack, int K, int C, int KS, int S, int P, hipStream_t stream);
 /* y = act(conv3d(x, w) + bias): input gradient of nn.ConvTranspose3d */
-int gz_conv3d_fwd(const float* x, const float* wpack, const float* bias, float* y, int N, int C, int D, int H, int W,
-                  int K, int OD, int OH, int OW, int KS, int S, int P, int act, float slope, hipStream_t stream);
+int gz_conv3d_fwd(const float* x, const float* wpack, const float* bias, float* y, float* workspace, size_t ws_bytes,
+                  int N, int C, int D, int H, int W, int K, int OD, int OH, int OW, int KS, int S, int P, int act,
+                  float slope, hipStream_t stream);
+/* split-K scratch of the two launchers above / below (0 = not split; NULL workspace = run unsplit) */
+size_t gz_conv3d_fwd_workspace_bytes(int N, int C, int K, int OD, int OH, int OW, int KS);
+size_t gz_conv3d_dgrad_workspace_bytes(int N, int C, int K, int OD, int OH, int OW, int KS);
 /* x = act(conv_transpose3d(y, w) + bias): nn.ConvTranspose3d forward */
-int gz_conv3d_dgrad(const float* y, const float* wpack, const float* bias, float* x, int N, int C, int D, int H,
-                    int W, int K, int OD, int OH, int OW, int KS, int S, int P, int act, float slope,
-                    hipStream_t stream);
+int gz_conv3d_dgrad(const float* y, const float* wpack, const float* bias, float* x, float* workspace,
+                    size_t ws_bytes, int N, int C, int D, int H, int W, int K, int OD, int OH, int OW, int KS, int S,
+                    int P, int act, float slope, hipStream_t stream);
 size_t gz_conv3d_wgrad_workspace_bytes(int N, int C, int K, int OD, int OH, int OW, int KS);
 int gz_conv3d_wgrad(const float* x, const float* y, float* dw, float* workspace, size_t ws_bytes, int N, int C, int D,
                     int H, int W, int K, int OD, int OH, int OW, int KS, int S, int P, hipStream_t stream);

@@ -118,7 +118,55 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
     }
 }
 
-// dgrad pack: wp[phase][(ko, ty, tx)][ldc] = w[ko][c][ky][kx], ky = ((py+P)%S) + S*ty (0 if >= KH)
+// Tap-major reduction order (gz_igemm.h: ConvFwdALoaderTap / ConvDgALoaderTap) is used when the tap count does not
+// divide a chunk (3x3, 5x5) and there are enough channels to fill the BK-wide channel blocks.
+static bool fwd_tap_major(int C, int KH, int KW) {
+    static int off = getenv("GZ_NO_TAPMAJOR") ? 1 : 0;
+    return !off && (BK % (KH * KW) != 0) && C >= BK;
+}
+
+static bool dgrad_tap_major(int K, int KH, int KW, int S) {
+    static int off = getenv("GZ_NO_TAPMAJOR") ? 1 : 0;
+    const int taps = ((KH + S - 1) / S) * ((KW + S - 1) / S);
+    const bool fixed = (KH % S == 0) && (KW % S == 0) && (BK % taps == 0);
+    return !off && !fixed && K >= BK;
+}
+
+// wp[(tap, c)][ld] = w[ko][c][tap], c padded to a multiple of BK with zero rows
+__global__ __launch_bounds__(256) void pack_fwd_tap_kernel(const float* __restrict__ w, float* __restrict__ wp, int K,
+                                                           int C, int taps, int cpad, int ld) {
+    const long long total = (long long)taps * cpad * ld;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int ko = (int)(i % ld);
+        long long row = i / ld;
+        int c = (int)(row % cpad), tap = (int)(row / cpad);
+        wp[i] = (ko < K && c < C) ? w[((long long)ko * C + c) * taps + tap] : 0.f;
+    }
+}
+
+// wp[phase][(tap, ko)][ldc] = w[ko][c][ky][kx] over the phase's own ny x nx taps (tap = ty * nx + tx), ko padded
+// to a multiple of BK; the unused tail of the phase's fixed-size TY*TX*kpad-row region is never read
+__global__ __launch_bounds__(256) void pack_dgrad_tap_kernel(const float* __restrict__ w, float* __restrict__ wp, int K,
+                                                             int C, int KH, int KW, int S, int P, int TY, int TX,
+                                                             int kpad, int ldc) {
+    const int phase = blockIdx.y;
+    const int py = phase / S, px = phase % S;
+    const int ry = (py + P) % S, rx = (px + P) % S;
+    const int ny = dg_taps(KH, S, P, py), nx = dg_taps(KW, S, P, px);
+    float* dst = wp + (long long)phase * TY * TX * kpad * ldc;
+    const long long total = (long long)ny * nx * kpad * ldc;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int c = (int)(i % ldc);
+        long long row = i / ldc;
+        int ko = (int)(row % kpad), tap = (int)(row / kpad);
+        int ky = ry + S * (tap / nx), kx = rx + S * (tap % nx);
+        dst[i] = (ko < K && c < C) ? w[(((long long)ko * C + c) * KH + ky) * KW + kx] : 0.f;
+    }
+}
+
+// dgrad pack: wp[phase][(ko, ty, tx)][ldc] = w[ko][c][ky][kx], ky = ((py+P)%S) + S*ty.  A phase only has the taps
+// whose ky < KH (kx < KW): ny(py) * nx(px) of them (dg_taps); its rows are packed tightly and the rest of the
+// phase's fixed-size K*TY*TX-row region is zero.  (k5 s2: 9/6/6/4 taps instead of 4 x 9.)
 __global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp,
                                                          int K, int C, int KH, int KW, int S, int P, int TY,
                                                          int TX, int ldc) {
@@ -126,15 +174,16 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict
     const int phase = blockIdx.y;
     const int py = phase / S, px = phase % S;
     const int ry = (py + P) % S, rx = (px + P) % S;
-    const int taps = TY * TX;
-    const long long phase_stride = (long long)K * taps * ldc;
+    const int ny = dg_taps(KH, S, P, py), nx = dg_taps(KW, S, P, px);
+    const int taps = ny * nx, pad = TY * TX - taps;
+    float* dst = wp + (long long)phase * K * TY * TX * ldc;
     for (int i = threadIdx.x; i < taps * ldc; i += blockDim.x) {
         int tap = i / ldc, c = i - tap * ldc;
-        int ky = ry + S * (tap / TX), kx = rx + S * (tap % TX);
-        float v = 0.f;
-        if (c < C && ky < KH && kx < KW) v = w[(((long long)ko * C + c) * KH + ky) * KW + kx];
-        wp[phase * phase_stride + ((long long)ko * taps + tap) * ldc + c] = v;
+        int ky = ry + S * (tap / nx), kx = rx + S * (tap % nx);
+        dst[((long long)ko * taps + tap) * ldc + c] = c < C ? w[(((long long)ko * C + c) * KH + ky) * KW + kx] : 0.f;
     }
+    for (int i = threadIdx.x; i < pad * ldc; i += blockDim.x)
+        dst[((long long)K * taps + (long long)ko * pad) * ldc + i] = 0.f;
 }
 
 // out[i] = sum_s slab[s][i].  Small weight tensors reach here with hundreds of slabs (split-K over a 1M-long
@@ -207,22 +256,35 @@ static int run_fwd(const float* x, const float* wp, const float* bias, float* y,
 #endif
     using BL = MContigLoader4<Cfg::BN>;
     typename AL::Params pa{x, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW)};
-    int Kg = s.C * G::kh * G::kw;
-    typename BL::Params pb{wp, Kg, round4(s.K), round4(s.K), 0};
     int M = s.N * s.OH * s.OW;
     EpiNCHW::Params pe{y, M, s.K, s.OH * s.OW, make_fastdiv(s.OH * s.OW), bias, act, slope};
+    if constexpr (BK % (G::kh * G::kw) != 0) {
+        if (fwd_tap_major(s.C, G::kh, G::kw)) {
+            using ALT = ConvFwdALoaderTap<Cfg::BM, G::kh, G::kw, G::s, G::p>;
+            int Kt = G::kh * G::kw * round_bk(s.C);
+            typename BL::Params pbt{wp, Kt, round4(s.K), round4(s.K), 0};
+            return launch_igemm<Cfg, ALT, BL, EpiNCHW>(pa, pbt, pe, M, s.K, Kt, 1, splits, st, slab);
+        }
+    }
+    int Kg = s.C * G::kh * G::kw;
+    typename BL::Params pb{wp, Kg, round4(s.K), round4(s.K), 0};
     return launch_igemm<Cfg, AL, BL, EpiNCHW>(pa, pb, pe, M, s.K, Kg, 1, splits, st, slab);
+}
+
+template <class G>
+static int fwd_kdim(const ConvShape& s) {
+    return G::kh * G::kw * (fwd_tap_major(s.C, G::kh, G::kw) ? round_bk(s.C) : s.C);
 }
 
 template <class G>
 static SplitPlan fwd_plan(const ConvShape& s) {
     long long M = (long long)s.N * s.OH * s.OW;
-    return plan_split(M, s.K, s.C * G::kh * G::kw, 1, pick_tile(M, s.K, 1));
+    return plan_split(M, s.K, fwd_kdim<G>(s), 1, pick_tile(M, s.K, 1));
 }
 
 template <class G>
 static size_t fwd_ws_bytes(const ConvShape& s) {
-    return split_bytes(fwd_plan<G>(s), (long long)s.N * s.OH * s.OW, s.K, s.C * G::kh * G::kw, 1);
+    return split_bytes(fwd_plan<G>(s), (long long)s.N * s.OH * s.OW, s.K, fwd_kdim<G>(s), 1);
 }
 
 template <class G>
@@ -346,6 +408,26 @@ static int run_dgrad(const float* y, const float* wp, const float* bias, float* 
     typename BL::Params pb{wp, Kg, ldc, ldc, (long long)Kg * ldc};
     int M = s.N * AH * AW;
     typename Epi::Params pe{x, M, s.C, s.H, s.W, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW), bias, act, slope};
+    if constexpr (!AL::FIXED) {
+        if (dgrad_tap_major(s.K, G::kh, G::kw, G::s)) {
+            using ALT = ConvDgALoaderTap<Cfg::BM, G::kh, G::kw, G::s, G::p>;
+            typename ALT::Params pat{y, s, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW)};
+            const int kpad = round_bk(s.K);
+            int Kt = AL::TAPS * kpad;
+            typename BL::Params pbt{wp, Kt, ldc, ldc, (long long)Kt * ldc};
+            int pc[8];
+            for (int ph = 0; ph < G::s * G::s; ++ph)
+                pc[ph] = dg_taps(G::kh, G::s, G::p, ph / G::s) * dg_taps(G::kw, G::s, G::p, ph % G::s) * (kpad / BK);
+            return launch_igemm<Cfg, ALT, BL, Epi>(pat, pbt, pe, M, s.C, Kt, G::s * G::s, splits, st, slab, pc);
+        }
+    }
+    if constexpr (!AL::UNIFORM) {
+        // phases differ in their tap count, hence in the length of their reduction
+        int pc[8];
+        for (int ph = 0; ph < G::s * G::s; ++ph)
+            pc[ph] = (s.K * dg_taps(G::kh, G::s, G::p, ph / G::s) * dg_taps(G::kw, G::s, G::p, ph % G::s) + BK - 1) / BK;
+        return launch_igemm<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kg, G::s * G::s, splits, st, slab, pc);
+    }
     return launch_igemm<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kg, G::s * G::s, splits, st, slab);
 }
 
@@ -359,14 +441,16 @@ template <class G>
 static SplitPlan dgrad_plan(const ConvShape& s) {
     constexpr int TAPS = ((G::kh + G::s - 1) / G::s) * ((G::kw + G::s - 1) / G::s);
     long long M = (long long)s.N * (s.H / G::s) * (s.W / G::s);
-    return plan_split(M, s.C, s.K * TAPS, G::s * G::s, pick_tile(M, s.C, G::s * G::s));
+    const int kk = dgrad_tap_major(s.K, G::kh, G::kw, G::s) ? round_bk(s.K) : s.K;
+    return plan_split(M, s.C, kk * TAPS, G::s * G::s, pick_tile(M, s.C, G::s * G::s));
 }
 
 template <class G>
 static size_t dgrad_ws_bytes(const ConvShape& s) {
     constexpr int TAPS = ((G::kh + G::s - 1) / G::s) * ((G::kw + G::s - 1) / G::s);
     if (s.H % G::s || s.W % G::s || dgrad_direct<G>(nullptr, s)) return 0;
-    return split_bytes(dgrad_plan<G>(s), (long long)s.N * (s.H / G::s) * (s.W / G::s), s.C, s.K * TAPS, G::s * G::s);
+    const int kk = dgrad_tap_major(s.K, G::kh, G::kw, G::s) ? round_bk(s.K) : s.K;
+    return split_bytes(dgrad_plan<G>(s), (long long)s.N * (s.H / G::s) * (s.W / G::s), s.C, kk * TAPS, G::s * G::s);
 }
 
 template <class G>
@@ -549,17 +633,25 @@ typedef Geo<1, 1, 1, 0> G1110;
 
 extern "C" {
 
-long long gz_conv2d_pack_fwd_elems(int K, int C, int KH, int KW) { return (long long)C * KH * KW * round4(K); }
+long long gz_conv2d_pack_fwd_elems(int K, int C, int KH, int KW) {
+    return (long long)(fwd_tap_major(C, KH, KW) ? round_bk(C) : C) * KH * KW * round4(K);
+}
 
 long long gz_conv2d_pack_dgrad_elems(int K, int C, int KH, int KW, int S) {
     int TY = (KH + S - 1) / S, TX = (KW + S - 1) / S;
-    return (long long)S * S * K * TY * TX * round4(C);
+    return (long long)S * S * (dgrad_tap_major(K, KH, KW, S) ? round_bk(K) : K) * TY * TX * round4(C);
 }
 
 int gz_conv2d_pack_fwd(const float* w, float* wp, int K, int C, int KH, int KW, hipStream_t stream) {
     gz::clear_stale_error();
     if (K <= 0 || C <= 0 || KH <= 0 || KW <= 0) return GZ_ERR_BAD_SHAPE;
     int Kg = C * KH * KW, ld = round4(K);
+    if (fwd_tap_major(C, KH, KW)) {
+        long long total = (long long)KH * KW * round_bk(C) * ld;
+        hipLaunchKernelGGL(pack_fwd_tap_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)),
+                           dim3(256), 0, stream, w, wp, K, C, KH * KW, round_bk(C), ld);
+        return launch_status();
+    }
     dim3 grid((Kg + 31) / 32, (ld + 31) / 32);
     hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, stream, w, wp, K, Kg, ld);
     return launch_status();
@@ -570,6 +662,13 @@ int gz_conv2d_pack_dgrad(const float* w, float* wp, int K, int C, int KH, int KW
     gz::clear_stale_error();
     if (K <= 0 || C <= 0 || KH <= 0 || KW <= 0 || S <= 0) return GZ_ERR_BAD_SHAPE;
     int TY = (KH + S - 1) / S, TX = (KW + S - 1) / S;
+    if (dgrad_tap_major(K, KH, KW, S)) {
+        long long total = (long long)TY * TX * round_bk(K) * round4(C);
+        unsigned bx = (unsigned)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+        hipLaunchKernelGGL(pack_dgrad_tap_kernel, dim3(bx, S * S), dim3(256), 0, stream, w, wp, K, C, KH, KW, S, P, TY,
+                           TX, round_bk(K), round4(C));
+        return launch_status();
+    }
     hipLaunchKernelGGL(pack_dgrad_kernel, dim3(K, S * S), dim3(256), 0, stream, w, wp, K, C, KH, KW, S, P, TY, TX,
                        round4(C));
     return launch_status();

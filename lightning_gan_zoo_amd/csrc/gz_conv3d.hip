@@ -13,6 +13,23 @@ using C3_64x64 = TileCfg<2, 2, 1, 1>;
 
 static inline int r4(int v) { return (v + 3) & ~3; }
 
+// split-K of under-filled F / Dg launches: same policy as gz_conv.hip (plan_split)
+static int plan3(int tile, long long M, long long N, int Kdim, int ny) {
+    static int off = getenv("GZ_NO_SPLITK") ? 1 : 0;
+    if (off) return 1;
+    const int bm = tile == 3 ? 64 : 128, bn = tile == 0 ? 128 : (tile == 2 ? 32 : 64);
+    const long long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * ny;
+    const int chunks = (Kdim + BK - 1) / BK;
+    if (chunks < 16 || tiles >= 512) return 1;
+    long long want = (1024 + tiles - 1) / tiles, cap = chunks / 8;
+    long long sp = want < cap ? want : cap;
+    return sp < 2 ? 1 : (int)sp;
+}
+
+static size_t bytes3(int splits, long long M, long long N, int Kdim, int ny) {
+    return splits > 1 ? (size_t)split_nz(Kdim, splits) * ny * M * N * 4 : 0;
+}
+
 static int pick3(long long M, long long N, int ny) {
     if (N <= 32) return 2;
     auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * ny; };
@@ -41,21 +58,25 @@ __global__ __launch_bounds__(256) void transpose_pad3_kernel(const float* __rest
     }
 }
 
-// wp[phase][(ko, td, ty, tx)][ldc] = w[ko][c][kd][ky][kx], k* = ((p* + P) % S) + S * t*  (0 if >= KS)
+// wp[phase][(ko, td, ty, tx)][ldc] = w[ko][c][kd][ky][kx], k* = ((p* + P) % S) + S * t*.  Only the taps with
+// k* < KS exist (k3 s2 p1: 1 tap on an even output coordinate, 2 on an odd one -> 1..8 per phase, 27 over the 8
+// phases instead of 8 x 8); a phase's rows are packed tightly, the rest of its fixed-size region is zero.
 __global__ __launch_bounds__(256) void pack_dgrad3_kernel(const float* __restrict__ w, float* __restrict__ wp, int K,
                                                           int C, int KS, int S, int P, int T, int ldc) {
     const int ko = blockIdx.x, phase = blockIdx.y;
     const int pd = phase / (S * S), py = (phase / S) % S, px = phase % S;
     const int rd = (pd + P) % S, ry = (py + P) % S, rx = (px + P) % S;
-    const int taps = T * T * T;
-    const long long phase_stride = (long long)K * taps * ldc;
+    const int nd = dg_taps(KS, S, P, pd), ny = dg_taps(KS, S, P, py), nx = dg_taps(KS, S, P, px);
+    const int taps = nd * ny * nx, pad = T * T * T - taps;
+    float* dst = wp + (long long)phase * K * T * T * T * ldc;
     for (int i = threadIdx.x; i < taps * ldc; i += blockDim.x) {
         int tap = i / ldc, c = i - tap * ldc;
-        int kd = rd + S * (tap / (T * T)), ky = ry + S * ((tap / T) % T), kx = rx + S * (tap % T);
-        float v = 0.f;
-        if (c < C && kd < KS && ky < KS && kx < KS) v = w[((((long long)ko * C + c) * KS + kd) * KS + ky) * KS + kx];
-        wp[phase * phase_stride + ((long long)ko * taps + tap) * ldc + c] = v;
+        int kd = rd + S * (tap / (ny * nx)), ky = ry + S * ((tap / nx) % ny), kx = rx + S * (tap % nx);
+        dst[((long long)ko * taps + tap) * ldc + c] =
+            c < C ? w[((((long long)ko * C + c) * KS + kd) * KS + ky) * KS + kx] : 0.f;
     }
+    for (int i = threadIdx.x; i < pad * ldc; i += blockDim.x)
+        dst[((long long)K * taps + (long long)ko * pad) * ldc + i] = 0.f;
 }
 
 __global__ __launch_bounds__(256) void reduce_slabs3_kernel(const float* __restrict__ slab, float* __restrict__ out,
@@ -77,7 +98,7 @@ static bool big3(long long e) { return e * 4 >= (1ll << 31); }
 
 template <class Cfg, int KS, int S, int P>
 static int run_fwd3(const float* x, const float* wp, const float* bias, float* y, const Conv3DShape& s, int act,
-                    float slope, hipStream_t st) {
+                    float slope, hipStream_t st, int splits, float* slab) {
     using AL = Conv3DFwdALoader<Cfg::BM, KS, S, P>;
     using BL = MContigLoader4<Cfg::BN>;
     const int osp = s.OD * s.OH * s.OW;
@@ -86,12 +107,12 @@ static int run_fwd3(const float* x, const float* wp, const float* bias, float* y
     typename BL::Params pb{wp, Kg, r4(s.K), r4(s.K), 0};
     int M = s.N * osp;
     EpiNCHW::Params pe{y, M, s.K, osp, make_fastdiv(osp), bias, act, slope};
-    return launch_igemm<Cfg, AL, BL, EpiNCHW>(pa, pb, pe, M, s.K, Kg, 1, 1, st);
+    return launch_igemm<Cfg, AL, BL, EpiNCHW>(pa, pb, pe, M, s.K, Kg, 1, splits, st, slab);
 }
 
 template <class Cfg, int KS, int S, int P>
 static int run_dgrad3(const float* y, const float* wp, const float* bias, float* x, const Conv3DShape& s, int act,
-                      float slope, hipStream_t st) {
+                      float slope, hipStream_t st, int splits, float* slab) {
     using AL = Conv3DDgALoader<Cfg::BM, KS, S, P>;
     using BL = MContigLoader4<Cfg::BN>;
     using Epi = EpiPhase3D<S>;
@@ -103,7 +124,11 @@ static int run_dgrad3(const float* y, const float* wp, const float* bias, float*
     int M = s.N * AD * AH * AW;
     typename Epi::Params pe{x, M, s.C, s.D, s.H, s.W, AD, AH, AW, make_fastdiv(AD * AH * AW), make_fastdiv(AH * AW),
                             make_fastdiv(AW), bias, act, slope};
-    return launch_igemm<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kg, S * S * S, 1, st);
+    int pc[8];
+    for (int ph = 0; ph < S * S * S; ++ph)
+        pc[ph] = (s.K * dg_taps(KS, S, P, ph / (S * S)) * dg_taps(KS, S, P, (ph / S) % S) * dg_taps(KS, S, P, ph % S) +
+                  BK - 1) / BK;
+    return launch_igemm<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kg, S * S * S, splits, st, slab, pc);
 }
 
 static int splits3(long long tiles, int chunks) {
@@ -186,8 +211,21 @@ int gz_conv3d_pack_dgrad(const float* w, float* wp, int K, int C, int KS, int S,
     return launch_status();
 }
 
-int gz_conv3d_fwd(const float* x, const float* wpack, const float* bias, float* y, int N, int C, int D, int H, int W,
-                  int K, int OD, int OH, int OW, int KS, int S, int P, int act, float slope, hipStream_t stream) {
+size_t gz_conv3d_fwd_workspace_bytes(int N, int C, int K, int OD, int OH, int OW, int KS) {
+    long long M = (long long)N * OD * OH * OW;
+    int Kg = C * KS * KS * KS;
+    return bytes3(plan3(pick3(M, K, 1), M, K, Kg, 1), M, K, Kg, 1);
+}
+
+size_t gz_conv3d_dgrad_workspace_bytes(int N, int C, int K, int OD, int OH, int OW, int KS) {
+    long long M = (long long)N * OD * OH * OW;      // per phase: the S = 2 output grid has OD*OH*OW cells per phase
+    int Kg = K * 8;
+    return bytes3(plan3(pick3(M, C, 8), M, C, Kg, 8), M, C, Kg, 8);
+}
+
+int gz_conv3d_fwd(const float* x, const float* wpack, const float* bias, float* y, float* workspace, size_t ws_bytes,
+                  int N, int C, int D, int H, int W, int K, int OD, int OH, int OW, int KS, int S, int P, int act,
+                  float slope, hipStream_t stream) {
     gz::clear_stale_error();
     Conv3DShape s{N, C, D, H, W, K, OD, OH, OW};
     if (KS != 3 || S != 2 || P != 1) return GZ_ERR_UNSUPPORTED;
@@ -195,22 +233,29 @@ int gz_conv3d_fwd(const float* x, const float* wpack, const float* bias, float* 
     if (big3((long long)N * C * D * H * W) || big3((long long)N * K * OD * OH * OW)) return GZ_ERR_TOO_LARGE;
     if (((uintptr_t)wpack & 15) || ((uintptr_t)y & 15)) return GZ_ERR_BAD_SHAPE;
     int t = pick3((long long)N * OD * OH * OW, K, 1);
-#define CALL(CFG) run_fwd3<CFG, 3, 2, 1>(x, wpack, bias, y, s, act, slope, stream)
+    int splits = plan3(t, (long long)N * OD * OH * OW, K, C * 27, 1);
+    if (splits > 1 && (!workspace || ws_bytes < bytes3(splits, (long long)N * OD * OH * OW, K, C * 27, 1))) splits = 1;
+    float* slab = splits > 1 ? workspace : nullptr;
+#define CALL(CFG) run_fwd3<CFG, 3, 2, 1>(x, wpack, bias, y, s, act, slope, stream, splits, slab)
     GZ3_TILE_SWITCH(t, CALL)
 #undef CALL
 }
 
-int gz_conv3d_dgrad(const float* y, const float* wpack, const float* bias, float* x, int N, int C, int D, int H,
-                    int W, int K, int OD, int OH, int OW, int KS, int S, int P, int act, float slope,
-                    hipStream_t stream) {
+int gz_conv3d_dgrad(const float* y, const float* wpack, const float* bias, float* x, float* workspace,
+                    size_t ws_bytes, int N, int C, int D, int H, int W, int K, int OD, int OH, int OW, int KS, int S,
+                    int P, int act, float slope, hipStream_t stream) {
     gz::clear_stale_error();
     Conv3DShape s{N, C, D, H, W, K, OD, OH, OW};
     if (KS != 3 || S != 2 || P != 1) return GZ_ERR_UNSUPPORTED;
     if (!shape3_ok(s, KS, S, P) || D % S || H % S || W % S) return GZ_ERR_BAD_SHAPE;
     if (big3((long long)N * C * D * H * W) || big3((long long)N * K * OD * OH * OW)) return GZ_ERR_TOO_LARGE;
     if ((uintptr_t)wpack & 15) return GZ_ERR_BAD_SHAPE;
-    int t = pick3((long long)N * (D / S) * (H / S) * (W / S), C, S * S * S);
-#define CALL(CFG) run_dgrad3<CFG, 3, 2, 1>(y, wpack, bias, x, s, act, slope, stream)
+    const long long Mp = (long long)N * (D / S) * (H / S) * (W / S);
+    int t = pick3(Mp, C, S * S * S);
+    int splits = plan3(t, Mp, C, K * 8, 8);
+    if (splits > 1 && (!workspace || ws_bytes < bytes3(splits, Mp, C, K * 8, 8))) splits = 1;
+    float* slab = splits > 1 ? workspace : nullptr;
+#define CALL(CFG) run_dgrad3<CFG, 3, 2, 1>(y, wpack, bias, x, s, act, slope, stream, splits, slab)
     GZ3_TILE_SWITCH(t, CALL)
 #undef CALL
 }

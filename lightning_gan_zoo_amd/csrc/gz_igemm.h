@@ -33,6 +33,11 @@ namespace gz {
 
 constexpr int NT = 256;
 constexpr int BK = 16;
+// number of kernel taps k = ((parity + P) % S) + S*t below KS that a transposed-conv output phase of that parity has
+__host__ __device__ constexpr int dg_taps(int KS, int S, int P, int parity) {
+    return (KS - ((parity + P) % S) + S - 1) / S;
+}
+
 constexpr uint32_t OOB = 0x80000000u;  // voffset that is out of range for every tensor (< 2 GiB)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
@@ -340,6 +345,163 @@ struct ConvFwdALoader {
     }
 };
 
+// Tap-major reduction order for kernels whose tap count does not divide a chunk (3x3: 9, 5x5: 25): with the
+// usual k = (c, tap) order every element of every chunk needs its own (c, ky, kx) decode and bounds test -- ~25
+// VALU instructions per 4-byte load, which made the 16-channel 128x128 ResNet layers VALU-bound on address
+// arithmetic.  With k = (tap, c), c padded to a multiple of BK, a chunk is ONE tap and BK consecutive channels:
+// per lane the voffsets are loop-invariant (pixel + its BK/STEP channel rows), the tap and the channel block
+// advance through the wave-uniform scalar offset, and the padding test is one compare pair per chunk.
+// The descriptor base is moved back by the largest negative tap shift so that voffsets stay non-negative; taps
+// in the padding use the out-of-range voffset and are never dereferenced.
+constexpr int round_bk(int v) { return (v + BK - 1) / BK * BK; }
+
+// A[m = (n, oy, ox)][k = (tap, c)] = x[n][c][oy*S-P+ky][ox*S-P+kx]
+template <int BM, int KH, int KW, int S, int P>
+struct ConvFwdALoaderTap {
+    using Params = typename ConvFwdALoader<BM, KH, KW, S, P>::Params;
+    static constexpr int LD = BM;
+    static constexpr int EPT = BM * BK / NT;
+    static constexpr int STEP = NT / BM;
+    static constexpr bool DMA = GZ_IGEMM_DMA;
+    static constexpr int NPARTS = 0;
+    __device__ __forceinline__ void issue_lds_part(int, float*, int) {}
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[EPT];
+    int kb, m_l, iy0, ix0, C, H, W, cblocks;
+    bool m_ok;
+    float r[DMA ? 1 : EPT];
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        const ConvShape& s = p.s;
+        const uint32_t shift = (uint32_t)(P * s.W + P) * 4u;
+        rsrc = make_rsrc(reinterpret_cast<const char*>(p.x) - shift, (uint32_t)s.N * s.C * s.H * s.W * 4u + shift);
+        m_l = tid % BM;
+        kb = tid / BM;
+        uint32_t m = (uint32_t)tile * BM + m_l;
+        m_ok = m < (uint32_t)s.N * s.OH * s.OW;
+        uint32_t n = fdiv(m, p.div_ohw);
+        uint32_t pix = m - n * (uint32_t)(s.OH * s.OW);
+        uint32_t oy = fdiv(pix, p.div_ow);
+        uint32_t ox = pix - oy * (uint32_t)s.OW;
+        iy0 = (int)oy * S - P;
+        ix0 = (int)ox * S - P;
+        C = s.C; H = s.H; W = s.W;
+        cblocks = round_bk(s.C) / BK;
+        const int pos = (int)(n * (uint32_t)(s.C * s.H * s.W)) + (iy0 + P) * W + (ix0 + P);   // >= 0 (shifted base)
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) voff[j] = (uint32_t)(pos + (kb + STEP * j) * H * W) * 4u;
+    }
+    // chunk -> (tap, channel block): wave-uniform
+    __device__ __forceinline__ void chunk(int kc, uint32_t& soff, bool& ok, int& cb) const {
+        const int tap = kc / cblocks;
+        cb = (kc - tap * cblocks) * BK;
+        const int dy = tap / KW, dx = tap - dy * KW;
+        soff = (uint32_t)(cb * H * W + dy * W + dx) * 4u;
+        ok = m_ok && (unsigned)(iy0 + dy) < (unsigned)H && (unsigned)(ix0 + dx) < (unsigned)W;
+    }
+    __device__ __forceinline__ void issue_lds(int kc, float* dst) {
+        float* wbase = dst + (m_l - (int)(threadIdx.x & 63));
+        uint32_t soff; bool ok; int cb;
+        chunk(kc, soff, ok, cb);
+#pragma unroll
+        for (int j = 0; j < EPT; ++j)
+            bload_lds4(rsrc, wbase + (kb + STEP * j) * LD, (ok && cb + kb + STEP * j < C) ? voff[j] : OOB, soff);
+    }
+    __device__ __forceinline__ void issue(int kc) {
+        if constexpr (!DMA) {
+            uint32_t soff; bool ok; int cb;
+            chunk(kc, soff, ok, cb);
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) r[j] = bload(rsrc, (ok && cb + kb + STEP * j < C) ? voff[j] : OOB, soff);
+        }
+    }
+    __device__ __forceinline__ void commit(float* dst) const {
+        if constexpr (!DMA) {
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) dst[(kb + STEP * j) * LD + m_l] = r[j];
+        }
+    }
+};
+
+// transposed conv, phase (py, px), tap-major: A[m = (n, a, b)][k = (tap, ko)] = y[n][ko][oy0 - ty][ox0 - tx] with
+// tap = ty * nx + tx over the phase's own ny x nx taps (dg_taps); the weight rows of a phase are packed in the
+// same order (pack_dgrad_tap_kernel), so phases with fewer taps simply have fewer chunks.
+template <int BM, int KH, int KW, int S, int P>
+struct ConvDgALoaderTap {
+    static constexpr int TY = (KH + S - 1) / S, TX = (KW + S - 1) / S;
+    static constexpr int TAPS = TY * TX;
+    static constexpr bool UNIFORM = false;      // phases have their own chunk counts (run_dgrad passes them)
+    struct Params {
+        const float* y;
+        ConvShape s;
+        int AH, AW;
+        FastDiv div_ahw, div_aw;
+    };
+    static constexpr int LD = BM;
+    static constexpr int EPT = BM * BK / NT;
+    static constexpr int STEP = NT / BM;
+    static constexpr bool DMA = GZ_IGEMM_DMA;
+    static constexpr int NPARTS = 0;
+    __device__ __forceinline__ void issue_lds_part(int, float*, int) {}
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[EPT];
+    int kb, m_l, oy0, ox0, K, OH, OW, kblocks, nx_p;
+    bool m_ok;
+    float r[DMA ? 1 : EPT];
+    __device__ __forceinline__ void init(const Params& p, int tile, int phase, int tid) {
+        const ConvShape& s = p.s;
+        const uint32_t shift = (uint32_t)((TY - 1) * s.OW + (TX - 1)) * 4u;
+        rsrc = make_rsrc(reinterpret_cast<const char*>(p.y) - shift, (uint32_t)s.N * s.K * s.OH * s.OW * 4u + shift);
+        m_l = tid % BM;
+        kb = tid / BM;
+        const int py = phase / S, px = phase % S;
+        nx_p = dg_taps(KW, S, P, px);
+        uint32_t m = (uint32_t)tile * BM + m_l;
+        m_ok = m < (uint32_t)s.N * p.AH * p.AW;
+        uint32_t n = fdiv(m, p.div_ahw);
+        uint32_t pix = m - n * (uint32_t)(p.AH * p.AW);
+        uint32_t a = fdiv(pix, p.div_aw);
+        uint32_t b = pix - a * (uint32_t)p.AW;
+        oy0 = (int)a + (py + P) / S;
+        ox0 = (int)b + (px + P) / S;
+        K = s.K; OH = s.OH; OW = s.OW;
+        kblocks = round_bk(s.K) / BK;
+        // voffsets address (oy0 - (TY-1), ox0 - (TX-1)) through the shifted base; the chunk's scalar offset
+        // walks forward from there to (oy0 - ty, ox0 - tx)
+        const int pos = (int)(n * (uint32_t)(s.K * s.OH * s.OW)) + oy0 * OW + ox0;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) voff[j] = (uint32_t)(pos + (kb + STEP * j) * OH * OW) * 4u;
+    }
+    __device__ __forceinline__ void chunk(int kc, uint32_t& soff, bool& ok, int& kob) const {
+        const int tap = kc / kblocks;
+        kob = (kc - tap * kblocks) * BK;
+        const int ty = tap / nx_p, tx = tap - ty * nx_p;
+        soff = (uint32_t)(kob * OH * OW + (TY - 1 - ty) * OW + (TX - 1 - tx)) * 4u;
+        ok = m_ok && (unsigned)(oy0 - ty) < (unsigned)OH && (unsigned)(ox0 - tx) < (unsigned)OW;
+    }
+    __device__ __forceinline__ void issue_lds(int kc, float* dst) {
+        float* wbase = dst + (m_l - (int)(threadIdx.x & 63));
+        uint32_t soff; bool ok; int kob;
+        chunk(kc, soff, ok, kob);
+#pragma unroll
+        for (int j = 0; j < EPT; ++j)
+            bload_lds4(rsrc, wbase + (kb + STEP * j) * LD, (ok && kob + kb + STEP * j < K) ? voff[j] : OOB, soff);
+    }
+    __device__ __forceinline__ void issue(int kc) {
+        if constexpr (!DMA) {
+            uint32_t soff; bool ok; int kob;
+            chunk(kc, soff, ok, kob);
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) r[j] = bload(rsrc, (ok && kob + kb + STEP * j < K) ? voff[j] : OOB, soff);
+        }
+    }
+    __device__ __forceinline__ void commit(float* dst) const {
+        if constexpr (!DMA) {
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) dst[(kb + STEP * j) * LD + m_l] = r[j];
+        }
+    }
+};
+
 // Forward loader for KW == 4, KH*KW == 16 (the k4 s2 p1 layers): the four kx taps of one (c, ky) are four
 // consecutive floats of an input row, so each lane gathers them with ONE 16-byte load (dword aligned)
 // instead of four 4-byte loads -- a chunk (one input channel) needs 2 vector loads per lane instead of 8.
@@ -426,16 +588,36 @@ struct ConvDgALoader {
     static constexpr int LD = BM;
     static constexpr int EPT = BM * BK / NT;
     static constexpr int STEP = NT / BM;
-    static constexpr bool FIXED = (BK % TAPS == 0);  // a chunk is BK/TAPS whole feature channels
+    // every phase has TY x TX real taps iff the stride divides the kernel size; otherwise (k5 s2: 3 or 2 per
+    // axis) the phase's own counts ty_p x tx_p index its tightly packed weight rows
+    static constexpr bool UNIFORM = (KH % S == 0) && (KW % S == 0);
+    static constexpr bool FIXED = UNIFORM && (BK % TAPS == 0);  // a chunk is BK/TAPS whole feature channels
     static constexpr bool DMA = GZ_IGEMM_DMA;
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff[FIXED ? EPT : 1];
     uint32_t nbase;
-    int kb, m_l, oy0, ox0, K, OH, OW;
+    int kb, m_l, oy0, ox0, K, OH, OW, ty_p, tx_p;
     bool m_ok;
     float r[DMA ? 1 : EPT];
+    template <int TYP, int TXP>
+    __device__ __forceinline__ uint32_t tap_voff_phase(int kc, int j) const {
+        constexpr int TP = TYP * TXP;
+        if constexpr (TP == 0) {
+            return OOB;
+        } else {
+            int k = kc * BK + kb + STEP * j;
+            int ko = k / TP;
+            int tap = k - ko * TP;
+            int oy = oy0 - tap / TXP, ox = ox0 - tap % TXP;
+            bool ok = m_ok && ko < K && (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
+            return ok ? (nbase + (uint32_t)((ko * OH + oy) * OW + ox)) * 4u : OOB;
+        }
+    }
     __device__ __forceinline__ uint32_t tap_voff(int kc, int j) const {
-        if constexpr (FIXED) {
+        if constexpr (!UNIFORM) {      // wave-uniform branches: the phase is a workgroup property
+            if (ty_p == TY) return tx_p == TX ? tap_voff_phase<TY, TX>(kc, j) : tap_voff_phase<TY, TX - 1>(kc, j);
+            return tx_p == TX ? tap_voff_phase<TY - 1, TX>(kc, j) : tap_voff_phase<TY - 1, TX - 1>(kc, j);
+        } else if constexpr (FIXED) {
             // feature channels past K only occur in a partial last chunk; their weights are zero-padded
             // but the reads must stay inside the tensor: the soffset is not range checked.
             int kol = (kb + STEP * j) / TAPS;
@@ -467,6 +649,8 @@ struct ConvDgALoader {
         m_l = tid % BM;
         kb = tid / BM;
         int py = phase / S, px = phase % S;
+        ty_p = dg_taps(KH, S, P, py);
+        tx_p = dg_taps(KW, S, P, px);
         uint32_t m = (uint32_t)tile * BM + m_l;
         m_ok = m < (uint32_t)s.N * p.AH * p.AW;
         uint32_t n = fdiv(m, p.div_ahw);
@@ -833,10 +1017,10 @@ struct Conv3DDgALoader {
     __device__ __forceinline__ void issue_lds(int, float*) {}
     static constexpr int EPT = BM * BK / NT;
     static constexpr int STEP = NT / BM;
-    static_assert(BK % TAPS == 0, "a chunk must hold whole feature channels");
+    static_assert(BK % TAPS == 0 && T <= 2, "a chunk must hold whole feature channels; 1 or 2 taps per axis");
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff[EPT];
-    int kb, m_l, K, OSP;
+    int kb, m_l, K, OSP, lt;     // lt = log2(taps of this phase): a chunk is BK >> lt whole feature channels
     float r[EPT];
     __device__ __forceinline__ void init(const Params& p, int tile, int phase, int tid) {
         const Conv3DShape& s = p.s;
@@ -844,6 +1028,9 @@ struct Conv3DDgALoader {
         m_l = tid % BM;
         kb = tid / BM;
         const int pd = phase / (S * S), py = (phase / S) % S, px = phase % S;
+        // per-axis tap counts of this phase (1 or 2), as shifts: the phase's weight rows are packed tightly
+        const int sd = dg_taps(KS, S, P, pd) - 1, sy = dg_taps(KS, S, P, py) - 1, sx = dg_taps(KS, S, P, px) - 1;
+        lt = sd + sy + sx;
         uint32_t m = (uint32_t)tile * BM + m_l;
         bool m_ok = m < (uint32_t)s.N * p.AD * p.AH * p.AW;
         uint32_t n = fdiv(m, p.div_adhw);
@@ -859,19 +1046,20 @@ struct Conv3DDgALoader {
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
             int kk = kb + STEP * j;
-            int kol = kk / TAPS, tap = kk % TAPS;
-            int od = od0 - tap / (T * T), oy = oy0 - (tap / T) % T, ox = ox0 - tap % T;
+            int kol = kk >> lt, tap = kk & ((1 << lt) - 1);
+            int tx = tap & sx, ty = (tap >> sx) & sy, td = tap >> (sx + sy);
+            int od = od0 - td, oy = oy0 - ty, ox = ox0 - tx;
             bool ok = m_ok && (unsigned)od < (unsigned)s.OD && (unsigned)oy < (unsigned)s.OH &&
                       (unsigned)ox < (unsigned)s.OW;
             voff[j] = ok ? (nbase + (uint32_t)(kol * OSP + (od * s.OH + oy) * s.OW + ox)) * 4u : OOB;
         }
     }
     __device__ __forceinline__ void issue(int kc) {
-        uint32_t soff = (uint32_t)kc * (uint32_t)((BK / TAPS) * OSP) * 4u;
-        int ko_base = kc * (BK / TAPS);
+        const int ko_base = kc * (BK >> lt);
+        uint32_t soff = (uint32_t)ko_base * (uint32_t)OSP * 4u;
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            int kol = (kb + STEP * j) / TAPS;
+            int kol = (kb + STEP * j) >> lt;
             r[j] = bload(rsrc, ko_base + kol < K ? voff[j] : OOB, soff);
         }
     }
@@ -953,6 +1141,7 @@ struct Wg3DBLoader {
 
 // C[z][m][n] row-major (n contiguous): wgrad slabs, plain GEMM.  Optional bias[n] + activation.
 struct EpiRowMajor {
+    static constexpr bool SWAP = false;   // lanes run along n, the contiguous dimension of the row-major output
     struct Params {
         float* c;
         int M, N, ldc;
@@ -983,10 +1172,12 @@ struct EpiRowMajor {
     }
 };
 
-// NCHW feature map: row m = (n, pix), column = channel.  4 consecutive registers are 4
-// consecutive pixels of one channel -> one 16-byte store per lane (needs OHW % 4 == 0,
-// otherwise scalar stores).  Optional bias[channel] + activation.
+// NCHW feature map: row m = (n, pix), column = channel.  Pixels are the contiguous dimension, so the tile is
+// accumulated transposed (SWAP: the MFMA operands trade places, D'[channel][m]): a lane owns one pixel, its 16
+// registers are 16 channels, and every store instruction writes 32 consecutive pixels of one channel (128 B
+// per half-wave) instead of 64 pieces in 64 different channel planes.  Optional bias[channel] + activation.
 struct EpiNCHW {
+    static constexpr bool SWAP = true;
     struct Params {
         float* out;
         int M, CH, HW;           // M = N*HW rows, CH channels
@@ -999,35 +1190,21 @@ struct EpiNCHW {
     __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
                                                  int n_base, int lane, int y, int z) {
         const int col_l = lane & 31, half = lane >> 5;
-        const bool vec = (p.HW & 3) == 0;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            int ch = n_base + j * 32 + col_l;
-            if (ch >= p.CH) continue;
-            float bv = p.bias ? p.bias[ch] : 0.f;
+        for (int i = 0; i < TM; ++i) {
+            const int m = m_base + i * 32 + col_l;
+            if (m >= p.M) continue;
+            const uint32_t n = fdiv((uint32_t)m, p.div_hw);
+            const uint32_t pix = (uint32_t)m - n * (uint32_t)p.HW;
+            float* base = p.out + (long long)n * p.CH * p.HW + pix;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+            for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    int m = m_base + i * 32 + 8 * g + 4 * half;
-                    if (m >= p.M) continue;
-                    f32x4 v;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = act_fwd(acc[i][j][4 * g + q] + bv, p.act, p.slope);
-                    if (vec) {
-                        uint32_t n = fdiv((uint32_t)m, p.div_hw);
-                        uint32_t pix = (uint32_t)m - n * (uint32_t)p.HW;
-                        *reinterpret_cast<f32x4*>(p.out + ((long long)n * p.CH + ch) * p.HW + pix) = v;
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            int mq = m + q;
-                            if (mq < p.M) {
-                                uint32_t n = fdiv((uint32_t)mq, p.div_hw);
-                                uint32_t pix = (uint32_t)mq - n * (uint32_t)p.HW;
-                                p.out[((long long)n * p.CH + ch) * p.HW + pix] = v[q];
-                            }
-                        }
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = n_base + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (ch < p.CH) {
+                        float bv = p.bias ? p.bias[ch] : 0.f;
+                        base[(long long)ch * p.HW] = act_fwd(acc[i][j][r] + bv, p.act, p.slope);
                     }
                 }
             }
@@ -1036,9 +1213,11 @@ struct EpiNCHW {
 };
 
 // dgrad / transposed-conv output: row m = (n, a, b) of phase y=(py,px) goes to
-// x[n][c][S*a+py][S*b+px].  Optional bias[c] + activation.
+// x[n][c][S*a+py][S*b+px].  Accumulated transposed like EpiNCHW: a store instruction covers 32 consecutive b of
+// one channel (every S-th float of a row).  Optional bias[c] + activation.
 template <int S>
 struct EpiPhase {
+    static constexpr bool SWAP = true;
     struct Params {
         float* out;
         int M, C, H, W, AH, AW;
@@ -1052,43 +1231,24 @@ struct EpiPhase {
                                                  int n_base, int lane, int y, int z) {
         const int col_l = lane & 31, half = lane >> 5;
         const int py = y / S, px = y % S;
-        const bool quad = (p.AW & 3) == 0;      // 4 consecutive rows = 4 consecutive b of one (n, a)
+        const long long chs = (long long)p.H * p.W;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int m = m_base + i * 32 + col_l;
+            if (m >= p.M) continue;
+            uint32_t n = fdiv((uint32_t)m, p.div_ahw);
+            uint32_t pix = (uint32_t)m - n * (uint32_t)(p.AH * p.AW);
+            uint32_t a = fdiv(pix, p.div_aw);
+            uint32_t b = pix - a * (uint32_t)p.AW;
+            float* base = p.out + ((long long)n * p.C * p.H + (S * a + py)) * p.W + (S * b + px);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int m0 = m_base + i * 32 + 8 * g + 4 * half;
-                long long o0 = 0;
-                if (quad) {
-                    if (m0 >= p.M) continue;
-                    uint32_t n = fdiv((uint32_t)m0, p.div_ahw);
-                    uint32_t pix = (uint32_t)m0 - n * (uint32_t)(p.AH * p.AW);
-                    uint32_t a = fdiv(pix, p.div_aw);
-                    uint32_t b = pix - a * (uint32_t)p.AW;
-                    o0 = ((long long)n * p.C * p.H + (S * a + py)) * p.W + (S * b + px);
-                }
+            for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    long long o;
-                    if (quad) {
-                        o = o0 + S * q;
-                    } else {
-                        int m = m0 + q;
-                        if (m >= p.M) continue;
-                        uint32_t n = fdiv((uint32_t)m, p.div_ahw);
-                        uint32_t pix = (uint32_t)m - n * (uint32_t)(p.AH * p.AW);
-                        uint32_t a = fdiv(pix, p.div_aw);
-                        uint32_t b = pix - a * (uint32_t)p.AW;
-                        o = ((long long)n * p.C * p.H + (S * a + py)) * p.W + (S * b + px);
-                    }
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        int c = n_base + j * 32 + col_l;
-                        if (c < p.C) {
-                            float bv = p.bias ? p.bias[c] : 0.f;
-                            p.out[o + (long long)c * p.H * p.W] =
-                                act_fwd(acc[i][j][4 * g + q] + bv, p.act, p.slope);
-                        }
+                for (int r = 0; r < 16; ++r) {
+                    const int c = n_base + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (c < p.C) {
+                        float bv = p.bias ? p.bias[c] : 0.f;
+                        base[(long long)c * chs] = act_fwd(acc[i][j][r] + bv, p.act, p.slope);
                     }
                 }
             }
@@ -1097,9 +1257,10 @@ struct EpiPhase {
 };
 
 // 3-D transposed-conv output: row m = (n, a, b, c) of phase y = (pd, py, px) goes to
-// x[n][ch][S*a+pd][S*b+py][S*c+px].  Optional bias[ch] + activation.
+// x[n][ch][S*a+pd][S*b+py][S*c+px] (transposed accumulation, lanes along c).  Optional bias[ch] + activation.
 template <int S>
 struct EpiPhase3D {
+    static constexpr bool SWAP = true;
     struct Params {
         float* out;
         int M, C, D, H, W, AD, AH, AW;
@@ -1116,24 +1277,24 @@ struct EpiPhase3D {
         const long long chs = (long long)p.D * p.H * p.W;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int m = m_base + i * 32 + col_l;
+            if (m >= p.M) continue;
+            uint32_t n = fdiv((uint32_t)m, p.div_adhw);
+            uint32_t v = (uint32_t)m - n * (uint32_t)(p.AD * p.AH * p.AW);
+            uint32_t a = fdiv(v, p.div_ahw);
+            v -= a * (uint32_t)(p.AH * p.AW);
+            uint32_t b = fdiv(v, p.div_aw);
+            uint32_t c = v - b * (uint32_t)p.AW;
+            float* base = p.out + (long long)n * p.C * chs + ((long long)(S * a + pd) * p.H + (S * b + py)) * p.W +
+                          (S * c + px);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m >= p.M) continue;
-                uint32_t n = fdiv((uint32_t)m, p.div_adhw);
-                uint32_t v = (uint32_t)m - n * (uint32_t)(p.AD * p.AH * p.AW);
-                uint32_t a = fdiv(v, p.div_ahw);
-                v -= a * (uint32_t)(p.AH * p.AW);
-                uint32_t b = fdiv(v, p.div_aw);
-                uint32_t c = v - b * (uint32_t)p.AW;
-                long long o = (long long)n * p.C * chs + ((long long)(S * a + pd) * p.H + (S * b + py)) * p.W +
-                              (S * c + px);
+            for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    int ch = n_base + j * 32 + col_l;
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = n_base + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     if (ch < p.C) {
                         float bv = p.bias ? p.bias[ch] : 0.f;
-                        p.out[o + (long long)ch * chs] = act_fwd(acc[i][j][r] + bv, p.act, p.slope);
+                        base[(long long)ch * chs] = act_fwd(acc[i][j][r] + bv, p.act, p.slope);
                     }
                 }
             }
@@ -1153,23 +1314,32 @@ struct GridMap {
     // splitk_finish_kernel<Epi> sums the slabs and applies the real epilogue.  Null: Epi::store directly.
     float* slab;
     int slab_m, slab_n;
+    // transposed convolutions whose phases have different tap counts (k3 s2, k5 s2): chunks of phase y
+    int var_chunks;
+    int phase_chunks[8];
 };
 
-template <int TM, int TN>
+// SWAP (transposed accumulators, lanes along m): the slab is kept [n][m] so that its stores and the finish
+// kernel's loads stay contiguous along the lanes; otherwise [m][n].
+template <bool SWAP, int TM, int TN>
 __device__ __forceinline__ void store_slab(const GridMap& gm, f32x16 (&acc)[TM][TN], int m_base, int n_base, int lane,
                                            int slab_idx) {
     float* c = gm.slab + (long long)slab_idx * gm.slab_m * gm.slab_n;
     const int col_l = lane & 31, half = lane >> 5;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        int n = n_base + j * 32 + col_l;
-        if (n >= gm.slab_n) continue;
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < gm.slab_m) c[(long long)m * gm.slab_n + n] = acc[i][j][r];
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+                if constexpr (SWAP) {
+                    int m = m_base + i * 32 + col_l, n = n_base + j * 32 + rr;
+                    if (m < gm.slab_m && n < gm.slab_n) c[(long long)n * gm.slab_m + m] = acc[i][j][r];
+                } else {
+                    int m = m_base + i * 32 + rr, n = n_base + j * 32 + col_l;
+                    if (m < gm.slab_m && n < gm.slab_n) c[(long long)m * gm.slab_n + n] = acc[i][j][r];
+                }
             }
         }
     }
@@ -1208,7 +1378,7 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
     const int tile_m = bid / gm.tiles_n;
     const int z = blockIdx.z;
     const int kc0 = z * gm.chunks_per_split;
-    const int kc1 = min(gm.chunks, kc0 + gm.chunks_per_split);
+    const int kc1 = min(gm.var_chunks ? gm.phase_chunks[y] : gm.chunks, kc0 + gm.chunks_per_split);
 
     AL al;
     BL bl;
@@ -1276,7 +1446,10 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i], bf[c][j], acc[i][j], 0, 0, 0);
+                    if constexpr (Epi::SWAP)      // D'[n][m]: lanes along m (see EpiNCHW)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[c][j], af[c][i], acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i], bf[c][j], acc[i][j], 0, 0, 0);
             // pin the order "next step's LDS reads, then this step's MFMAs" (hipcc otherwise sinks the
             // reads behind the MFMAs to save two registers)
             if constexpr (INTERLEAVE) {
@@ -1317,7 +1490,7 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
     if (acc[0][0][0] == 123456.789f)
 #endif
     if (gm.slab)
-        store_slab<TM, TN>(gm, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32, lane,
+        store_slab<Epi::SWAP, TM, TN>(gm, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32, lane,
                            y * (int)gridDim.z + z);
     else
         Epi::template store<TM, TN>(pe, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32,
@@ -1337,17 +1510,21 @@ __global__ __launch_bounds__(NT) void splitk_finish_kernel(const float* __restri
     const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m_base = tile_m * 32, n_base = tile_n * 32;
-    const int col = n_base + (lane & 31), half = lane >> 5;
+    const int col_l = lane & 31, half = lane >> 5;
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-    if (col < N) {
-        for (int z = wave; z < nz; z += 4) {
-            const float* c = slab + (long long)(y * nz + z) * M * N;
+    for (int z = wave; z < nz; z += 4) {
+        const float* c = slab + (long long)(y * nz + z) * M * N;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < M) acc[0][0][r] += c[(long long)m * N + col];
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if constexpr (Epi::SWAP) {
+                int m = m_base + col_l, n = n_base + rr;
+                if (m < M && n < N) acc[0][0][r] += c[(long long)n * M + m];
+            } else {
+                int m = m_base + rr, n = n_base + col_l;
+                if (m < M && n < N) acc[0][0][r] += c[(long long)m * N + n];
             }
         }
     }
@@ -1376,8 +1553,13 @@ inline int split_nz(int K, int splits) {
 template <class Cfg, class AL, class BL, class Epi>
 inline int launch_igemm(const typename AL::Params& pa, const typename BL::Params& pb,
                         const typename Epi::Params& pe, int M, int N, int K, int ny, int splits,
-                        hipStream_t stream, float* slab = nullptr) {
+                        hipStream_t stream, float* slab = nullptr, const int* phase_chunks = nullptr) {
     GridMap gm;
+    gm.var_chunks = 0;
+    if (phase_chunks && ny <= 8) {
+        gm.var_chunks = 1;
+        for (int i = 0; i < ny; ++i) gm.phase_chunks[i] = phase_chunks[i];
+    }
     gm.slab = nullptr;
     gm.slab_m = M;
     gm.slab_n = N;

@@ -732,9 +732,10 @@ def _conv3d_fwd_raw(x, w, bias, act, slope):
     OD, OH, OW = D // 2, H // 2, W // 2
     y = torch.empty((N, K, OD, OH, OW), device=x.device, dtype=torch.float32)
     wp = _packed3(w, "f")
+    ws, nbytes = _scratch(lib.gz_conv3d_fwd_workspace_bytes(N, C, K, OD, OH, OW, KS), x.device)
     _timed_detail(lambda: "igemm3d<F> N%d C%d D%d K%d" % (N, C, D, K), 2.0 * N * OD * OH * OW * K * C * KS ** 3,
-                  lambda: check(lib.gz_conv3d_fwd(_p(x), _p(wp), _p(bias), _p(y), N, C, D, H, W, K, OD, OH, OW, KS, 2, 1,
-                                                  act, slope, _stream()), "conv3d_fwd"))
+                  lambda: check(lib.gz_conv3d_fwd(_p(x), _p(wp), _p(bias), _p(y), _p(ws), nbytes, N, C, D, H, W, K, OD,
+                                                  OH, OW, KS, 2, 1, act, slope, _stream()), "conv3d_fwd"))
     return y
 
 
@@ -744,9 +745,10 @@ def _conv3d_dgrad_raw(g, w, bias, act, slope):
     D, H, W = 2 * OD, 2 * OH, 2 * OW
     x = torch.empty((N, C, D, H, W), device=g.device, dtype=torch.float32)
     wp = _packed3(w, "d")
+    ws, nbytes = _scratch(lib.gz_conv3d_dgrad_workspace_bytes(N, C, K, OD, OH, OW, KS), g.device)
     _timed_detail(lambda: "igemm3d<Dg> N%d C%d D%d K%d" % (N, C, D, K), 2.0 * N * OD * OH * OW * K * C * KS ** 3,
-                  lambda: check(lib.gz_conv3d_dgrad(_p(g), _p(wp), _p(bias), _p(x), N, C, D, H, W, K, OD, OH, OW, KS, 2,
-                                                    1, act, slope, _stream()), "conv3d_dgrad"))
+                  lambda: check(lib.gz_conv3d_dgrad(_p(g), _p(wp), _p(bias), _p(x), _p(ws), nbytes, N, C, D, H, W, K,
+                                                    OD, OH, OW, KS, 2, 1, act, slope, _stream()), "conv3d_dgrad"))
     return x
 
 

@@ -65,8 +65,13 @@ def compose(expt, overrides, module_root=None):
             cfg[tgt[0]][tgt[1]] = v
         if dotted == "train.img_size":
             for net in ("discriminator", "generator"):
-                if "img_size" in cfg[net]:
-                    cfg[net]["img_size"] = v
+                for key in ("img_size", "size"):       # `size: ${train.img_size}` in gan_stability_r1.yaml
+                    if key in cfg[net]:
+                        cfg[net][key] = v
+        if dotted == "model.noise_dim":
+            for net in ("discriminator", "generator"):
+                if "z_dim" in cfg[net]:                # `z_dim: ${model.noise_dim}`
+                    cfg[net]["z_dim"] = v
         if dotted.startswith("optimisation.lr"):
             for o in ("disc_optimiser", "gen_optimiser", "optimiser"):
                 cfg[o]["lr"] = v

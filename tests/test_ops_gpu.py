@@ -216,7 +216,8 @@ def test_gp_tail_ops():
 # ---------------------------------------------------------------------------
 # HoloGAN operators
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("case", [(2, 8, 4, 4), (3, 20, 4, 12), (4, 64, 8, 16), (2, 128, 4, 130)])
+@pytest.mark.parametrize("case", [(2, 8, 4, 4), (3, 20, 4, 12), (4, 64, 8, 16), (2, 128, 4, 130),
+                                  (8, 512, 4, 128)])      # last: few output tiles -> split-K forward and dgrad
 def test_conv3d_family(case):
     """ConvTranspose3d(k3,s2,p1,op1) forward (Dg), its input gradient (F) and weight gradient (Wg)."""
     F = _F()

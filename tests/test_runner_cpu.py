@@ -17,6 +17,11 @@ def test_override_grammar_and_derived_values():
     assert cfg.generator.features_g == 8 and cfg.discriminator.features_d == 8
     assert cfg.generator.channels_noise == 16 and cfg.discriminator.norm == "instance_norm2d"
     assert cfg.disc_optimiser.lr == 0.001 and cfg.loss_weight.lambda_gp == 10
+    expt, ov, _ = R.parse_overrides(["+expt=gan_stability_r1", "train.img_size=32", "model.noise_dim=24",
+                                     "loss_weight.reg=3.5"])
+    cfg = R.compose(expt, ov)
+    assert cfg.generator.size == 32 and cfg.discriminator.size == 32 and cfg.generator.z_dim == 24
+    assert cfg.loss_weight.reg == 3.5 and cfg.model.lm["_target_"].endswith("GANStabilityR1")
     with pytest.raises(SystemExit):
         R.compose("dc_gan", {"train.no_such_key": 1})
     with pytest.raises(SystemExit):
