@@ -478,6 +478,138 @@ static int dispatch_dgrad(const float* y, const float* wp, const float* bias, fl
 }
 
 // ---------------------------------------------------------------------------
+// Wg of 3x3 s1 p1 layers with <= 32 channels on both sides (the 128x128 / 64x64 stages of the R1 ResNets, the
+// image-side convolutions).  As an implicit GEMM this is M = K <= 32 rows of a 64-row tile: three quarters of
+// the MFMA work multiplies padding.  Here one wavefront owns 16 consecutive pixels of one image row and issues
+// v_mfma_f32_16x16x4_f32 with A = y[ko][4 pixels], B = x[c][the same 4 pixels shifted by the tap]: 9 * KT * CT
+// exact 16x16 tiles, nothing padded.  Lane (i = l & 15, q = l >> 4) loads ONE aligned float4 per operand row i
+// (pixels 4q..4q+3); the dx = -1 / +1 taps are assembled from the neighbouring lanes' vectors (lane +-16) plus
+// one edge dword, rows in the vertical padding are skipped wave-uniformly.  Each workgroup sums its four
+// wavefronts through LDS in a fixed order and writes one slab; reduce_slabs_kernel adds the slabs.
+// ---------------------------------------------------------------------------
+template <int KT, int CT>
+__global__ __launch_bounds__(256) void wgrad_smallch_k3_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                               float* __restrict__ slab, ConvShape s, int groups,
+                                                               FastDiv div_seg, FastDiv div_h) {
+    constexpr int NACC = KT * CT * 9;
+    __shared__ float red[KT * CT * 9 * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int H = s.H, W = s.W, HW = s.H * s.W;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (uint32_t)s.N * s.C * HW * 4u);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y, (uint32_t)s.N * s.K * HW * 4u);
+    f32x4 acc[KT][CT][9];
+#pragma unroll
+    for (int a = 0; a < KT; ++a)
+#pragma unroll
+        for (int b = 0; b < CT; ++b)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[a][b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int segs = W >> 4;
+    const int nwaves = gridDim.x * 4;
+    for (int g = blockIdx.x * 4 + wave; g < groups; g += nwaves) {
+        const uint32_t rowid = fdiv((uint32_t)g, div_seg);               // n * H + h
+        const int w0 = (g - (int)rowid * segs) << 4;
+        const uint32_t n = fdiv(rowid, div_h);
+        const int h = (int)(rowid - n * (uint32_t)H);
+        const int wq = w0 + 4 * q;
+        f32x4 yv[KT];
+#pragma unroll
+        for (int a = 0; a < KT; ++a) {
+            const int ko = a * 16 + i;
+            yv[a] = bload4(ry, ko < s.K ? ((n * (uint32_t)s.K + ko) * (uint32_t)HW + (uint32_t)(h * W + wq)) * 4u : OOB, 0);
+        }
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int hh = h + dy - 1;
+            if ((unsigned)hh >= (unsigned)H) continue;                   // wave-uniform: a padding row contributes nothing
+#pragma unroll
+            for (int b = 0; b < CT; ++b) {
+                const int c = b * 16 + i;
+                const uint32_t base = ((n * (uint32_t)s.C + c) * (uint32_t)HW + (uint32_t)(hh * W + wq)) * 4u;
+                const bool cok = c < s.C;
+                const f32x4 cv = bload4(rx, cok ? base : OOB, 0);
+                // the pixel left of this lane's vector: lane - 16 holds it, except for q == 0 (previous segment / padding)
+                float left = __shfl_up(cv[3], 16, 64);
+                float right = __shfl_down(cv[0], 16, 64);
+                const float el = bload(rx, (cok && q == 0 && wq > 0) ? base - 4u : OOB, 0);
+                const float er = bload(rx, (cok && q == 3 && wq + 4 < W) ? base + 16u : OOB, 0);
+                if (q == 0) left = el;
+                if (q == 3) right = er;
+                const f32x4 lv = {left, cv[0], cv[1], cv[2]};
+                const f32x4 rv = {cv[1], cv[2], cv[3], right};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int a = 0; a < KT; ++a) {
+                        acc[a][b][dy * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a][j], lv[j], acc[a][b][dy * 3 + 0], 0, 0, 0);
+                        acc[a][b][dy * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a][j], cv[j], acc[a][b][dy * 3 + 1], 0, 0, 0);
+                        acc[a][b][dy * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv[a][j], rv[j], acc[a][b][dy * 3 + 2], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // workgroup sum in a fixed order: wave 0 stores, waves 1..3 add in turn
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < KT; ++a)
+#pragma unroll
+                for (int b = 0; b < CT; ++b)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* dst = &red[(((a * CT + b) * 9 + t) * 4 + r) * 64 + lane];
+                            *dst = (w == 0 ? 0.f : *dst) + acc[a][b][t][r];
+                        }
+        }
+        __syncthreads();
+    }
+    // D layout of the 16x16 tile: register r of lane l is (row 4 * (l >> 4) + r, column l & 15) = (ko, c)
+    float* out = slab + (long long)blockIdx.x * s.K * s.C * 9;
+    for (int e = threadIdx.x; e < NACC * 256; e += 256) {
+        const int l = e & 63, r = (e >> 6) & 3, rest = e >> 8;
+        const int t = rest % 9, ab = rest / 9;
+        const int ko = (ab / CT) * 16 + 4 * (l >> 4) + r, c = (ab % CT) * 16 + (l & 15);
+        if (ko < s.K && c < s.C) out[((long long)ko * s.C + c) * 9 + t] = red[e];
+    }
+}
+
+static bool wgrad_smallch_ok(const ConvShape& s, int KH, int KW, int S, int P) {
+    static int off = getenv("GZ_NO_SMALLCH_WG") ? 1 : 0;
+    return !off && KH == 3 && KW == 3 && S == 1 && P == 1 && s.K <= 32 && s.C <= 32 && (s.W & 15) == 0 &&
+           (long long)s.N * s.H * s.W >= 65536;
+}
+
+static int wgrad_smallch_blocks(const ConvShape& s) {
+    long long groups = (long long)s.N * s.H * (s.W >> 4);
+    long long blocks = (groups + 15) / 16;          // >= 4 pixel groups per wavefront
+    return (int)(blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks));
+}
+
+static int run_wgrad_smallch(const float* x, const float* y, float* dw, float* ws, size_t ws_bytes, const ConvShape& s,
+                             hipStream_t st) {
+    const int blocks = wgrad_smallch_blocks(s);
+    const long long count = (long long)s.K * s.C * 9;
+    if (!ws || ws_bytes < (size_t)blocks * count * 4) return GZ_ERR_WORKSPACE;
+    const int groups = s.N * s.H * (s.W >> 4);
+    const FastDiv dseg = make_fastdiv(s.W >> 4), dh = make_fastdiv(s.H);
+    const int kt = (s.K + 15) / 16, ct = (s.C + 15) / 16;
+#define GZ_SMALLCH(KT_, CT_) \
+    hipLaunchKernelGGL((wgrad_smallch_k3_kernel<KT_, CT_>), dim3(blocks), dim3(256), 0, st, x, y, ws, s, groups, dseg, dh)
+    if (kt == 1 && ct == 1) GZ_SMALLCH(1, 1);
+    else if (kt == 1) GZ_SMALLCH(1, 2);
+    else if (ct == 1) GZ_SMALLCH(2, 1);
+    else GZ_SMALLCH(2, 2);
+#undef GZ_SMALLCH
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64 * RS_WAVES), 0, st, ws, dw,
+                       blocks, count);
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------
 // Wg
 // ---------------------------------------------------------------------------
 static int wg_target() {
@@ -719,6 +851,8 @@ int gz_conv2d_dgrad(const float* y, const float* wpack, const float* bias, float
 
 size_t gz_conv2d_wgrad_workspace_bytes(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW) {
     long long count = (long long)K * C * KH * KW;
+    ConvShape s{N, C, H, W, K, OH, OW};
+    if (OH == H && OW == W && wgrad_smallch_ok(s, KH, KW, 1, 1)) return (size_t)wgrad_smallch_blocks(s) * count * 4;
     int chunks = (N * OH * OW + BK - 1) / BK;
     // upper bound over the tile choices: smallest tile count is with 128x128 tiles
     long long tiles = (long long)((K + 127) / 128) * ((C * KH * KW + 127) / 128);
@@ -732,6 +866,7 @@ int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* workspace,
     ConvShape s{N, C, H, W, K, OH, OW};
     if (!shape_ok(s, KH, KW, S, P)) return GZ_ERR_BAD_SHAPE;
     if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
+    if (wgrad_smallch_ok(s, KH, KW, S, P)) return run_wgrad_smallch(x, y, dw, workspace, ws_bytes, s, stream);
 #define CALL(G) dispatch_wgrad<G>(x, y, dw, workspace, ws_bytes, s, stream)
     GZ_GEOM_DISPATCH(CALL)
 #undef CALL

@@ -552,3 +552,21 @@ def test_gemm_split_k(shape, tb):
     assert rel(c, ref) < TOL
     c2 = F.gemm(a.t().contiguous().cuda(), bd, bias.cuda(), trans_a=True, trans_b=tb, act=F.ACT_RELU)
     assert rel(c2, ref) < TOL
+
+
+@pytest.mark.parametrize("case", [(16, 16, 64, 16), (4, 3, 128, 16), (4, 16, 128, 3), (16, 32, 64, 32),
+                                  (16, 16, 64, 32), (32, 20, 48, 24)])
+def test_wgrad_small_channel_3x3(case):
+    """The 16x16x4-MFMA weight-gradient kernel of 3x3 s1 p1 layers with <= 32 channels (R1 ResNet high-resolution
+    stages): against torch, and against the implicit-GEMM path it replaces (GZ_NO_SMALLCH_WG is read once per
+    process, so the comparison is with the CPU reference only)."""
+    F = _F()
+    from lightning_gan_zoo_amd._lib import lib
+    N, C, H, K = case
+    x, gy = rnd(N, C, H, H, seed=61), rnd(N, K, H, H, seed=62)
+    count = K * C * 9
+    assert lib.gz_conv2d_wgrad_workspace_bytes(N, C, H, H, K, H, H, 3, 3) >= 4 * count
+    dw_ref = torch.nn.grad.conv2d_weight(x.double(), (K, C, 3, 3), gy.double(), stride=1, padding=1)
+    dw = F._conv_wgrad_raw(x.cuda(), gy.cuda(), F.K3S1P1)
+    assert rel(dw, dw_ref) < TOL
+    assert torch.equal(dw, F._conv_wgrad_raw(x.cuda(), gy.cuda(), F.K3S1P1))      # fixed summation order
