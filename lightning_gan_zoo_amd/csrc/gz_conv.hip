@@ -478,8 +478,8 @@ static int dispatch_dgrad(const float* y, const float* wp, const float* bias, fl
 }
 
 // ---------------------------------------------------------------------------
-// Wg of 3x3 s1 p1 layers with <= 32 channels on both sides (the 128x128 / 64x64 stages of the R1 ResNets, the
-// image-side convolutions).  As an implicit GEMM this is M = K <= 32 rows of a 64-row tile: three quarters of
+// Wg of 3x3 s1 p1 layers with few channels (ceil(K/16) * ceil(C/16) <= 4: the 128x128 / 64x64 stages of the R1
+// ResNets, the image-side convolutions 64 -> 3 / 3 -> 16).  As an implicit GEMM this is M = K <= 32 rows of a 64-row tile: three quarters of
 // the MFMA work multiplies padding.  Here one wavefront owns 16 consecutive pixels of one image row and issues
 // v_mfma_f32_16x16x4_f32 with A = y[ko][4 pixels], B = x[c][the same 4 pixels shifted by the tap]: 9 * KT * CT
 // exact 16x16 tiles, nothing padded.  Lane (i = l & 15, q = l >> 4) loads ONE aligned float4 per operand row i
@@ -579,7 +579,8 @@ __global__ __launch_bounds__(256) void wgrad_smallch_k3_kernel(const float* __re
 
 static bool wgrad_smallch_ok(const ConvShape& s, int KH, int KW, int S, int P) {
     static int off = getenv("GZ_NO_SMALLCH_WG") ? 1 : 0;
-    return !off && KH == 3 && KW == 3 && S == 1 && P == 1 && s.K <= 32 && s.C <= 32 && (s.W & 15) == 0 &&
+    const int kt = (s.K + 15) / 16, ct = (s.C + 15) / 16;      // 16x16 tiles per tap: at most 4 (36 accumulators)
+    return !off && KH == 3 && KW == 3 && S == 1 && P == 1 && kt * ct <= 4 && (s.W & 15) == 0 &&
            (long long)s.N * s.H * s.W >= 65536;
 }
 
@@ -600,9 +601,11 @@ static int run_wgrad_smallch(const float* x, const float* y, float* dw, float* w
 #define GZ_SMALLCH(KT_, CT_) \
     hipLaunchKernelGGL((wgrad_smallch_k3_kernel<KT_, CT_>), dim3(blocks), dim3(256), 0, st, x, y, ws, s, groups, dseg, dh)
     if (kt == 1 && ct == 1) GZ_SMALLCH(1, 1);
-    else if (kt == 1) GZ_SMALLCH(1, 2);
-    else if (ct == 1) GZ_SMALLCH(2, 1);
-    else GZ_SMALLCH(2, 2);
+    else if (kt == 1 && ct == 2) GZ_SMALLCH(1, 2);
+    else if (kt == 2 && ct == 1) GZ_SMALLCH(2, 1);
+    else if (kt == 2 && ct == 2) GZ_SMALLCH(2, 2);
+    else if (kt == 1 && ct <= 4) GZ_SMALLCH(1, 4);
+    else GZ_SMALLCH(4, 1);
 #undef GZ_SMALLCH
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64 * RS_WAVES), 0, st, ws, dw,
                        blocks, count);

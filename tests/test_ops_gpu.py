@@ -555,7 +555,7 @@ def test_gemm_split_k(shape, tb):
 
 
 @pytest.mark.parametrize("case", [(16, 16, 64, 16), (4, 3, 128, 16), (4, 16, 128, 3), (16, 32, 64, 32),
-                                  (16, 16, 64, 32), (32, 20, 48, 24)])
+                                  (16, 16, 64, 32), (32, 20, 48, 24), (16, 64, 64, 3), (16, 5, 64, 50)])
 def test_wgrad_small_channel_3x3(case):
     """The 16x16x4-MFMA weight-gradient kernel of 3x3 s1 p1 layers with <= 32 channels (R1 ResNet high-resolution
     stages): against torch, and against the implicit-GEMM path it replaces (GZ_NO_SMALLCH_WG is read once per
