@@ -1573,7 +1573,8 @@ inline int launch_igemm(const typename AL::Params& pa, const typename BL::Params
     gm.ny = ny;
     dim3 grid(gm.tiles_m * gm.tiles_n * ny, 1, nz);
     if (slab && nz > 1) gm.slab = slab;
-    hipLaunchKernelGGL((igemm_kernel<Cfg, AL, BL, Epi>), grid, dim3(NT), 0, stream, pa, pb, pe, gm);
+    static int dyn_lds = getenv("GZ_DYN_LDS") ? atoi(getenv("GZ_DYN_LDS")) : 0;   // experiment: throttle workgroups per CU
+    hipLaunchKernelGGL((igemm_kernel<Cfg, AL, BL, Epi>), grid, dim3(NT), dyn_lds, stream, pa, pb, pe, gm);
     if (gm.slab) {
         const int fm = (M + 31) / 32, fn = (N + 31) / 32;
         hipLaunchKernelGGL((splitk_finish_kernel<Epi>), dim3(fm * fn * ny), dim3(NT), 0, stream, slab, nz, M, N, pe, fn,

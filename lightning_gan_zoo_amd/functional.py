@@ -29,7 +29,14 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    # the launchers take the caller's current stream explicitly; the raw query is ~10x cheaper than building a
+    # torch.cuda.Stream object per launch (0.6 ms per step at ~300 launches)
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -1,0 +1,60 @@
+"""HBM bytes per launch of every implicit-GEMM kernel from two rocprofv3 PMC passes.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dirA> -- python bench.py --steps 3 --warmup 1 \
+        --no-cpu-baseline --no-bs128 --no-kernel-timer
+    rocprofv3 --pmc WRITE_SIZE ... -d <dirB> -- (same)
+    python tools/pmc_traffic.py <dirA> <dirB> profiles/traffic.json profiles/<round>_traffic_pmc_detail.json
+
+traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes (MI355X_MICROARCH.md, HBM section: FETCH_SIZE under-reports
+reads by 2x on gfx950; the raw sum is kept in the detail file).  Labels match bench.py's roofline labels.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def label_of(name):
+    m = re.search(r"igemm_kernel<gz::TileCfg<(\d+), (\d+), (\d+), (\d+)>, gz::(\w+)<", name)
+    if not m:
+        return None
+    wm, wn, tm, tn = (int(m.group(i)) for i in range(1, 5))
+    loader = m.group(5)
+    if loader.startswith("ConvFwd"):
+        op = "F"
+    elif loader.startswith("ConvDg"):
+        op = "Dg"
+    elif loader.startswith("WgALoader"):
+        op = "Wg"
+    else:
+        return None
+    return "igemm<%s,%dx%d>" % (op, wm * tm * 32, wn * tn * 32)
+
+
+def collect(d, counter):
+    out = {}
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            if row.get("Counter_Name") != counter:
+                continue
+            lab = label_of(row["Kernel_Name"])
+            if lab:
+                n, tot = out.get(lab, (0, 0.0))
+                out[lab] = (n + 1, tot + float(row["Counter_Value"]))
+    return out
+
+
+fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+traffic, detail = {}, {}
+for lab in sorted(set(fetch) & set(write)):
+    nf, f = fetch[lab]
+    nw, w = write[lab]
+    fk, wk = f / nf, w / nw
+    traffic[lab] = int((2 * fk + wk) * 1024)
+    detail[lab] = {"launches_sampled": nf, "fetch_kb_raw": round(fk, 1), "write_kb": round(wk, 1),
+                   "hbm_bytes_per_launch_corrected": traffic[lab], "hbm_bytes_per_launch_raw": int((fk + wk) * 1024)}
+json.dump(traffic, open(sys.argv[3], "w"), indent=1)
+json.dump(detail, open(sys.argv[4], "w"), indent=1)
+print(json.dumps(detail, indent=1))
