@@ -478,6 +478,124 @@ static int dispatch_dgrad(const float* y, const float* wp, const float* bias, fl
 }
 
 // ---------------------------------------------------------------------------
+// F / Dg of 3x3 s1 p1 layers with <= 32 channels on both sides (same layers as wgrad_smallch below).  In the
+// 128x32 implicit-GEMM tile half of the MFMA columns are padding when K = 16 and the three kx taps of a row are
+// fetched three times.  Here a wavefront owns 16 consecutive pixels of one output row: B = x[4 channels][16
+// pixels] comes from ONE dword load per lane and row, the kx = -1 / +1 operands are the same registers shifted
+// by one lane (plus one predicated edge load), A = w[16 output channels][4 input channels] of the tap is read
+// from an LDS copy of the packed weights staged once per workgroup, and v_mfma_f32_16x16x4_f32 accumulates
+// D[output channel][pixel] -- stores are 64-byte runs per channel.  Dg is the same kernel on gy with the taps
+// mirrored (tap' = 8 - tap) and the roles of K and C exchanged; both read the weight images the implicit-GEMM
+// path uses (tap-major when the input side has >= 16 channels, (c, tap)-major otherwise).
+// ---------------------------------------------------------------------------
+template <int OT, int IT>     // 16-channel blocks on the output / input side
+__global__ __launch_bounds__(256) void conv3x3_smallch_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              int N, int CI, int CO, int H, int W, int groups,
+                                                              FastDiv div_seg, FastDiv div_h, int tap_major, int inpad,
+                                                              int ld, int flip, int act, float slope) {
+    constexpr int CB = IT * 4;                       // input-channel quads
+    __shared__ float Ws[9 * CB * OT * 64];           // [tap][cb][ot][q][i]
+    for (int e = threadIdx.x; e < 9 * CB * OT * 64; e += 256) {
+        const int i = e & 15, q = (e >> 4) & 3;
+        int rest = e >> 6;
+        const int ot = rest % OT;
+        rest /= OT;
+        const int cb = rest % CB, tap = rest / CB;
+        const int co = ot * 16 + i, ci = cb * 4 + q;
+        const int t = flip ? 8 - tap : tap;
+        float v = 0.f;
+        if (co < CO && ci < CI) v = wp[(long long)(tap_major ? t * inpad + ci : ci * 9 + t) * ld + co];
+        Ws[e] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int HW = H * W;
+    // descriptor moved back by one image row: the per-lane voffset addresses row h - 1 + 1 = h of channel q, the
+    // (row, channel-quad) step is a wave-uniform scalar offset, so the inner loop has no per-lane address math
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(reinterpret_cast<const char*>(in) - (size_t)W * 4,
+                                                 (uint32_t)N * CI * HW * 4u + (uint32_t)W * 4u);
+    const int segs = W >> 4;
+    const int nwaves = gridDim.x * 4;
+    for (int g = blockIdx.x * 4 + wave; g < groups; g += nwaves) {
+        const uint32_t rowid = fdiv((uint32_t)g, div_seg);               // n * H + h
+        const int w0 = (g - (int)rowid * segs) << 4;
+        const uint32_t n = fdiv(rowid, div_h);
+        const int h = (int)(rowid - n * (uint32_t)H);
+        const uint32_t vmain = ((n * (uint32_t)CI + q) * (uint32_t)HW + (uint32_t)(h * W + w0 + i)) * 4u;
+        uint32_t vedge = OOB;
+        if (i == 0 && w0 > 0) vedge = vmain - 4u;
+        if (i == 15 && w0 + 16 < W) vedge = vmain + 4u;
+        f32x4 acc[OT];
+#pragma unroll
+        for (int a = 0; a < OT; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int hh = h + dy - 1;
+            if ((unsigned)hh >= (unsigned)H) continue;                   // wave-uniform
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const bool cok = cb * 4 + q < CI;
+                const uint32_t soff = (uint32_t)(cb * 4 * HW + dy * W) * 4u;
+                const float v0 = bload(rin, cok ? vmain : OOB, soff);
+                // lanes 0 / 15 of each 16-lane row fetch the pixel left / right of the segment (zero in the padding)
+                const float ev = bload(rin, cok ? vedge : OOB, soff);
+                float left = __shfl_up(v0, 1, 16), right = __shfl_down(v0, 1, 16);
+                if (i == 0) left = ev;
+                if (i == 15) right = ev;
+                const float* wrow = Ws + ((dy * 3) * CB + cb) * OT * 64 + lane;
+#pragma unroll
+                for (int a = 0; a < OT; ++a) {
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[(0 * CB) * OT * 64 + a * 64], left, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[(1 * CB) * OT * 64 + a * 64], v0, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[(2 * CB) * OT * 64 + a * 64], right, acc[a], 0, 0, 0);
+                }
+            }
+        }
+        // D[row = output channel 4q + r][column = pixel i]
+#pragma unroll
+        for (int a = 0; a < OT; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = a * 16 + 4 * q + r;
+                if (co < CO) {
+                    const float bv = bias ? bias[co] : 0.f;
+                    out[((long long)(n * (uint32_t)CO + co) * H + h) * W + w0 + i] = act_fwd(acc[a][r] + bv, act, slope);
+                }
+            }
+    }
+}
+
+static bool conv3_smallch_ok(int N, int CI, int CO, int H, int W) {
+    static int off = getenv("GZ_NO_SMALLCH_CONV") ? 1 : 0;
+    // measured against the implicit-GEMM path (tools/resnet_bench.py): wins when the output side fits one 16-row
+    // MFMA tile and the input side fills at least half a 16-channel block (16->16 @ 128x128: 123 -> 72 us);
+    // loses for 3 input channels (K dimension mostly padding) and for 32 output channels
+    return !off && CO <= 16 && CI > 8 && CI <= 32 && (W & 15) == 0 && (long long)N * H * W >= 65536;
+}
+
+static int run_conv3_smallch(const float* in, const float* wp, const float* bias, float* out, int N, int CI, int CO,
+                             int H, int W, int tap_major, int flip, int act, float slope, hipStream_t st) {
+    const int groups = N * H * (W >> 4);
+    static int gpw = getenv("GZ_C3_GPW") ? atoi(getenv("GZ_C3_GPW")) : 4;
+    long long blocks = (groups + 4 * gpw - 1) / (4 * gpw);   // >= gpw pixel groups per wavefront: the weights are staged per workgroup
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    const FastDiv dseg = make_fastdiv(W >> 4), dh = make_fastdiv(H);
+    const int ot = (CO + 15) / 16, it = (CI + 15) / 16;
+#define GZ_C3(OT_, IT_)                                                                                              \
+    hipLaunchKernelGGL((conv3x3_smallch_kernel<OT_, IT_>), dim3((unsigned)blocks), dim3(256), 0, st, in, wp, bias, out, \
+                       N, CI, CO, H, W, groups, dseg, dh, tap_major, round_bk(CI), round4(CO), flip, act, slope)
+    if (ot == 1 && it == 1) GZ_C3(1, 1);
+    else if (ot == 1) GZ_C3(1, 2);
+    else if (it == 1) GZ_C3(2, 1);
+    else GZ_C3(2, 2);
+#undef GZ_C3
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------
 // Wg of 3x3 s1 p1 layers with few channels (ceil(K/16) * ceil(C/16) <= 4: the 128x128 / 64x64 stages of the R1
 // ResNets, the image-side convolutions 64 -> 3 / 3 -> 16).  As an implicit GEMM this is M = K <= 32 rows of a 64-row tile: three quarters of
 // the MFMA work multiplies padding.  Here one wavefront owns 16 consecutive pixels of one image row and issues
@@ -834,6 +952,8 @@ int gz_conv2d_fwd(const float* x, const float* wpack, const float* bias, float* 
     if (!shape_ok(s, KH, KW, S, P)) return GZ_ERR_BAD_SHAPE;
     if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
     if (((uintptr_t)wpack & 15) || ((uintptr_t)y & 15)) return GZ_ERR_BAD_SHAPE;
+    if (KH == 3 && KW == 3 && S == 1 && P == 1 && conv3_smallch_ok(N, C, K, H, W))
+        return run_conv3_smallch(x, wpack, bias, y, N, C, K, H, W, fwd_tap_major(C, 3, 3), 0, act, slope, stream);
 #define CALL(G) dispatch_fwd<G>(x, wpack, bias, y, s, act, slope, workspace, ws_bytes, stream)
     GZ_GEOM_DISPATCH(CALL)
 #undef CALL
@@ -847,6 +967,8 @@ int gz_conv2d_dgrad(const float* y, const float* wpack, const float* bias, float
     if (!shape_ok(s, KH, KW, S, P)) return GZ_ERR_BAD_SHAPE;
     if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
     if ((uintptr_t)wpack & 15) return GZ_ERR_BAD_SHAPE;
+    if (KH == 3 && KW == 3 && S == 1 && P == 1 && conv3_smallch_ok(N, K, C, H, W))
+        return run_conv3_smallch(y, wpack, bias, x, N, K, C, H, W, dgrad_tap_major(K, 3, 3, 1), 1, act, slope, stream);
 #define CALL(G) dispatch_dgrad<G>(y, wpack, bias, x, s, act, slope, workspace, ws_bytes, stream)
     GZ_GEOM_DISPATCH(CALL)
 #undef CALL

@@ -570,3 +570,24 @@ def test_wgrad_small_channel_3x3(case):
     dw = F._conv_wgrad_raw(x.cuda(), gy.cuda(), F.K3S1P1)
     assert rel(dw, dw_ref) < TOL
     assert torch.equal(dw, F._conv_wgrad_raw(x.cuda(), gy.cuda(), F.K3S1P1))      # fixed summation order
+
+
+@pytest.mark.parametrize("case", [(16, 16, 64, 16), (4, 3, 128, 16), (4, 16, 128, 3), (16, 32, 64, 32),
+                                  (16, 16, 64, 32), (32, 20, 48, 24), (8, 5, 96, 30)])
+def test_conv3x3_small_channel_fwd_dgrad(case):
+    """The direct 16x16x4-MFMA forward / input-gradient kernel of 3x3 s1 p1 layers with <= 32 channels, with the
+    bias + activation epilogues, for both weight image formats (tap-major when the input side has >= 16
+    channels) and ragged channel counts."""
+    F = _F()
+    N, C, H, K = case
+    g = F.K3S1P1
+    x, w, b = rnd(N, C, H, H, seed=81), rnd(K, C, 3, 3, seed=82, scale=0.2), rnd(K, seed=83)
+    y_ref = TF.leaky_relu(TF.conv2d(x, w, b, 1, 1), 0.2)
+    gy, bc = rnd(N, K, H, H, seed=84), rnd(C, seed=85)
+    dx_ref = torch.tanh(TF.conv_transpose2d(gy, w, bc, 1, 1))
+    y = F._conv_fwd_raw(x.cuda(), w.cuda(), b.cuda(), g, F.ACT_LRELU, 0.2)
+    assert rel(y, y_ref) < TOL
+    dx = F._conv_dgrad_raw(gy.cuda(), w.cuda(), bc.cuda(), g, (H, H), F.ACT_TANH, 0.0)
+    assert rel(dx, dx_ref) < TOL
+    assert rel(F._conv_dgrad_raw(gy.cuda(), w.cuda(), None, g, (H, H), F.ACT_NONE, 0.0),
+               TF.conv_transpose2d(gy, w, None, 1, 1)) < TOL
