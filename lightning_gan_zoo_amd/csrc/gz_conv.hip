@@ -572,7 +572,7 @@ static bool conv3_smallch_ok(int N, int CI, int CO, int H, int W) {
     // measured against the implicit-GEMM path (tools/resnet_bench.py): wins when the output side fits one 16-row
     // MFMA tile and the input side fills at least half a 16-channel block (16->16 @ 128x128: 123 -> 72 us);
     // loses for 3 input channels (K dimension mostly padding) and for 32 output channels
-    return !off && CO <= 16 && CI > 8 && CI <= 32 && (W & 15) == 0 && (long long)N * H * W >= 65536;
+    return !off && CO <= 16 && CI > 8 && CI <= 64 && (W & 15) == 0 && (long long)N * H * W >= 65536;
 }
 
 static int run_conv3_smallch(const float* in, const float* wp, const float* bias, float* out, int N, int CI, int CO,
@@ -587,10 +587,10 @@ static int run_conv3_smallch(const float* in, const float* wp, const float* bias
 #define GZ_C3(OT_, IT_)                                                                                              \
     hipLaunchKernelGGL((conv3x3_smallch_kernel<OT_, IT_>), dim3((unsigned)blocks), dim3(256), 0, st, in, wp, bias, out, \
                        N, CI, CO, H, W, groups, dseg, dh, tap_major, round_bk(CI), round4(CO), flip, act, slope)
-    if (ot == 1 && it == 1) GZ_C3(1, 1);
-    else if (ot == 1) GZ_C3(1, 2);
-    else if (it == 1) GZ_C3(2, 1);
-    else GZ_C3(2, 2);
+    (void)ot;                                        // conv3_smallch_ok admits one output block only
+    if (it == 1) GZ_C3(1, 1);
+    else if (it == 2) GZ_C3(1, 2);
+    else GZ_C3(1, 4);
 #undef GZ_C3
     return launch_status();
 }

@@ -573,7 +573,8 @@ def test_wgrad_small_channel_3x3(case):
 
 
 @pytest.mark.parametrize("case", [(16, 16, 64, 16), (4, 3, 128, 16), (4, 16, 128, 3), (16, 32, 64, 32),
-                                  (16, 16, 64, 32), (32, 20, 48, 24), (8, 5, 96, 30)])
+                                  (16, 16, 64, 32), (32, 20, 48, 24), (8, 5, 96, 30), (16, 64, 64, 3),
+                                  (16, 9, 64, 50)])
 def test_conv3x3_small_channel_fwd_dgrad(case):
     """The direct 16x16x4-MFMA forward / input-gradient kernel of 3x3 s1 p1 layers with <= 32 channels, with the
     bias + activation epilogues, for both weight image formats (tap-major when the input side has >= 16
