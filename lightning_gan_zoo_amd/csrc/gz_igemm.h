@@ -1497,13 +1497,13 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
                                     lane, y, z);
 }
 
-// Second pass of a split-K launch: a workgroup owns one 32x32 output block; its four wavefronts each sum every
-// fourth slab into the accumulator image Epi::store expects (the MFMA C/D layout), the partial images meet in
+// Second pass of a split-K launch: a workgroup owns one 32x32 output block; its WAVES wavefronts each sum every
+// WAVES-th slab into the accumulator image Epi::store expects (the MFMA C/D layout), the partial images meet in
 // LDS in a fixed order, and wavefront 0 runs the op's own epilogue (bias, activation, NCHW / phase scatter).
-template <class Epi>
-__global__ __launch_bounds__(NT) void splitk_finish_kernel(const float* __restrict__ slab, int nz, int M, int N,
-                                                           typename Epi::Params pe, int tiles_n, int ny) {
-    __shared__ float part[3][16][64];
+template <class Epi, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void splitk_finish_kernel(const float* __restrict__ slab, int nz, int M, int N,
+                                                                   typename Epi::Params pe, int tiles_n, int ny) {
+    __shared__ float part[WAVES - 1][16][64];
     int bid = blockIdx.x;
     const int y = bid % ny;
     bid /= ny;
@@ -1514,7 +1514,7 @@ __global__ __launch_bounds__(NT) void splitk_finish_kernel(const float* __restri
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-    for (int z = wave; z < nz; z += 4) {
+    for (int z = wave; z < nz; z += WAVES) {
         const float* c = slab + (long long)(y * nz + z) * M * N;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1535,7 +1535,12 @@ __global__ __launch_bounds__(NT) void splitk_finish_kernel(const float* __restri
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][0][r] += (part[0][r][lane] + part[1][r][lane]) + part[2][r][lane];
+        for (int r = 0; r < 16; ++r) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES - 1; ++w) t += part[w][r][lane];
+            acc[0][0][r] += t;
+        }
         Epi::template store<1, 1>(pe, acc, m_base, n_base, lane, y, 0);
     }
 }
@@ -1577,8 +1582,13 @@ inline int launch_igemm(const typename AL::Params& pa, const typename BL::Params
     hipLaunchKernelGGL((igemm_kernel<Cfg, AL, BL, Epi>), grid, dim3(NT), dyn_lds, stream, pa, pb, pe, gm);
     if (gm.slab) {
         const int fm = (M + 31) / 32, fn = (N + 31) / 32;
-        hipLaunchKernelGGL((splitk_finish_kernel<Epi>), dim3(fm * fn * ny), dim3(NT), 0, stream, slab, nz, M, N, pe, fn,
-                           ny);
+        // many slabs over few output blocks (the K = 8192 / 32768 linear heads): 16 wavefronts share the slab walk
+        if (nz > 16)
+            hipLaunchKernelGGL((splitk_finish_kernel<Epi, 16>), dim3(fm * fn * ny), dim3(1024), 0, stream, slab, nz, M, N,
+                               pe, fn, ny);
+        else
+            hipLaunchKernelGGL((splitk_finish_kernel<Epi, 4>), dim3(fm * fn * ny), dim3(NT), 0, stream, slab, nz, M, N, pe,
+                               fn, ny);
     }
     return launch_status();
 }

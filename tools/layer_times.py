@@ -14,7 +14,7 @@ from lightning_gan_zoo_amd import functional as F  # noqa: E402
 
 expt = sys.argv[1] if len(sys.argv) > 1 else "hologan"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else bench.DEFAULT_BATCH[expt]
-img = bench.NATIVE_IMG_SIZE.get(expt, 64)
+img = int(sys.argv[3]) if len(sys.argv) > 3 else bench.NATIVE_IMG_SIZE.get(expt, 64)
 torch.set_num_threads(min(8, torch.get_num_threads()))
 dev = torch.device("cuda", 0)
 module, trainer = bench.build_trainer(expt, batch, dev, 1, False, img)
