@@ -58,6 +58,23 @@ __global__ __launch_bounds__(256) void transpose_pad3_kernel(const float* __rest
     }
 }
 
+// forward weights in tap-major order (Conv3DFwdALoaderTap): wp[(tap, c)][ld] = w[ko][c][tap], c padded to BK
+static bool fwd3_tap_major(int C) {
+    static int off = getenv("GZ_NO_TAPMAJOR") ? 1 : 0;
+    return !off && C >= BK;
+}
+
+__global__ __launch_bounds__(256) void pack_fwd3_tap_kernel(const float* __restrict__ w, float* __restrict__ wp, int K,
+                                                            int C, int taps, int cpad, int ld) {
+    const long long total = (long long)taps * cpad * ld;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int ko = (int)(i % ld);
+        long long row = i / ld;
+        int c = (int)(row % cpad), tap = (int)(row / cpad);
+        wp[i] = (ko < K && c < C) ? w[((long long)ko * C + c) * taps + tap] : 0.f;
+    }
+}
+
 // wp[phase][(ko, td, ty, tx)][ldc] = w[ko][c][kd][ky][kx], k* = ((p* + P) % S) + S * t*.  Only the taps with
 // k* < KS exist (k3 s2 p1: 1 tap on an even output coordinate, 2 on an odd one -> 1..8 per phase, 27 over the 8
 // phases instead of 8 x 8); a phase's rows are packed tightly, the rest of its fixed-size region is zero.
@@ -103,10 +120,16 @@ static int run_fwd3(const float* x, const float* wp, const float* bias, float* y
     using BL = MContigLoader4<Cfg::BN>;
     const int osp = s.OD * s.OH * s.OW;
     typename AL::Params pa{x, s, make_fastdiv(osp), make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW)};
-    int Kg = s.C * KS * KS * KS;
-    typename BL::Params pb{wp, Kg, r4(s.K), r4(s.K), 0};
     int M = s.N * osp;
     EpiNCHW::Params pe{y, M, s.K, osp, make_fastdiv(osp), bias, act, slope};
+    if (fwd3_tap_major(s.C)) {
+        using ALT = Conv3DFwdALoaderTap<Cfg::BM, KS, S, P>;
+        int Kt = KS * KS * KS * round_bk(s.C);
+        typename BL::Params pbt{wp, Kt, r4(s.K), r4(s.K), 0};
+        return launch_igemm<Cfg, ALT, BL, EpiNCHW>(pa, pbt, pe, M, s.K, Kt, 1, splits, st, slab);
+    }
+    int Kg = s.C * KS * KS * KS;
+    typename BL::Params pb{wp, Kg, r4(s.K), r4(s.K), 0};
     return launch_igemm<Cfg, AL, BL, EpiNCHW>(pa, pb, pe, M, s.K, Kg, 1, splits, st, slab);
 }
 
@@ -187,7 +210,9 @@ using namespace gz;
 
 extern "C" {
 
-long long gz_conv3d_pack_fwd_elems(int K, int C, int KS) { return (long long)C * KS * KS * KS * r4(K); }
+long long gz_conv3d_pack_fwd_elems(int K, int C, int KS) {
+    return (long long)(fwd3_tap_major(C) ? round_bk(C) : C) * KS * KS * KS * r4(K);
+}
 
 long long gz_conv3d_pack_dgrad_elems(int K, int C, int KS, int S) {
     int T = (KS + S - 1) / S;
@@ -198,6 +223,12 @@ int gz_conv3d_pack_fwd(const float* w, float* wp, int K, int C, int KS, hipStrea
     gz::clear_stale_error();
     if (K <= 0 || C <= 0 || KS <= 0) return GZ_ERR_BAD_SHAPE;
     int Kg = C * KS * KS * KS, ld = r4(K);
+    if (fwd3_tap_major(C)) {
+        long long total = (long long)KS * KS * KS * round_bk(C) * ld;
+        hipLaunchKernelGGL(pack_fwd3_tap_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)),
+                           dim3(256), 0, stream, w, wp, K, C, KS * KS * KS, round_bk(C), ld);
+        return launch_status();
+    }
     hipLaunchKernelGGL(transpose_pad3_kernel, dim3((Kg + 31) / 32, (ld + 31) / 32), dim3(256), 0, stream, w, wp, K, Kg,
                        ld);
     return launch_status();
@@ -213,7 +244,7 @@ int gz_conv3d_pack_dgrad(const float* w, float* wp, int K, int C, int KS, int S,
 
 size_t gz_conv3d_fwd_workspace_bytes(int N, int C, int K, int OD, int OH, int OW, int KS) {
     long long M = (long long)N * OD * OH * OW;
-    int Kg = C * KS * KS * KS;
+    int Kg = (fwd3_tap_major(C) ? round_bk(C) : C) * KS * KS * KS;
     return bytes3(plan3(pick3(M, K, 1), M, K, Kg, 1), M, K, Kg, 1);
 }
 
@@ -233,8 +264,9 @@ int gz_conv3d_fwd(const float* x, const float* wpack, const float* bias, float* 
     if (big3((long long)N * C * D * H * W) || big3((long long)N * K * OD * OH * OW)) return GZ_ERR_TOO_LARGE;
     if (((uintptr_t)wpack & 15) || ((uintptr_t)y & 15)) return GZ_ERR_BAD_SHAPE;
     int t = pick3((long long)N * OD * OH * OW, K, 1);
-    int splits = plan3(t, (long long)N * OD * OH * OW, K, C * 27, 1);
-    if (splits > 1 && (!workspace || ws_bytes < bytes3(splits, (long long)N * OD * OH * OW, K, C * 27, 1))) splits = 1;
+    const int kdim = (fwd3_tap_major(C) ? round_bk(C) : C) * 27;
+    int splits = plan3(t, (long long)N * OD * OH * OW, K, kdim, 1);
+    if (splits > 1 && (!workspace || ws_bytes < bytes3(splits, (long long)N * OD * OH * OW, K, kdim, 1))) splits = 1;
     float* slab = splits > 1 ? workspace : nullptr;
 #define CALL(CFG) run_fwd3<CFG, 3, 2, 1>(x, wpack, bias, y, s, act, slope, stream, splits, slab)
     GZ3_TILE_SWITCH(t, CALL)

@@ -999,6 +999,75 @@ struct Conv3DFwdALoader {
     }
 };
 
+// tap-major variant (see ConvFwdALoaderTap): A[m = (n, od, oy, ox)][k = (tap, c)], c padded to a multiple of BK
+template <int BM, int KS, int S, int P>
+struct Conv3DFwdALoaderTap {
+    using Params = typename Conv3DFwdALoader<BM, KS, S, P>::Params;
+    static constexpr int LD = BM;
+    static constexpr int NPARTS = 0;
+    __device__ __forceinline__ void issue_lds_part(int, float*, int) {}
+    static constexpr bool DMA = GZ_IGEMM_DMA;
+    static constexpr int EPT = BM * BK / NT;
+    static constexpr int STEP = NT / BM;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[EPT];
+    int kb, m_l, id0, iy0, ix0, C, D, H, W, cblocks;
+    bool m_ok;
+    float r[DMA ? 1 : EPT];
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        const Conv3DShape& s = p.s;
+        const uint32_t shift = (uint32_t)((P * s.H + P) * s.W + P) * 4u;
+        rsrc = make_rsrc(reinterpret_cast<const char*>(p.x) - shift,
+                         (uint32_t)s.N * s.C * s.D * s.H * s.W * 4u + shift);
+        m_l = tid % BM;
+        kb = tid / BM;
+        uint32_t m = (uint32_t)tile * BM + m_l;
+        m_ok = m < (uint32_t)s.N * s.OD * s.OH * s.OW;
+        uint32_t n = fdiv(m, p.div_odhw);
+        uint32_t v = m - n * (uint32_t)(s.OD * s.OH * s.OW);
+        uint32_t od = fdiv(v, p.div_ohw);
+        v -= od * (uint32_t)(s.OH * s.OW);
+        uint32_t oy = fdiv(v, p.div_ow);
+        uint32_t ox = v - oy * (uint32_t)s.OW;
+        id0 = (int)od * S - P; iy0 = (int)oy * S - P; ix0 = (int)ox * S - P;
+        C = s.C; D = s.D; H = s.H; W = s.W;
+        cblocks = round_bk(s.C) / BK;
+        const int pos = (int)(n * (uint32_t)(s.C * s.D * s.H * s.W)) + ((id0 + P) * H + (iy0 + P)) * W + (ix0 + P);
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) voff[j] = (uint32_t)(pos + (kb + STEP * j) * D * H * W) * 4u;
+    }
+    __device__ __forceinline__ void chunk(int kc, uint32_t& soff, bool& ok, int& cb) const {
+        const int tap = kc / cblocks;
+        cb = (kc - tap * cblocks) * BK;
+        const int kd = tap / (KS * KS), ky = (tap / KS) % KS, kx = tap % KS;
+        soff = (uint32_t)(cb * D * H * W + (kd * H + ky) * W + kx) * 4u;
+        ok = m_ok && (unsigned)(id0 + kd) < (unsigned)D && (unsigned)(iy0 + ky) < (unsigned)H &&
+             (unsigned)(ix0 + kx) < (unsigned)W;
+    }
+    __device__ __forceinline__ void issue_lds(int kc, float* dst) {
+        float* wbase = dst + (m_l - (int)(threadIdx.x & 63));
+        uint32_t soff; bool ok; int cb;
+        chunk(kc, soff, ok, cb);
+#pragma unroll
+        for (int j = 0; j < EPT; ++j)
+            bload_lds4(rsrc, wbase + (kb + STEP * j) * LD, (ok && cb + kb + STEP * j < C) ? voff[j] : OOB, soff);
+    }
+    __device__ __forceinline__ void issue(int kc) {
+        if constexpr (!DMA) {
+            uint32_t soff; bool ok; int cb;
+            chunk(kc, soff, ok, cb);
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) r[j] = bload(rsrc, (ok && cb + kb + STEP * j < C) ? voff[j] : OOB, soff);
+        }
+    }
+    __device__ __forceinline__ void commit(float* dst) const {
+        if constexpr (!DMA) {
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) dst[(kb + STEP * j) * LD + m_l] = r[j];
+        }
+    }
+};
+
 // transposed 3-D conv, phase (pd, py, px): A[m = (n, a, b, c)][k = (ko, td, ty, tx)]
 template <int BM, int KS, int S, int P>
 struct Conv3DDgALoader {
@@ -1317,6 +1386,7 @@ struct GridMap {
     // transposed convolutions whose phases have different tap counts (k3 s2, k5 s2): chunks of phase y
     int var_chunks;
     int phase_chunks[8];
+    int phase_order[8];        // phases by decreasing chunk count
 };
 
 // SWAP (transposed accumulators, lanes along m): the slab is kept [n][m] so that its stores and the finish
@@ -1366,14 +1436,23 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
     // contiguous run of tiles (neighbouring tiles share operand panels in that XCD's L2).
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
-    {
+    int y;
+    if (gm.var_chunks) {
+        // phases of unequal length (1..8 taps): longest phases first over ALL tiles, so that the workgroups still
+        // running when the grid drains are the short ones (with the phases of a tile adjacent, the 8-tap phase of
+        // the last tiles ran alone for a quarter of the kernel).  Plain round-robin over the XCDs keeps every
+        // XCD's mix of phases equal.
+        const int tiles = gm.tiles_m * gm.tiles_n;
+        y = gm.phase_order[bid / tiles];
+        bid %= tiles;
+    } else {
         const int q = nwg >> 3, rr = nwg & 7, x = bid & 7, i = bid >> 3;
         bid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + i;
+        // phases of one tile are adjacent (same XCD, close in time): they read the same feature patch and
+        // their interleaved stores meet in that XCD's L2.
+        y = bid % gm.ny;
+        bid /= gm.ny;
     }
-    // phases of one tile are adjacent (same XCD, close in time): they read the same feature patch and
-    // their interleaved stores meet in that XCD's L2.
-    const int y = bid % gm.ny;
-    bid /= gm.ny;
     const int tile_n = bid % gm.tiles_n;
     const int tile_m = bid / gm.tiles_n;
     const int z = blockIdx.z;
@@ -1563,7 +1642,16 @@ inline int launch_igemm(const typename AL::Params& pa, const typename BL::Params
     gm.var_chunks = 0;
     if (phase_chunks && ny <= 8) {
         gm.var_chunks = 1;
-        for (int i = 0; i < ny; ++i) gm.phase_chunks[i] = phase_chunks[i];
+        for (int i = 0; i < ny; ++i) {
+            gm.phase_chunks[i] = phase_chunks[i];
+            gm.phase_order[i] = i;
+        }
+        for (int i = 1; i < ny; ++i)          // insertion sort, stable, descending
+            for (int j = i; j > 0 && gm.phase_chunks[gm.phase_order[j]] > gm.phase_chunks[gm.phase_order[j - 1]]; --j) {
+                int t = gm.phase_order[j];
+                gm.phase_order[j] = gm.phase_order[j - 1];
+                gm.phase_order[j - 1] = t;
+            }
     }
     gm.slab = nullptr;
     gm.slab_m = M;
