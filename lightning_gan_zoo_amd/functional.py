@@ -12,6 +12,7 @@ so `torch.autograd.grad(..., create_graph=True)` (the WGAN-GP gradient penalty,
 reference core/utils/utils.py:48-54) works through these ops to any order.
 """
 import ctypes
+import os
 import weakref
 from collections import namedtuple
 
@@ -242,6 +243,39 @@ class _ActBwd(torch.autograd.Function):
 # ---------------------------------------------------------------------------
 # F / Dg / Wg
 # ---------------------------------------------------------------------------
+# In a first-order backward the weight gradient and the input gradient of a layer are independent and could share
+# the GPU from two streams (one kernel's drain covered by the other).  Measured and left OFF (threshold 0): two large
+# MFMA-bound kernels running together lose more to cache / LDS contention than their drains cost (dc_gan +8 %,
+# hologan +9 % step time), and for the small R1 layers the two extra stream waits per layer make the already
+# launch-heavy step host-bound (15.4 -> 19.0 ms).  GZ_WG_SIDE_STREAM_FLOPS=<flops> enables it for layers below
+# that size.  When enabled, the main stream waits for the side stream before anything else is enqueued, so every
+# consumer sees both results and no record_stream is needed.
+_side_streams = {}
+_WG_SIDE_FLOPS = float(os.environ.get("GZ_WG_SIDE_STREAM_FLOPS", "0"))
+
+
+def _conv_flops(x, gy, w):
+    return 2.0 * gy.shape[0] * gy.shape[2] * gy.shape[3] * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
+
+
+def _pair_wgrad_dgrad(wgrad, dgrad, flops):
+    """Run wgrad() on the side stream and dgrad() on the current one; returns (dx, dw)."""
+    if flops > _WG_SIDE_FLOPS or torch.is_grad_enabled():     # double backward: one stream (autograd tracks nothing across)
+        dx = dgrad()
+        return dx, wgrad()
+    main = torch.cuda.current_stream()
+    key = (main.device_index, main.cuda_stream)
+    side = _side_streams.get(key)
+    if side is None:
+        side = _side_streams[key] = torch.cuda.Stream(device=main.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        dw = wgrad()
+    dx = dgrad()
+    main.wait_stream(side)
+    return dx, dw
+
+
 class _ConvF(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, geom, act, slope):
@@ -259,9 +293,13 @@ class _ConvF(torch.autograd.Function):
         if ctx.act != ACT_NONE:
             gy = _ActBwd.apply(gy, y, ctx.act, ctx.slope)
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            dx, dw = _pair_wgrad_dgrad(lambda: _ConvWg.apply(x, gy, geom),
+                                       lambda: _ConvDg.apply(gy, w, None, geom, tuple(x.shape[2:]), ACT_NONE, 0.0),
+                                       _conv_flops(x, gy, w))
+        elif ctx.needs_input_grad[0]:
             dx = _ConvDg.apply(gy, w, None, geom, tuple(x.shape[2:]), ACT_NONE, 0.0)
-        if ctx.needs_input_grad[1]:
+        elif ctx.needs_input_grad[1]:
             dw = _ConvWg.apply(x, gy, geom)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = gy.sum((0, 2, 3))
@@ -287,9 +325,12 @@ class _ConvDg(torch.autograd.Function):
         if ctx.act != ACT_NONE:
             v = _ActBwd.apply(v, x, ctx.act, ctx.slope)
         dg = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            dg, dw = _pair_wgrad_dgrad(lambda: _ConvWg.apply(v, g, geom),
+                                       lambda: _ConvF.apply(v, w, None, geom, ACT_NONE, 0.0), _conv_flops(v, g, w))
+        elif ctx.needs_input_grad[0]:
             dg = _ConvF.apply(v, w, None, geom, ACT_NONE, 0.0)
-        if ctx.needs_input_grad[1]:
+        elif ctx.needs_input_grad[1]:
             dw = _ConvWg.apply(v, g, geom)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = v.sum((0, 2, 3))
