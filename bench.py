@@ -37,14 +37,16 @@ DEFAULT_BATCH = {"dc_gan": 512, "wgan": 512, "wgan_gp": 256, "hologan": 64, "gan
 PEAK_FP32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
 
 
-def build_trainer(expt, batch, device, world, force_sync=False, img_size=64):
+def build_trainer(expt, batch, device, world, force_sync=False, img_size=64, graph=False):
     from lightning_gan_zoo_amd.config import locate, make_cfg
     from lightning_gan_zoo_amd.ddp import GradSync
-    from lightning_gan_zoo_amd.harness import Trainer
+    from lightning_gan_zoo_amd.harness import GraphedTrainer, Trainer
     cfg = make_cfg(expt, batch_size=batch, img_size=img_size)
     torch.manual_seed(42)                 # run_network.py:27, same seed on every rank
     module = locate(cfg.model.lm["_target_"])(cfg, None).to(device)
     sync = GradSync(module) if (world > 1 or force_sync) else None
+    if graph and sync is None:
+        return module, GraphedTrainer(module)
     return module, Trainer(module, grad_sync=sync)
 
 
@@ -152,6 +154,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bs128", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay each optimizer step from a captured HIP graph (single GPU; not for hologan)")
     ap.add_argument("--force-grad-sync", action="store_true",
                     help="use the data-parallel gradient path (flat buffers, deferred step) even on one rank")
     args = ap.parse_args()
@@ -177,11 +181,14 @@ def main():
     torch.set_num_threads(min(8, torch.get_num_threads()))
     if args.force_grad_sync and world == 1 and not dist.is_initialized() and "RANK" in os.environ:
         dist.init_process_group("nccl")
-    module, trainer = build_trainer(args.expt, args.batch, device, world, args.force_grad_sync, args.img_size)
+    module, trainer = build_trainer(args.expt, args.batch, device, world, args.force_grad_sync, args.img_size,
+                                    args.graph)
+    if args.graph:
+        args.no_kernel_timer = True        # per-launch events cannot be recorded inside a replayed graph
     batch = synthetic_batch(args.batch, device, rank, args.img_size)
     timer = F.KernelTimer()
     # warm-up happens inside timed_pairs; the per-launch HIP events are recorded during the timed region
-    for _ in range(2):
+    for _ in range(8 if args.graph else 2):     # graph mode: eager warm-up + capture of both optimizer steps
         trainer.step(batch)
     trainer.finish()
     if not args.no_kernel_timer:

@@ -195,6 +195,12 @@ int gz_upsample2_bwd(const float* gy, float* gx, long long planes, int H, int W,
 int gz_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg,
                  float* const* exp_avg_sq, const long long* numel, float lr, float beta1, float beta2, float eps,
                  int step, float grad_scale, hipStream_t stream);
+/* graph-capturable Adam: tick = device float[3] {step, 1 - beta1^step, sqrt(1 - beta2^step)}; gz_adam_tick advances
+ * it by one step, gz_adam_step_dev reads the corrections from it (same update as gz_adam_step) */
+int gz_adam_tick(float* tick, float beta1, float beta2, hipStream_t stream);
+int gz_adam_step_dev(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                     float* const* exp_avg_sq, const long long* numel, float lr, float beta1, float beta2, float eps,
+                     const float* tick, float grad_scale, hipStream_t stream);
 int gz_rmsprop_step(int count, float* const* params, const float* const* grads, float* const* square_avg,
                     const long long* numel, float lr, float alpha, float eps, float grad_scale, hipStream_t stream);
 

@@ -26,8 +26,11 @@ def gradient_penalty(critic, real, fake, device="cpu", alpha=None):
     """
     bs = real.shape[0]
     given = alpha
-    alpha = draw_on_host(lambda: (torch.rand((bs, 1, 1, 1)) if given is None else given).reshape(bs).float(),
-                         real.device)
+    if given is not None and given.is_cuda:          # already staged (harness.GraphedTrainer's static buffer)
+        alpha = given.reshape(bs)
+    else:
+        alpha = draw_on_host(lambda: (torch.rand((bs, 1, 1, 1)) if given is None else given).reshape(bs).float(),
+                             real.device)
     interpolated_images = F.lerp_rows(real, fake, alpha)
     interpolated_images.requires_grad_()
     mixed_scores = critic(interpolated_images)

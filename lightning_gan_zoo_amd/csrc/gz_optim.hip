@@ -53,6 +53,41 @@ __global__ __launch_bounds__(OPT_THREADS) void adam_kernel(OptTable t, float lr,
     }
 }
 
+// Graph-capturable Adam: the step counter and the two bias corrections live in device memory
+// (tick[0] = step, tick[1] = 1 - beta1^step, tick[2] = sqrt(1 - beta2^step)), advanced by a one-thread kernel in
+// front of the update, so that a captured launch sequence stays valid for every replay.
+__global__ void adam_tick_kernel(float* tick, float beta1, float beta2) {
+    const double step = (double)tick[0] + 1.0;
+    tick[0] = (float)step;
+    tick[1] = (float)(1.0 - pow((double)beta1, step));
+    tick[2] = (float)sqrt(1.0 - pow((double)beta2, step));
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void adam_dev_kernel(OptTable t, float lr, float beta1, float beta2, float eps,
+                                                               const float* __restrict__ tick, float grad_scale) {
+    const int k = find_tensor(t, blockIdx.x);
+    const long long base = (long long)(blockIdx.x - t.first_block[k]) * OPT_CHUNK;
+    float* p = t.p[k];
+    const float* g = t.g[k];
+    float* m = t.m[k];
+    float* v = t.v[k];
+    const long long n = t.n[k];
+    const float step_size = lr / tick[1];
+    const float bc2_sqrt = tick[2];
+    for (int i = threadIdx.x; i < OPT_CHUNK; i += OPT_THREADS) {
+        long long e = base + i;
+        if (e >= n) break;
+        float gv = g[e] * grad_scale;
+        float mv = m[e];
+        mv = mv + (gv - mv) * (1.f - beta1);
+        float vv = v[e] * beta2 + (1.f - beta2) * gv * gv;
+        float denom = sqrtf(vv) / bc2_sqrt + eps;
+        p[e] = p[e] - step_size * (mv / denom);
+        m[e] = mv;
+        v[e] = vv;
+    }
+}
+
 __global__ __launch_bounds__(OPT_THREADS) void rmsprop_kernel(OptTable t, float lr, float alpha, float eps,
                                                               float grad_scale) {
     const int k = find_tensor(t, blockIdx.x);
@@ -109,6 +144,26 @@ int gz_adam_step(int count, float* const* params, const float* const* grads, flo
     double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(OPT_THREADS), 0, stream, t, lr, beta1, beta2, eps, (float)bc1,
                        (float)sqrt(bc2), grad_scale);
+    return launch_status();
+}
+
+int gz_adam_tick(float* tick, float beta1, float beta2, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (!tick) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, stream, tick, beta1, beta2);
+    return launch_status();
+}
+
+int gz_adam_step_dev(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                     float* const* exp_avg_sq, const long long* numel, float lr, float beta1, float beta2, float eps,
+                     const float* tick, float grad_scale, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (!tick) return GZ_ERR_BAD_SHAPE;
+    OptTable t;
+    int blocks = fill_table(t, count, params, grads, exp_avg, exp_avg_sq, numel);
+    if (blocks < 0) return blocks;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(OPT_THREADS), 0, stream, t, lr, beta1, beta2, eps, tick,
+                       grad_scale);
     return launch_status();
 }
 

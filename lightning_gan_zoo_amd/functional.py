@@ -114,11 +114,19 @@ def _timed_detail(label_fn, flops, launch):
 # discriminator passes of one step share one pack.
 # ---------------------------------------------------------------------------
 _pack_cache = {}
+_pack_cache_enabled = True     # harness.GraphedTrainer turns it off: a captured step must contain its pack kernels
+
+
+def set_pack_cache(enabled):
+    global _pack_cache_enabled
+    _pack_cache_enabled = bool(enabled)
+    _pack_cache.clear()
+    _pack3_cache.clear()
 
 
 def _packed(w, kind, geom):
     key = (w.data_ptr(), kind)
-    cacheable = isinstance(w, torch.nn.Parameter)
+    cacheable = _pack_cache_enabled and isinstance(w, torch.nn.Parameter)
     if cacheable:
         hit = _pack_cache.get(key)
         if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == tuple(w.shape):
@@ -757,7 +765,7 @@ _pack3_cache = {}
 
 def _packed3(w, kind):
     key = (w.data_ptr(), kind)
-    cacheable = isinstance(w, torch.nn.Parameter)
+    cacheable = _pack_cache_enabled and isinstance(w, torch.nn.Parameter)
     if cacheable:
         hit = _pack3_cache.get(key)
         if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == tuple(w.shape):

@@ -36,11 +36,59 @@ class Adam(torch.optim.Optimizer):
                         foreach=None, capturable=False, differentiable=False, fused=None)
         super().__init__(params, defaults)
 
+    def make_capturable(self):
+        """Move the step counter to the device so that ``step()`` can be captured in a HIP graph and replayed
+        (harness.GraphedTrainer): one float[3] per param group {step, 1 - beta1^step, sqrt(1 - beta2^step)} advanced
+        by gz_adam_tick; the per-parameter ``state['step']`` entries become views of its first element (what
+        torch.optim.Adam(capturable=True) keeps as 0-dim device tensors)."""
+        for group in self.param_groups:
+            params = [p for p in group["params"]]
+            if not params:
+                continue
+            steps = {float(self.state[p]["step"]) for p in params if self.state.get(p)}
+            if len(steps) > 1:
+                raise RuntimeError("capturable fused Adam needs one step count per param group")
+            step = steps.pop() if steps else 0.0
+            beta1, beta2 = group["betas"]
+            tick = torch.tensor([step, 1.0 - beta1 ** step if step else 0.0, (1.0 - beta2 ** step) ** 0.5 if step else 0.0],
+                                dtype=torch.float32, device=params[0].device)
+            group["capturable"] = True
+            group["_tick"] = tick
+            for p in params:
+                _check_tensor(p)
+                st = self.state[p]
+                if not st:
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] = tick[0]
+
+    def _step_capturable(self, group, grad_scale, stream):
+        beta1, beta2 = group["betas"]
+        tick = group["_tick"]
+        plist = [p for p in group["params"] if p.grad is not None]
+        if not plist:
+            return
+        check(lib.gz_adam_tick(ctypes.c_void_p(tick.data_ptr()), float(beta1), float(beta2), stream), "adam_tick")
+        for i in range(0, len(plist), MAX_TENSORS):
+            chunk = plist[i:i + MAX_TENSORS]
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in chunk]
+            numel = (ctypes.c_longlong * len(chunk))(*[p.numel() for p in chunk])
+            check(lib.gz_adam_step_dev(len(chunk), _ptr_array(chunk), _ptr_array(grads),
+                                       _ptr_array([self.state[p]["exp_avg"] for p in chunk]),
+                                       _ptr_array([self.state[p]["exp_avg_sq"] for p in chunk]), numel,
+                                       float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),
+                                       ctypes.c_void_p(tick.data_ptr()), float(grad_scale), stream), "adam_step_dev")
+        for p in plist:
+            F.invalidate(p)
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         loss = closure() if closure is not None else None
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for group in self.param_groups:
+            if group.get("_tick") is not None:
+                self._step_capturable(group, grad_scale, stream)
+                continue
             beta1, beta2 = group["betas"]
             by_step = {}
             for p in group["params"]:
@@ -79,6 +127,12 @@ class RMSprop(torch.optim.Optimizer):
         defaults = dict(lr=lr, momentum=0, alpha=alpha, eps=eps, centered=False, weight_decay=0, capturable=False,
                         foreach=None, maximize=False, differentiable=False)
         super().__init__(params, defaults)
+
+    def make_capturable(self):
+        """RMSprop's update does not depend on the step count: the kernel launch is replayable as it is (the
+        ``state['step']`` counters then count captures, not replays)."""
+        for group in self.param_groups:
+            group["capturable"] = True
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):

@@ -196,3 +196,34 @@ def test_loss_trajectory_tracks_oracle(expt):
     with torch.no_grad():
         a, b = hip.generator(z.cuda()).cpu(), cpu.generator(z)
     assert float((a - b).abs().max()) < TOL * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("expt", ["dc_gan", "wgan", "wgan_gp", scenario.R1_EXPT])
+def test_graphed_trainer_matches_eager_trainer(expt):
+    """harness.GraphedTrainer (each optimizer step captured once in a HIP graph and replayed) against the eager
+    Trainer: same seed, same host RNG stream, same batches -> the same kernels in the same order, so the loss
+    trajectory and the final parameters must agree to rounding (bit-identical in practice)."""
+    from helpers import synthetic_real
+    from lightning_gan_zoo_amd.harness import GraphedTrainer, Trainer
+    kw = dict(batch_size=8, features=8, noise_dim=16)
+    if expt == scenario.R1_EXPT:
+        kw.update(features=4, img_size=32)
+    img = kw.get("img_size", 64)
+    results = {}
+    for name, cls in (("eager", Trainer), ("graph", GraphedTrainer)):
+        cfg = make_cfg(expt, **kw)
+        torch.manual_seed(42)
+        module = locate(cfg.model.lm["_target_"])(cfg, None).to("cuda")
+        trainer = cls(module)
+        torch.manual_seed(7)                      # host generator: latent noise / alpha draws
+        labels = torch.zeros(8, dtype=torch.int64, device="cuda")
+        losses = []
+        for k in range(5 * len(trainer.order)):
+            real = synthetic_real(8, size=img, seed=600 + k).cuda()
+            loss, idx = trainer.step((real, labels))
+            losses.append(float(loss.item()))
+        results[name] = (np.array(losses), {k: v.detach().cpu().clone() for k, v in module.state_dict().items()})
+    (le, se), (lg, sg) = results["eager"], results["graph"]
+    assert np.abs(le - lg).max() <= 1e-6 * max(1.0, np.abs(le).max()), (le, lg)
+    for k in se:
+        assert torch.allclose(se[k].float(), sg[k].float(), rtol=1e-6, atol=1e-7), k
