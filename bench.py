@@ -11,6 +11,7 @@ then training_step(optimizer_idx=1)+backward+Adam on another (SURVEY.md section 
 counts both batches (2*B*N / t_pair).  Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -67,6 +68,12 @@ def timed_pairs(trainer, batch, steps, warmup, world, timer=None):
         trainer.step(batch)
     trainer.finish()
     torch.cuda.synchronize()
+    # A full (generation 2) Python garbage collection walks every object torch and this package have created --
+    # 70 ms here, i.e. ten bs=128 pairs -- and its trigger point is deterministic in the allocation count, so it
+    # kept landing inside one of the timed regions.  Collect now and park the survivors in the permanent
+    # generation: later collections only look at the step's own short-lived objects (< 1 ms).
+    gc.collect()
+    gc.freeze()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()

@@ -168,6 +168,11 @@ def main(argv=None):
         step, epoch = load_checkpoint(ckpt, module, trainer)
         trainer.batch_idx = step
         print("resumed from %s at step %d" % (ckpt, step))
+    # a full Python garbage collection walks every object torch has created (~70 ms, several training steps):
+    # park the set-up's survivors in the permanent generation so that later collections stay short
+    import gc
+    gc.collect()
+    gc.freeze()
     t0 = time.time()
     last = {}
     for batch in data:
