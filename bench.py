@@ -166,6 +166,10 @@ def main():
     ap.add_argument("--force-grad-sync", action="store_true",
                     help="use the data-parallel gradient path (flat buffers, deferred step) even on one rank")
     args = ap.parse_args()
+    # stdout carries exactly one line, the JSON result: library chatter written to file descriptor 1 (RCCL prints its
+    # version banner there when the process group is torn down) is sent to stderr instead
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if args.batch is None:
         args.batch = DEFAULT_BATCH.get(args.expt, 128)
     if args.img_size is None:
@@ -263,7 +267,7 @@ def main():
                             "ms_per_step": round(dt2 / args.steps * 1e3, 3)}
         if world == 1 and not args.no_cpu_baseline and args.expt == "dc_gan":
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=result_out, flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
