@@ -72,8 +72,11 @@ int gz_conv2d_dgrad(const float* y, const float* wpack, const float* bias, float
 
 /* dw[K,C,KH,KW] = weight gradient.  Replaces aten::convolution_backward's grad_weight. */
 size_t gz_conv2d_wgrad_workspace_bytes(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW);
-int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* workspace, size_t ws_bytes, int N, int C,
-                    int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream);
+/* dbias[K] (may be NULL) = sum over pixels of y, the bias gradient: produced in the same pass only by the
+ * launches gz_conv2d_wgrad_fuses_bias reports (3x3 s1 p1 with few channels); otherwise pass NULL and reduce y */
+int gz_conv2d_wgrad_fuses_bias(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P);
+int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* dbias, float* workspace, size_t ws_bytes, int N,
+                    int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream);
 
 /* diagnostic: tile configuration a launch would use (op 0 F, 1 Dg, 2 Wg) -> 0 128x128, 1 128x64, 2 128x32, 3 64x64 */
 int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S);

@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256) void reduce_few_slabs_kernel(const float* __re
 constexpr int RS_WAVES = 16;
 __global__ __launch_bounds__(64 * RS_WAVES) void reduce_slabs_kernel(const float* __restrict__ slab,
                                                                      float* __restrict__ out, int S,
-                                                                     long long count) {
+                                                                     long long count, long long stride,
+                                                                     float* __restrict__ out2, long long split) {
     __shared__ float part[RS_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long i = (long long)blockIdx.x * 64 + lane;
@@ -209,13 +210,13 @@ __global__ __launch_bounds__(64 * RS_WAVES) void reduce_slabs_kernel(const float
     if (i < count) {
         const float* p = slab + i;
         int s = wave;
-        for (; s + 3 * RS_WAVES < S; s += 4 * RS_WAVES) {
-            a0 += p[(long long)s * count];
-            a1 += p[(long long)(s + RS_WAVES) * count];
-            a2 += p[(long long)(s + 2 * RS_WAVES) * count];
-            a3 += p[(long long)(s + 3 * RS_WAVES) * count];
+        for (; s + 3 * RS_WAVES < S; s += 4 * RS_WAVES) {        // `stride` = slab row length (>= count)
+            a0 += p[(long long)s * stride];
+            a1 += p[(long long)(s + RS_WAVES) * stride];
+            a2 += p[(long long)(s + 2 * RS_WAVES) * stride];
+            a3 += p[(long long)(s + 3 * RS_WAVES) * stride];
         }
-        for (; s < S; s += RS_WAVES) a0 += p[(long long)s * count];
+        for (; s < S; s += RS_WAVES) a0 += p[(long long)s * stride];
     }
     part[wave][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
@@ -223,7 +224,8 @@ __global__ __launch_bounds__(64 * RS_WAVES) void reduce_slabs_kernel(const float
         float acc = 0.f;
 #pragma unroll
         for (int w = 0; w < RS_WAVES; ++w) acc += part[w][lane];
-        out[i] = acc;
+        if (out2 && i >= split) out2[i - split] = acc;     // tail of the slab row: the fused bias gradient
+        else out[i] = acc;
     }
 }
 
@@ -611,6 +613,10 @@ __global__ __launch_bounds__(256) void wgrad_smallch_k3_kernel(const float* __re
                                                                FastDiv div_seg, FastDiv div_h) {
     constexpr int NACC = KT * CT * 9;
     __shared__ float red[KT * CT * 9 * 256];
+    __shared__ float bsum[4][KT * 16];
+    float ysum[KT];                 // the bias gradient sum_pixels y[ko] comes for free: y is read here anyway
+#pragma unroll
+    for (int a = 0; a < KT; ++a) ysum[a] = 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int H = s.H, W = s.W, HW = s.H * s.W;
@@ -636,6 +642,7 @@ __global__ __launch_bounds__(256) void wgrad_smallch_k3_kernel(const float* __re
         for (int a = 0; a < KT; ++a) {
             const int ko = a * 16 + i;
             yv[a] = bload4(ry, ko < s.K ? ((n * (uint32_t)s.K + ko) * (uint32_t)HW + (uint32_t)(h * W + wq)) * 4u : OOB, 0);
+            ysum[a] += (yv[a][0] + yv[a][1]) + (yv[a][2] + yv[a][3]);
         }
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
@@ -685,8 +692,21 @@ __global__ __launch_bounds__(256) void wgrad_smallch_k3_kernel(const float* __re
         }
         __syncthreads();
     }
+    // bias gradient: lanes i, i+16, i+32, i+48 hold the same channel; then the four wavefronts in order
+#pragma unroll
+    for (int a = 0; a < KT; ++a) {
+        float v = ysum[a];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 16) bsum[wave][a * 16 + lane] = v;
+    }
+    __syncthreads();
+    // slab row of this workgroup: K*C*9 weight-gradient entries followed by K bias-gradient entries
+    float* out = slab + (long long)blockIdx.x * ((long long)s.K * s.C * 9 + s.K);
+    if (threadIdx.x < KT * 16 && (int)threadIdx.x < s.K)
+        out[(long long)s.K * s.C * 9 + threadIdx.x] =
+            ((bsum[0][threadIdx.x] + bsum[1][threadIdx.x]) + bsum[2][threadIdx.x]) + bsum[3][threadIdx.x];
     // D layout of the 16x16 tile: register r of lane l is (row 4 * (l >> 4) + r, column l & 15) = (ko, c)
-    float* out = slab + (long long)blockIdx.x * s.K * s.C * 9;
     for (int e = threadIdx.x; e < NACC * 256; e += 256) {
         const int l = e & 63, r = (e >> 6) & 3, rest = e >> 8;
         const int t = rest % 9, ab = rest / 9;
@@ -708,11 +728,11 @@ static int wgrad_smallch_blocks(const ConvShape& s) {
     return (int)(blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks));
 }
 
-static int run_wgrad_smallch(const float* x, const float* y, float* dw, float* ws, size_t ws_bytes, const ConvShape& s,
-                             hipStream_t st) {
+static int run_wgrad_smallch(const float* x, const float* y, float* dw, float* dbias, float* ws, size_t ws_bytes,
+                             const ConvShape& s, hipStream_t st) {
     const int blocks = wgrad_smallch_blocks(s);
     const long long count = (long long)s.K * s.C * 9;
-    if (!ws || ws_bytes < (size_t)blocks * count * 4) return GZ_ERR_WORKSPACE;
+    if (!ws || ws_bytes < (size_t)blocks * (count + s.K) * 4) return GZ_ERR_WORKSPACE;
     const int groups = s.N * s.H * (s.W >> 4);
     const FastDiv dseg = make_fastdiv(s.W >> 4), dh = make_fastdiv(s.H);
     const int kt = (s.K + 15) / 16, ct = (s.C + 15) / 16;
@@ -725,8 +745,11 @@ static int run_wgrad_smallch(const float* x, const float* y, float* dw, float* w
     else if (kt == 1 && ct <= 4) GZ_SMALLCH(1, 4);
     else GZ_SMALLCH(4, 1);
 #undef GZ_SMALLCH
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64 * RS_WAVES), 0, st, ws, dw,
-                       blocks, count);
+    // slab rows are count + K long; without a dbias pointer the K-long tails are simply not reduced
+    const long long row = count + s.K;
+    const long long outs = dbias ? row : count;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((outs + 63) / 64)), dim3(64 * RS_WAVES), 0, st, ws, dw, blocks,
+                       outs, row, dbias, count);
     return launch_status();
 }
 
@@ -796,7 +819,7 @@ static int launch_wgrad(const typename AL::Params& pa, const typename BL::Params
                                nz, count);
         else
             hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64 * RS_WAVES), 0, st, ws,
-                               dw, nz, count);
+                               dw, nz, count, count, (float*)nullptr, 0ll);
         rc = launch_status();
     }
     return rc;
@@ -977,7 +1000,7 @@ int gz_conv2d_dgrad(const float* y, const float* wpack, const float* bias, float
 size_t gz_conv2d_wgrad_workspace_bytes(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW) {
     long long count = (long long)K * C * KH * KW;
     ConvShape s{N, C, H, W, K, OH, OW};
-    if (OH == H && OW == W && wgrad_smallch_ok(s, KH, KW, 1, 1)) return (size_t)wgrad_smallch_blocks(s) * count * 4;
+    if (OH == H && OW == W && wgrad_smallch_ok(s, KH, KW, 1, 1)) return (size_t)wgrad_smallch_blocks(s) * (count + K) * 4;
     int chunks = (N * OH * OW + BK - 1) / BK;
     // upper bound over the tile choices: smallest tile count is with 128x128 tiles
     long long tiles = (long long)((K + 127) / 128) * ((C * KH * KW + 127) / 128);
@@ -985,13 +1008,19 @@ size_t gz_conv2d_wgrad_workspace_bytes(int N, int C, int H, int W, int K, int OH
     return splits > 1 ? (size_t)splits * count * 4 : 0;
 }
 
-int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* workspace, size_t ws_bytes, int N, int C,
-                    int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream) {
+int gz_conv2d_wgrad_fuses_bias(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P) {
+    ConvShape s{N, C, H, W, K, OH, OW};
+    return shape_ok(s, KH, KW, S, P) && wgrad_smallch_ok(s, KH, KW, S, P) ? 1 : 0;
+}
+
+int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* dbias, float* workspace, size_t ws_bytes, int N,
+                    int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream) {
     gz::clear_stale_error();
     ConvShape s{N, C, H, W, K, OH, OW};
     if (!shape_ok(s, KH, KW, S, P)) return GZ_ERR_BAD_SHAPE;
     if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
-    if (wgrad_smallch_ok(s, KH, KW, S, P)) return run_wgrad_smallch(x, y, dw, workspace, ws_bytes, s, stream);
+    if (wgrad_smallch_ok(s, KH, KW, S, P)) return run_wgrad_smallch(x, y, dw, dbias, workspace, ws_bytes, s, stream);
+    if (dbias) return GZ_ERR_UNSUPPORTED;       // ask gz_conv2d_wgrad_fuses_bias first
 #define CALL(G) dispatch_wgrad<G>(x, y, dw, workspace, ws_bytes, s, stream)
     GZ_GEOM_DISPATCH(CALL)
 #undef CALL

@@ -196,15 +196,22 @@ def _conv_dgrad_raw(g, w, bias, geom, hw, act, slope):
     return x
 
 
-def _conv_wgrad_raw(x, g, geom):
+def _conv_wgrad_raw(x, g, geom, with_bias=False):
+    """dw (and, with_bias, the bias gradient db = g.sum((0, 2, 3)): in the same launch where the kernel reads all
+    of g anyway -- gz_conv2d_wgrad_fuses_bias -- otherwise by a separate reduction)."""
     N, C, H, W = x.shape
     _, K, OH, OW = g.shape
     dw = torch.empty((K, C, geom.kh, geom.kw), device=x.device, dtype=torch.float32)
     nbytes = lib.gz_conv2d_wgrad_workspace_bytes(N, C, H, W, K, OH, OW, geom.kh, geom.kw)
     ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+    db = None
+    if with_bias and lib.gz_conv2d_wgrad_fuses_bias(N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride, geom.pad):
+        db = torch.empty(K, device=x.device, dtype=torch.float32)
     _timed(2, (N, C, H, W, K, OH, OW), geom, 2.0 * N * OH * OW * K * C * geom.kh * geom.kw, lambda: check(
-        lib.gz_conv2d_wgrad(_p(x), _p(g), _p(dw), _p(ws), nbytes, N, C, H, W, K, OH, OW, geom.kh, geom.kw,
+        lib.gz_conv2d_wgrad(_p(x), _p(g), _p(dw), _p(db), _p(ws), nbytes, N, C, H, W, K, OH, OW, geom.kh, geom.kw,
                             geom.stride, geom.pad, _stream()), "conv2d_wgrad"))
+    if with_bias:
+        return dw, (db if db is not None else g.sum((0, 2, 3)))
     return dw
 
 
@@ -300,6 +307,8 @@ class _ConvF(torch.autograd.Function):
         geom = ctx.geom
         if ctx.act != ACT_NONE:
             gy = _ActBwd.apply(gy, y, ctx.act, ctx.slope)
+        if not torch.is_grad_enabled() and _WG_SIDE_FLOPS <= 0:
+            return _ConvF._first_order(ctx, gy, x, w, geom)
         dx = dw = db = None
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
             dx, dw = _pair_wgrad_dgrad(lambda: _ConvWg.apply(x, gy, geom),
@@ -310,6 +319,23 @@ class _ConvF(torch.autograd.Function):
         elif ctx.needs_input_grad[1]:
             dw = _ConvWg.apply(x, gy, geom)
         if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = gy.sum((0, 2, 3))
+        return dx, dw, db, None, None, None
+
+    @staticmethod
+    def _first_order(ctx, gy, x, w, geom):
+        """No graph is being recorded: raw launches, weight and bias gradient from one kernel where it can."""
+        gy = _req(gy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _conv_dgrad_raw(gy, w, None, geom, tuple(x.shape[2:]), ACT_NONE, 0.0)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            if want_b:
+                dw, db = _conv_wgrad_raw(x, gy, geom, with_bias=True)
+            else:
+                dw = _conv_wgrad_raw(x, gy, geom)
+        elif want_b:
             db = gy.sum((0, 2, 3))
         return dx, dw, db, None, None, None
 
@@ -332,6 +358,12 @@ class _ConvDg(torch.autograd.Function):
         geom = ctx.geom
         if ctx.act != ACT_NONE:
             v = _ActBwd.apply(v, x, ctx.act, ctx.slope)
+        if not torch.is_grad_enabled() and _WG_SIDE_FLOPS <= 0:      # no graph is being recorded: raw launches
+            v = _req(v)
+            dg = _conv_fwd_raw(v, w, None, geom, ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
+            dw = _conv_wgrad_raw(v, g, geom) if ctx.needs_input_grad[1] else None
+            db = v.sum((0, 2, 3)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            return dg, dw, db, None, None, None, None
         dg = dw = db = None
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
             dg, dw = _pair_wgrad_dgrad(lambda: _ConvWg.apply(v, g, geom),

@@ -570,6 +570,10 @@ def test_wgrad_small_channel_3x3(case):
     dw = F._conv_wgrad_raw(x.cuda(), gy.cuda(), F.K3S1P1)
     assert rel(dw, dw_ref) < TOL
     assert torch.equal(dw, F._conv_wgrad_raw(x.cuda(), gy.cuda(), F.K3S1P1))      # fixed summation order
+    # the same launch also yields the bias gradient
+    assert lib.gz_conv2d_wgrad_fuses_bias(N, C, H, H, K, H, H, 3, 3, 1, 1) == 1
+    dw2, db = F._conv_wgrad_raw(x.cuda(), gy.cuda(), F.K3S1P1, with_bias=True)
+    assert torch.equal(dw2, dw) and rel(db, gy.double().sum((0, 2, 3))) < TOL
 
 
 @pytest.mark.parametrize("case", [(16, 16, 64, 16), (4, 3, 128, 16), (4, 16, 128, 3), (16, 32, 64, 32),
