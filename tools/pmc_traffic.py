@@ -46,15 +46,16 @@ def collect(d, counter):
     return out
 
 
-fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
-traffic, detail = {}, {}
-for lab in sorted(set(fetch) & set(write)):
-    nf, f = fetch[lab]
-    nw, w = write[lab]
-    fk, wk = f / nf, w / nw
-    traffic[lab] = int((2 * fk + wk) * 1024)
-    detail[lab] = {"launches_sampled": nf, "fetch_kb_raw": round(fk, 1), "write_kb": round(wk, 1),
-                   "hbm_bytes_per_launch_corrected": traffic[lab], "hbm_bytes_per_launch_raw": int((fk + wk) * 1024)}
-json.dump(traffic, open(sys.argv[3], "w"), indent=1)
-json.dump(detail, open(sys.argv[4], "w"), indent=1)
-print(json.dumps(detail, indent=1))
+if __name__ == "__main__":
+    fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+    traffic, detail = {}, {}
+    for lab in sorted(set(fetch) & set(write)):
+        nf, f = fetch[lab]
+        nw, w = write[lab]
+        fk, wk = f / nf, w / nw
+        traffic[lab] = int((2 * fk + wk) * 1024)
+        detail[lab] = {"launches_sampled": nf, "fetch_kb_raw": round(fk, 1), "write_kb": round(wk, 1),
+                       "hbm_bytes_per_launch_corrected": traffic[lab], "hbm_bytes_per_launch_raw": int((fk + wk) * 1024)}
+    json.dump(traffic, open(sys.argv[3], "w"), indent=1)
+    json.dump(detail, open(sys.argv[4], "w"), indent=1)
+    print(json.dumps(detail, indent=1))
