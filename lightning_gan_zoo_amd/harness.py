@@ -74,7 +74,7 @@ class HostStager:
     same values go through a small ring of pinned buffers and an asynchronous copy instead.  The
     host RNG stream, the values and the device they land on are unchanged."""
 
-    def __init__(self, depth=4):
+    def __init__(self, depth=16):     # deep enough that a buffer is only revisited after several steps (no host wait)
         self.depth = depth
         self.slots = {}     # (shape, dtype) -> [buffers, events, cursor]
 
