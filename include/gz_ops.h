@@ -134,6 +134,9 @@ int gz_norm_coef_elems(int N, int C, int per_channel);
 int gz_batchnorm_stats(const float* x, const float* gamma, const float* beta, float* coef, float* running_mean,
                        float* running_var, long long* num_batches_tracked, void* workspace, int N, int C,
                        int inner, float eps, float momentum, hipStream_t stream);
+/* out[c] = sum over n and the inner dimension of x[n][c][:]: the bias gradient of a convolution (aten's
+ * grad_bias); workspace as for the statistics passes (gz_norm_workspace_bytes) */
+int gz_channel_sum(const float* x, float* out, void* workspace, int N, int C, int inner, hipStream_t stream);
 /* eval-mode coefficients from the running statistics */
 int gz_batchnorm_eval_coef(const float* gamma, const float* beta, const float* running_mean,
                            const float* running_var, float* coef, int C, float eps, hipStream_t stream);

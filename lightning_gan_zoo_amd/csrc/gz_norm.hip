@@ -73,6 +73,16 @@ __global__ __launch_bounds__(PW_THREADS) void row_sums_kernel(const float* __res
     }
 }
 
+// out[c] = sum_n sums[n*C + c].x : second half of gz_channel_sum (bias gradient of a convolution)
+__global__ __launch_bounds__(64) void channel_sum_finalize_kernel(const f32x2* __restrict__ sums, float* __restrict__ out,
+                                                                  int N, int C) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0;
+    for (int n = lane; n < N; n += 64) s += (double)sums[(long long)n * C + c].x;
+    s = wave_sum_d(s);
+    if (lane == 0) out[c] = (float)s;
+}
+
 // BatchNorm finalize: one wavefront per channel; lanes stride over n, fp64 shuffle-combine.
 // coef[0*C..] = scale, coef[1*C..] = shift, coef[2*C..] = mean, coef[3*C..] = rstd
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const f32x2* __restrict__ sums,
@@ -465,6 +475,15 @@ int gz_batchnorm_stats(const float* x, const float* gamma, const float* beta, fl
     hipLaunchKernelGGL(row_sums_kernel, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, (f32x2*)workspace, g);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, stream, (const f32x2*)workspace, gamma, beta, coef,
                        running_mean, running_var, num_batches_tracked, N, C, inner, eps, momentum);
+    return launch_status();
+}
+
+int gz_channel_sum(const float* x, float* out, void* workspace, int N, int C, int inner, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
+    RowGeom g = row_geom((long long)N * C, inner);
+    hipLaunchKernelGGL(row_sums_kernel, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, (f32x2*)workspace, g);
+    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C), dim3(64), 0, stream, (const f32x2*)workspace, out, N, C);
     return launch_status();
 }
 

@@ -196,6 +196,18 @@ def _conv_dgrad_raw(g, w, bias, geom, hw, act, slope):
     return x
 
 
+def _channel_sum_raw(g):
+    """g.sum over every dimension but the channel (the bias gradient of a convolution), no autograd."""
+    N, C = g.shape[0], g.shape[1]
+    inner = g.numel() // (N * C)
+    if inner % 4:
+        return g.sum([d for d in range(g.dim()) if d != 1])
+    out = torch.empty(C, device=g.device, dtype=torch.float32)
+    ws = torch.empty(max(lib.gz_norm_workspace_bytes(N, C) // 4, 1), device=g.device, dtype=torch.float32)
+    check(lib.gz_channel_sum(_p(g), _p(out), _p(ws), N, C, inner, _stream()), "channel_sum")
+    return out
+
+
 def _conv_wgrad_raw(x, g, geom, with_bias=False):
     """dw (and, with_bias, the bias gradient db = g.sum((0, 2, 3)): in the same launch where the kernel reads all
     of g anyway -- gz_conv2d_wgrad_fuses_bias -- otherwise by a separate reduction)."""
@@ -211,7 +223,7 @@ def _conv_wgrad_raw(x, g, geom, with_bias=False):
         lib.gz_conv2d_wgrad(_p(x), _p(g), _p(dw), _p(db), _p(ws), nbytes, N, C, H, W, K, OH, OW, geom.kh, geom.kw,
                             geom.stride, geom.pad, _stream()), "conv2d_wgrad"))
     if with_bias:
-        return dw, (db if db is not None else g.sum((0, 2, 3)))
+        return dw, (db if db is not None else _channel_sum_raw(g))
     return dw
 
 
@@ -336,7 +348,7 @@ class _ConvF(torch.autograd.Function):
             else:
                 dw = _conv_wgrad_raw(x, gy, geom)
         elif want_b:
-            db = gy.sum((0, 2, 3))
+            db = _channel_sum_raw(gy)
         return dx, dw, db, None, None, None
 
 
@@ -362,7 +374,7 @@ class _ConvDg(torch.autograd.Function):
             v = _req(v)
             dg = _conv_fwd_raw(v, w, None, geom, ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
             dw = _conv_wgrad_raw(v, g, geom) if ctx.needs_input_grad[1] else None
-            db = v.sum((0, 2, 3)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            db = _channel_sum_raw(v) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
             return dg, dw, db, None, None, None, None
         dg = dw = db = None
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
@@ -868,7 +880,9 @@ class _Conv3DDg(torch.autograd.Function):
         v = _req(v)
         dg = _Conv3DF.apply(v, w) if ctx.needs_input_grad[0] else None
         dw = _Conv3DWg.apply(v, g, w.shape[2]) if ctx.needs_input_grad[1] else None
-        db = v.sum((0, 2, 3, 4)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = v.sum((0, 2, 3, 4)) if torch.is_grad_enabled() else _channel_sum_raw(v)
         return dg, dw, db
 
 

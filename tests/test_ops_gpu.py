@@ -596,3 +596,11 @@ def test_conv3x3_small_channel_fwd_dgrad(case):
     assert rel(dx, dx_ref) < TOL
     assert rel(F._conv_dgrad_raw(gy.cuda(), w.cuda(), None, g, (H, H), F.ACT_NONE, 0.0),
                TF.conv_transpose2d(gy, w, None, 1, 1)) < TOL
+
+
+@pytest.mark.parametrize("shape", [(8, 16, 32, 32), (3, 5, 4, 4), (64, 64, 16, 16, 16), (2, 7, 6, 10)])
+def test_channel_sum(shape):
+    F = _F()
+    g = rnd(*shape, seed=91)
+    ref = g.double().sum([d for d in range(g.dim()) if d != 1])
+    assert rel(F._channel_sum_raw(g.cuda()), ref) < 1e-5
