@@ -1387,6 +1387,7 @@ struct GridMap {
     int var_chunks;
     int phase_chunks[8];
     int phase_order[8];        // phases by decreasing chunk count
+    int no_swizzle;            // experiment (GZ_NO_XCD_SWIZZLE): plain blockIdx order
 };
 
 // SWAP (transposed accumulators, lanes along m): the slab is kept [n][m] so that its stores and the finish
@@ -1446,8 +1447,10 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
         y = gm.phase_order[bid / tiles];
         bid %= tiles;
     } else {
-        const int q = nwg >> 3, rr = nwg & 7, x = bid & 7, i = bid >> 3;
-        bid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + i;
+        if (!gm.no_swizzle) {
+            const int q = nwg >> 3, rr = nwg & 7, x = bid & 7, i = bid >> 3;
+            bid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + i;
+        }
         // phases of one tile are adjacent (same XCD, close in time): they read the same feature patch and
         // their interleaved stores meet in that XCD's L2.
         y = bid % gm.ny;
@@ -1639,6 +1642,8 @@ inline int launch_igemm(const typename AL::Params& pa, const typename BL::Params
                         const typename Epi::Params& pe, int M, int N, int K, int ny, int splits,
                         hipStream_t stream, float* slab = nullptr, const int* phase_chunks = nullptr) {
     GridMap gm;
+    static int no_swz = getenv("GZ_NO_XCD_SWIZZLE") ? 1 : 0;
+    gm.no_swizzle = no_swz;
     gm.var_chunks = 0;
     if (phase_chunks && ny <= 8) {
         gm.var_chunks = 1;
