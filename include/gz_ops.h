@@ -193,6 +193,12 @@ int gz_avgpool3s2_bwd(const float* gy, float* gx, long long planes, int H, int W
 int gz_upsample2_fwd(const float* x, float* y, long long planes, int H, int W, hipStream_t stream);
 int gz_upsample2_bwd(const float* gy, float* gx, long long planes, int H, int W, hipStream_t stream);
 
+/* ---- input step ---------------------------------------------------------------------------------
+ * decoded uint8 images [N,H,W,C] -> float [N,C,H,W] = (x / 255 - mean) / std: ToTensor() + Normalize(mean, std) of
+ * core/lightning_module.py:42-47 on the device */
+int gz_u8hwc_to_nchw(const unsigned char* in, float* out, int N, int H, int W, int C, float mean, float std,
+                     hipStream_t stream);
+
 /* ---- fused multi-tensor optimizer steps (the `optimiser` nodes of conf/expt/*.yaml) -------------------------
  * `count` <= GZ_OPT_MAX_TENSORS tensors per call (host arrays of device pointers and element counts);
  * grads are multiplied by grad_scale first (1/world for data-parallel means).  Formulas are torch.optim's

@@ -1235,3 +1235,18 @@ class _UpsampleT(torch.autograd.Function):
 def upsample2(x):
     """nn.Upsample(scale_factor=2), nearest (resnet.py:31)."""
     return _Upsample.apply(x)
+
+
+# ---------------------------------------------------------------------------
+# input step (SURVEY.md 8-f2)
+# ---------------------------------------------------------------------------
+def normalize_u8_images(u8, mean, std):
+    """Decoded uint8 images [N,H,W,C] on the GPU -> float [N,C,H,W] = (x / 255 - mean) / std: ToTensor() +
+    Normalize(mean, std) of reference core/lightning_module.py:42-47, one pass on the device."""
+    if not u8.is_cuda or u8.dtype != torch.uint8 or u8.dim() != 4:
+        raise RuntimeError("lightning_gan_zoo_amd: expected a uint8 NHWC tensor on the GPU")
+    u8 = u8 if u8.is_contiguous() else u8.contiguous()
+    N, H, W, C = u8.shape
+    out = torch.empty((N, C, H, W), device=u8.device, dtype=torch.float32)
+    check(lib.gz_u8hwc_to_nchw(_p(u8), _p(out), N, H, W, C, float(mean), float(std), _stream()), "u8hwc_to_nchw")
+    return out

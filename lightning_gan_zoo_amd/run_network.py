@@ -107,6 +107,88 @@ class TensorFileImages:
                 yield real, torch.zeros(self.batch, dtype=torch.int64, device=self.device)
 
 
+IMG_EXTENSIONS = (".jpg", ".jpeg", ".png", ".ppm", ".bmp", ".pgm", ".tif", ".tiff", ".webp")
+
+
+def image_folder_samples(root):
+    """(path, class_index) list with torchvision.datasets.ImageFolder's ordering: classes = sorted sub-directories,
+    inside a class a sorted walk, file names sorted, image extensions only (reference lightning_module.py:89-91)."""
+    classes = sorted(d.name for d in os.scandir(root) if d.is_dir())
+    if not classes:
+        raise FileNotFoundError("no class folders under %r" % root)
+    samples = []
+    for idx, cls in enumerate(classes):
+        for dirpath, _, fnames in sorted(os.walk(os.path.join(root, cls), followlinks=True)):
+            for fname in sorted(fnames):
+                if fname.lower().endswith(IMG_EXTENSIONS):
+                    samples.append((os.path.join(dirpath, fname), idx))
+    return samples, classes
+
+
+class ImageFolderImages:
+    """The reference's real-data input step -- ImageFolder -> Resize((S, S)) -> ToTensor -> Normalize(mean, std),
+    DataLoader without shuffling, incomplete last batch kept (core/lightning_module.py:42-47,89-92) -- with the
+    decode + resize on a background host thread and ToTensor / Normalize / HWC->CHW on the device
+    (functional.normalize_u8_images): the host hands over 1 byte per element through a ring of pinned buffers."""
+
+    def __init__(self, root, batch, img_size, channels, mean, std, device, prefetch=3):
+        self.samples, self.classes = image_folder_samples(root)
+        if not self.samples:
+            raise FileNotFoundError("no images under %r" % root)
+        self.batch, self.size, self.channels = batch, img_size, channels
+        self.mean, self.std, self.device, self.prefetch = mean, std, torch.device(device), prefetch
+
+    def decode(self, path):
+        import numpy as np
+        from PIL import Image
+        with open(path, "rb") as f:
+            img = Image.open(f).convert("RGB" if self.channels == 3 else "L")    # ImageFolder's pil_loader gives RGB
+        img = img.resize((self.size, self.size), Image.BILINEAR)                # transforms.Resize on a PIL image
+        a = np.asarray(img, dtype=np.uint8)
+        return a if a.ndim == 3 else a[:, :, None]
+
+    def host_batches(self):
+        """uint8 [b, S, S, C] arrays and int64 labels, epoch after epoch, in dataset order."""
+        import numpy as np
+        while True:
+            for i in range(0, len(self.samples), self.batch):
+                chunk = self.samples[i:i + self.batch]
+                yield (np.stack([self.decode(p) for p, _ in chunk]), np.array([c for _, c in chunk], dtype=np.int64))
+
+    def __iter__(self):
+        import queue
+        import threading
+        from . import functional as F
+        q = queue.Queue(maxsize=self.prefetch)
+
+        def producer():
+            for item in self.host_batches():
+                q.put(item)
+
+        threading.Thread(target=producer, daemon=True).start()
+        ring, cursor = {}, 0
+        while True:
+            imgs, labels = q.get()
+            if self.device.type != "cuda":        # CPU oracle runs: same arithmetic with torch
+                x = torch.from_numpy(imgs).permute(0, 3, 1, 2).float().div(255).sub(self.mean).div(self.std)
+                yield x, torch.from_numpy(labels)
+                continue
+            key = imgs.shape
+            slots = ring.setdefault(key, [[torch.empty(key, dtype=torch.uint8).pin_memory(), None]
+                                          for _ in range(self.prefetch + 1)])
+            buf, ev = slots[cursor % len(slots)]
+            if ev is not None:
+                ev.synchronize()
+            buf.copy_(torch.from_numpy(imgs))
+            u8 = buf.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            slots[cursor % len(slots)][1] = ev
+            cursor += 1
+            yield (F.normalize_u8_images(u8, self.mean, self.std),
+                   torch.from_numpy(labels).to(self.device, non_blocking=True))
+
+
 def find_ckpt(ckpt_dir):
     """reference run_network.py:19-23: exactly one *.ckpt in the directory, else none."""
     if not ckpt_dir:
@@ -160,6 +242,9 @@ def main(argv=None):
     t = cfg.train
     if run["dataset"] == "synthetic":
         data = SyntheticImages(t.batch_size, t.channels_img, t.img_size, device, 1234 + int(os.environ.get("RANK", "0")))
+    elif run["dataset"] == "image_folder":          # the reference's ImageFolder(root=cfg.dataset.root) (:89-91)
+        data = ImageFolderImages(run["dataset_path"], t.batch_size, t.img_size, t.channels_img, t.data_mean, t.data_std,
+                                 device)
     else:
         data = TensorFileImages(run["dataset_path"], t.batch_size, device)
     step = epoch = 0
