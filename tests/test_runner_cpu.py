@@ -45,3 +45,17 @@ def test_train_checkpoint_resume_roundtrip(tmp_path):
     m2, t2, s2 = R.main(args + ["max_steps=6"])
     assert s2 == 6 and os.listdir(ck) == ["step=6.ckpt"]
     assert t2.optim[0]["optimizer"].state_dict()["state"][0]["step"] >= 3  # Adam state was restored, then advanced
+
+
+def test_runner_trains_from_an_image_folder(tmp_path):
+    """`dataset=image_folder`: the reference's ImageFolder -> Resize -> ToTensor -> Normalize input step feeding
+    the step classes (here the CPU oracle's, so no GPU is needed)."""
+    from test_input_step import make_folder
+    root = str(tmp_path / "imgs")
+    make_folder(root)
+    torch.set_num_threads(2)
+    module, trainer, step = R.main(["+expt=dc_gan", "module_root=oracle.reference_cpu", "device=cpu",
+                                    "dataset=image_folder", "dataset_path=" + root, "train.batch_size=3",
+                                    "train.features_gen=8", "train.features_disc=8", "model.noise_dim=16",
+                                    "max_steps=4", "log_every=1000"])
+    assert step == 4 and all(torch.isfinite(p).all() for p in module.parameters())
