@@ -227,3 +227,51 @@ def test_graphed_trainer_matches_eager_trainer(expt):
     assert np.abs(le - lg).max() <= 1e-6 * max(1.0, np.abs(le).max()), (le, lg)
     for k in se:
         assert torch.allclose(se[k].float(), sg[k].float(), rtol=1e-6, atol=1e-7), k
+
+
+def test_full_size_batch_consistency():
+    """BASELINE size (features 64, bs 512), size-independent property: a sample's output does not depend on its
+    batch when no statistic is shared across samples -- the generator with BatchNorm in eval mode, the WGAN-GP
+    critic with its per-sample InstanceNorm -- and a sum-reduced loss makes gradients additive over the batch.
+    The bs=512 pass runs the 128x128 / 128x64 tiles and the split-K weight gradients, the eight bs=64 passes the
+    small tiles: both must give the same images, scores, input gradients and critic parameter gradients (1e-3);
+    the small-batch pieces are themselves pinned to the CPU oracle by the fixture tests above."""
+    from helpers import fill_closed_form
+    step = build_product_step("wgan_gp", "full")
+    fill_closed_form(step.generator, 1)
+    fill_closed_form(step.discriminator, 2)
+    scenario.stabilise(step)            # LeakyReLU masks away from the threshold: gradients comparable at 1e-3
+    step.to("cuda")
+    step.generator.eval()
+    g = torch.Generator().manual_seed(77)
+    z = torch.randn(512, 100, generator=g).cuda()
+    w = torch.randn(512, generator=g).cuda()            # per-sample loss weights: a non-trivial upstream gradient
+    with torch.no_grad():
+        fake512 = step.generator(z)
+
+    def run(idx):
+        step.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            fake = step.generator(z[idx])
+        images = fake
+        fake = fake512[idx].clone().requires_grad_()     # the critic sees identical inputs in both tilings
+        scores = step.discriminator(fake).reshape(-1)
+        (scores * w[idx]).sum().backward()
+        grads = {n: p.grad.detach().clone() for n, p in step.discriminator.named_parameters()}
+        return images, scores.detach(), fake.grad.detach(), grads
+
+    full = run(slice(0, 512))
+    parts = [run(slice(i, i + 64)) for i in range(0, 512, 64)]
+    worst = {}
+    for k, name in enumerate(("images", "scores", "input gradient")):
+        a, b = full[k], torch.cat([p[k] for p in parts])
+        # forward quantities in max norm; gradients in relative L2 (a LeakyReLU mask entry whose pre-activation is
+        # zero up to rounding may differ between two tilings: a local O(1) change, see test_oracle_golden.compare)
+        worst[name] = float((a - b).abs().max() / b.abs().max()) if k < 2 else float((a - b).norm() / b.norm())
+        assert worst[name] <= TOL, (name, worst[name])
+    for n, gf in full[3].items():
+        gs = sum(p[3][n] for p in parts)
+        err = float((gf - gs).norm() / gs.norm().clamp_min(1e-30))
+        worst["parameter gradients"] = max(worst.get("parameter gradients", 0.0), err)
+        assert err <= TOL, (n, err)
+    print("bs512 vs 8 x bs64:", {k: f"{v:.1e}" for k, v in worst.items()})
