@@ -615,9 +615,25 @@ class _BatchNormAct(torch.autograd.Function):
     def backward(ctx, gout):
         x, coef = ctx.saved_tensors
         N, C, inner, act, slope, training = ctx.cfg
-        if not training:
-            raise RuntimeError("BatchNorm backward in eval mode is outside the hot path")
         gout = _req(gout)
+        if not training:
+            # eval mode: y = act(x * scale[c] + shift[c]) with constants from the running statistics -- a plain
+            # per-channel affine, assembled from the row helpers (not on the training hot path)
+            st = _stream()
+            gp = gout
+            if act != ACT_NONE:
+                out = torch.empty_like(x)
+                check(lib.gz_norm_act_fwd(_p(x), _p(coef), _p(out), N, C, inner, 1, act, slope, st), "norm_act_fwd")
+                gp = _act_bwd_raw(gout, out, act, slope)
+            scale, mean, rstd = coef[:C], coef[2 * C:3 * C], coef[3 * C:]
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = _rowscale_raw(gp.view(N * C, inner), scale.repeat(N).contiguous(), N * C, inner, False).view_as(x)
+            dbeta = _channel_sum_raw(gp)
+            sgx = _rowdot_raw(gp.view(N * C, inner), x.view(N * C, inner), False).view(N, C).sum(0)
+            dgamma = rstd * (sgx - mean * dbeta)
+            return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
+                    None, None, None, None, None, None, None, None)
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
         dgamma = torch.empty(C, device=x.device, dtype=torch.float32)

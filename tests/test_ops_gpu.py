@@ -604,3 +604,23 @@ def test_channel_sum(shape):
     g = rnd(*shape, seed=91)
     ref = g.double().sum([d for d in range(g.dim()) if d != 1])
     assert rel(F._channel_sum_raw(g.cuda()), ref) < 1e-5
+
+
+@pytest.mark.parametrize("act", ["relu", "lrelu"])
+def test_batchnorm_eval_mode_backward(act):
+    """Eval-mode BatchNorm + activation (running statistics as constants): dx, dgamma, dbeta against torch."""
+    F = _F()
+    N, C, H = 6, 12, 8
+    x, g, b = rnd(N, C, H, H, seed=101), rnd(C, seed=102).abs() + 0.5, rnd(C, seed=103)
+    rm, rv, go = rnd(C, seed=104), rnd(C, seed=105).abs() + 0.3, rnd(N, C, H, H, seed=106)
+    xr, gr, br = (t.clone().requires_grad_() for t in (x, g, b))
+    y = TF.batch_norm(xr, rm.clone(), rv.clone(), gr, br, False, 0.1, 1e-5)
+    y = TF.relu(y) if act == "relu" else TF.leaky_relu(y, 0.2)
+    y.backward(go)
+    xd, gd, bd = (t.cuda().requires_grad_() for t in (x, g, b))
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    yd = F.batch_norm_act(xd, gd, bd, rm.cuda(), rv.cuda(), nbt, False, 0.1, 1e-5,
+                          F.ACT_RELU if act == "relu" else F.ACT_LRELU, 0.2)
+    yd.backward(go.cuda())
+    assert rel(yd, y) < TOL and rel(xd.grad, xr.grad) < TOL and rel(gd.grad, gr.grad) < TOL and rel(bd.grad, br.grad) < TOL
+    assert int(nbt) == 0
