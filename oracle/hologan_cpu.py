@@ -92,7 +92,10 @@ def view_matrices(view, size=16, new_size=16):
     """Inverse of  C_new . (T . S . (Rz . Ry)) . C_old  per sample, fp32, same association order as
     hologan_generator.py:145-214."""
     view = torch.as_tensor(view)
-    dt = torch.get_default_dtype()      # float32; float64 only in the conditioning run of make_golden.py
+    # always float32, as the reference hard-codes it (:148-186): the clamped-corner interpolation is DISCONTINUOUS
+    # at the volume faces (x = -0 gives weights ~0, x = +0 gives the voxel), which right-angle views hit exactly,
+    # so the coordinates must be the reference's fp32 ones even in make_golden.py's float64 conditioning run
+    dt = torch.float32
     col = lambda i: view[:, i].reshape(-1, 1, 1).to(dt)       # noqa: E731
     th, ga, sc, tx, ty, tz = (col(i) for i in range(6))
     one, zero = torch.ones_like(th), torch.zeros_like(th)
@@ -150,8 +153,9 @@ def trilinear_indices(vox_shape, x, y, z):
 def rigid_resample(vox, view, size=16, new_size=16):
     """transformation3d + apply_transformation + interpolation: [N,C,16,16,16] -> [N,C,16,16,16]."""
     n, c = vox.shape[:2]
-    x, y, z = resample_coords(view_matrices(view, size, new_size), new_size)
+    x, y, z = resample_coords(view_matrices(view, size, new_size), new_size)     # float32 coordinates
     idx, wts = trilinear_indices(vox.shape, x, y, z)
+    wts = [w.to(vox.dtype) for w in wts]
     flat = vox.permute(0, 2, 3, 4, 1).reshape(-1, c)
     out = None
     for i, w in zip(idx, wts):

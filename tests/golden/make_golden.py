@@ -44,9 +44,9 @@ class _TorchProxy:
         return getattr(torch, name)
 
 
-def build_reference_step(expt, size):
+def build_reference_step(expt, size, stable=False):
     ns = ref_import.load_reference()
-    cfg = make_cfg(expt, module_root="core", **scenario.cfg_kwargs(expt, size))
+    cfg = make_cfg(expt, module_root="core", **scenario.cfg_kwargs(expt, size, stable))
     cfg = ref_import.to_attr(cfg)
     if expt == "hologan":
         cfg.generator["gpu"] = False
@@ -55,30 +55,60 @@ def build_reference_step(expt, size):
     return cls(cfg, logging_dir=None), ns
 
 
-def build_oracle_step(expt, size):
+def build_oracle_step(expt, size, stable=False):
     from lightning_gan_zoo_amd.config import locate
-    cfg = make_cfg(expt, module_root="oracle.reference_cpu", **scenario.cfg_kwargs(expt, size))
+    cfg = make_cfg(expt, module_root="oracle.reference_cpu", **scenario.cfg_kwargs(expt, size, stable))
     torch.manual_seed(42)
     return locate(cfg.model.lm["_target_"])(cfg, logging_dir=None)
 
 
+class _MaskMargins:
+    """Smallest |pre-activation| every ReLU / LeakyReLU module of the reference saw during a run, keyed by the
+    input's per-sample shape (a global forward-pre hook: the reference is observed, not modified)."""
+
+    def __init__(self):
+        self.margins = {}
+
+    def __enter__(self):
+        def hook(mod, inp):
+            if isinstance(mod, (torch.nn.ReLU, torch.nn.LeakyReLU)):
+                x = inp[0].detach()
+                key = "%s%s" % (type(mod).__name__, "x".join(str(d) for d in x.shape[1:]))
+                self.margins[key] = min(self.margins.get(key, float("inf")), float(x.abs().min()))
+        self.handle = torch.nn.modules.module.register_module_forward_pre_hook(hook)
+        return self
+
+    def __exit__(self, *exc):
+        self.handle.remove()
+
+
 def run_reference(expt, size, stable, dtype, full, inputs):
+    """The step is always CONSTRUCTED under the float32 default dtype, whatever ``dtype`` the run uses: the
+    spectral-norm ``weight_u / weight_v`` buffers are drawn at construction, and drawing them in double gives
+    different vectors -- the fp64 run would then measure "another u/v", not fp32 rounding (that is what the
+    round-1 HoloGAN ``cond/`` entries did)."""
     if expt == "hologan" and dtype == torch.float64:
         # the reference's resampler hard-codes float32 (hologan_generator.py:148-186,327-330), so its
         # conditioning run uses the oracle, which test_oracle_golden.py pins to the reference in fp32
-        step = build_oracle_step(expt, size)
-        return scenario.run_scenario(step, inputs, "cpu", full=full, stable=stable, dtype=dtype)
-    step, ns = build_reference_step(expt, size)
+        step = build_oracle_step(expt, size, stable)
+        torch.set_default_dtype(torch.float64)
+        try:
+            return scenario.run_scenario(step, inputs, "cpu", full=full, stable=stable, dtype=dtype)
+        finally:
+            torch.set_default_dtype(torch.float32)
+    step, ns = build_reference_step(expt, size, stable)
     proxy = _TorchProxy()
     ns.utils.torch = proxy
 
     def set_alpha(_step, alpha, proxy=proxy):
         proxy.alpha = alpha
 
+    torch.set_default_dtype(dtype)
     try:
         out = scenario.run_scenario(step, inputs, "cpu", full=full, set_alpha=set_alpha, stable=stable,
                                     dtype=dtype)
     finally:
+        torch.set_default_dtype(torch.float32)
         ns.utils.torch = torch
     return out
 
@@ -102,21 +132,33 @@ def main(argv):
     expts = argv or list(scenario.STD_EXPTS)
     for expt in expts:
         variants = [("tiny", False), ("full", False)]
-        if expt in ("dc_gan", "wgan_gp"):   # WGAN clamps every D parameter (norm biases too); HoloGAN's D norm has no bias
+        if expt in ("dc_gan", "wgan_gp", "hologan"):   # WGAN clamps every D parameter (norm biases too)
             variants.append(("full", True))
         for size, stable in variants:
             full = size == "tiny"
-            inputs = scenario.make_inputs(expt, size, stable)      # drawn in fp32, shared by both runs
+            seed_offset, margins = 0, {}
+            if expt == "hologan" and stable:
+                # the discriminator's InstanceNorm2d(affine=False) -> LeakyReLU masks cannot be shifted off the
+                # threshold (scenario.stabilise_hologan); keep the inputs whose closest call is the least close
+                best = None
+                for so in range(6):
+                    with _MaskMargins() as mm:
+                        run_reference(expt, size, stable, torch.float32, False,
+                                      scenario.make_inputs(expt, size, stable, so))
+                    worst = min(mm.margins.values())
+                    print(f"  seed_offset {so}: smallest |pre-activation| {worst:.2e}")
+                    if best is None or worst > best[0]:
+                        best = (worst, so, dict(mm.margins))
+                _, seed_offset, margins = best
+            inputs = scenario.make_inputs(expt, size, stable, seed_offset)      # drawn in fp32, shared by both runs
             out = run_reference(expt, size, stable, torch.float32, full, inputs)
             # fp64 run of the same reference code: how well-defined is each quantity in fp32?
-            torch.set_default_dtype(torch.float64)
-            try:
-                o64 = run_reference(expt, size, stable, torch.float64, True, inputs)
-            finally:
-                torch.set_default_dtype(torch.float32)
+            o64 = run_reference(expt, size, stable, torch.float64, True, inputs)
             o32_full = out if full else run_reference(expt, size, stable, torch.float32, True, inputs)
             cond = sensitivity(o32_full, o64)
             blob = {"in/" + k: v.numpy() for k, v in inputs.items() if not k.startswith("real_")}
+            blob["in/seed_offset"] = np.int64(seed_offset)
+            blob.update({"margin/" + k: np.float64(v) for k, v in margins.items()})
             blob["in/real_checksum"] = np.float64(sum(float(v.double().sum()) for k, v in sorted(inputs.items())
                                                       if k.startswith("real_")))
             blob.update({"out/" + k: np.asarray(v) for k, v in out.items()})

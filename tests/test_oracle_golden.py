@@ -14,8 +14,8 @@ from lightning_gan_zoo_amd.config import locate, make_cfg
 ORACLE_ROOT = "oracle.reference_cpu"
 
 
-def build_oracle_step(expt, size):
-    cfg = make_cfg(expt, module_root=ORACLE_ROOT, **scenario.cfg_kwargs(expt, size))
+def build_oracle_step(expt, size, stable=False):
+    cfg = make_cfg(expt, module_root=ORACLE_ROOT, **scenario.cfg_kwargs(expt, size, stable))
     torch.manual_seed(42)
     return locate(cfg.model.lm["_target_"])(cfg, logging_dir=None)
 
@@ -24,9 +24,10 @@ def load_golden(expt, size, stable=False):
     """-> (inputs, golden outputs, cond).  The synthetic reals are regenerated from their seeds
     and checked against the fixture's checksum; z / alpha come from the fixture."""
     blob = np.load(os.path.join(GOLDEN_DIR, f"{expt}_{size}{'_stable' if stable else ''}.npz"))
-    inputs = scenario.make_inputs(expt, size, stable)
+    seed_offset = int(blob["in/seed_offset"]) if "in/seed_offset" in blob.files else 0
+    inputs = scenario.make_inputs(expt, size, stable, seed_offset)
     for k in blob.files:
-        if k.startswith("in/") and k != "in/real_checksum":
+        if k.startswith("in/") and k not in ("in/real_checksum", "in/seed_offset"):
             assert torch.equal(inputs[k[3:]], torch.from_numpy(blob[k])), f"host RNG drift in {k}"
     chk = sum(float(v.double().sum()) for k, v in sorted(inputs.items()) if k.startswith("real_"))
     assert abs(chk - float(blob["in/real_checksum"])) < 1e-6 * max(1.0, abs(chk)), "host RNG drift in reals"
@@ -57,7 +58,7 @@ def update_agreement(out, golden, init, lr):
 
 
 def compare(out, golden, tol, label, atol_scale=None, cond=None, cond_factor=10.0, final_abs=0.0,
-            grad_floor=0.0, final_tol=2e-4):
+            grad_floor=0.0, final_tol=2e-4, report=False):
     """Every recorded quantity within ``tol`` of the fixture, relative to the largest reference
     magnitude of that quantity (scalars: relative to max(|ref|, atol_scale), where atol_scale is
     the logit scale -- WGAN losses are differences of logit means).  Integer tensors (BatchNorm
@@ -119,6 +120,12 @@ def compare(out, golden, tol, label, atol_scale=None, cond=None, cond_factor=10.
             e = max(e, max(d.max() - slack, 0.0) / scale / 10.0)
         errs.append((e / t, e, t, k))
     errs.sort(reverse=True)
+    if report:       # distribution of bars / errors (pytest -s)
+        bars = np.array([t for _, _, t, _ in errs])
+        es = np.array([e for _, e, _, _ in errs])
+        print(f"{label}: {len(errs)} quantities; bars <= 1e-3: {(bars <= 1e-3).sum()}, <= 1e-2: {(bars <= 1e-2).sum()}, "
+              f"max bar {bars.max():.1e}; errors > 1e-3: {[(k, f'{e:.1e}') for _, e, _, k in errs if e > 1e-3]}; "
+              f"median error {np.median(es):.1e}")
     worst = errs[0]
     assert worst[0] <= 1.0, (f"{label}: {worst[3]} rel err {worst[1]:.3e} > bar {worst[2]:.3e}; "
                              f"next: {[(k, f'{e:.1e}/{t:.1e}') for _, e, t, k in errs[1:4]]}")
@@ -150,14 +157,36 @@ def test_oracle_matches_reference_fixture(expt, size):
             final_tol=2e-2 if expt == "hologan" else 2e-4)
 
 
-@pytest.mark.parametrize("expt", ["dc_gan", "wgan_gp"])
+@pytest.mark.parametrize("expt", ["dc_gan", "wgan_gp", "hologan"])
 def test_oracle_matches_stable_mask_fixture(expt):
     torch.set_num_threads(4)
-    inputs, golden, _ = load_golden(expt, "full", stable=True)
-    step = build_oracle_step(expt, "full")
+    inputs, golden, cond = load_golden(expt, "full", stable=True)
+    step = build_oracle_step(expt, "full", stable=True)
     out = scenario.run_scenario(step, inputs, "cpu", full=False, set_alpha=set_alpha, stable=True)
     scale = float(np.abs(golden["probe/logits"]).max())
-    compare(out, golden, 1e-5, f"oracle {expt}/full/stable", atol_scale=scale)
+    if expt == "hologan":
+        # the early generator layers' gradients are ~1e-7 differences of O(1) terms (AdaIN projects the constant
+        # part out): the CPU kernels' thread-count-dependent summation order alone moves them by ~1e-4, which is
+        # also what the fixture's own fp32-vs-fp64 sensitivity says -- so the bar follows cond there
+        compare(out, golden, 1e-5, f"oracle {expt}/full/stable", atol_scale=scale, cond=cond)
+    else:
+        compare(out, golden, 1e-5, f"oracle {expt}/full/stable", atol_scale=scale)
+
+
+def test_hologan_fixture_conditioning_is_rounding_not_a_different_state():
+    """Round-1 finding: the HoloGAN ``cond/`` entries came from an fp64 run whose spectral-norm u / v had been
+    re-drawn in double (and whose right-angle views fell on the other side of the resampler's face discontinuity),
+    so every gradient bar was 20-900 %.  With the state shared and the coordinates kept in fp32 the fp32-vs-fp64
+    discrepancy is what it should be: ~1e-7 for the power-iteration buffers, <= 1e-2 for every gradient."""
+    for size, stable in (("tiny", False), ("full", False), ("full", True)):
+        _, golden, cond = load_golden("hologan", size, stable)
+        for k, v in cond.items():
+            if k.startswith(("buf_d/", "probe/")):
+                assert v < 1e-4, (size, stable, k, v)
+            elif k.startswith("grad") and v < 1.0:        # > 1: exactly-zero gradients (conv bias in front of AdaIN)
+                assert v < 1e-2, (size, stable, k, v)
+        zero = [k for k, v in cond.items() if v > 1.0]
+        assert all(k.endswith((".convTranspose.bias", "conv2d.bias")) and "blocks." in k or "block" in k for k in zero), zero
 
 
 def test_oracle_state_dict_names_match_reference_listing():
