@@ -139,15 +139,19 @@ def main(argv):
             seed_offset, margins = 0, {}
             if expt == "hologan" and stable:
                 # the discriminator's InstanceNorm2d(affine=False) -> LeakyReLU masks cannot be shifted off the
-                # threshold (scenario.stabilise_hologan); keep the inputs whose closest call is the least close
+                # threshold (scenario.stabilise_hologan): of ~3 M pre-activations a few always lie within fp32
+                # rounding of zero.  Keep the inputs on which the reference's own fp32 and fp64 runs agree best
+                # (no mask entry of THAT pair on the other side), and record how close the closest call was.
                 best = None
                 for so in range(6):
+                    cand = scenario.make_inputs(expt, size, stable, so)
                     with _MaskMargins() as mm:
-                        run_reference(expt, size, stable, torch.float32, False,
-                                      scenario.make_inputs(expt, size, stable, so))
-                    worst = min(mm.margins.values())
-                    print(f"  seed_offset {so}: smallest |pre-activation| {worst:.2e}")
-                    if best is None or worst > best[0]:
+                        c32 = run_reference(expt, size, stable, torch.float32, True, cand)
+                    c64 = run_reference(expt, size, stable, torch.float64, True, cand)
+                    worst = max(v for k, v in sensitivity(c32, c64).items() if k.startswith("grad") and v < 1.0)
+                    print(f"  seed_offset {so}: worst gradient cond {worst:.2e}, smallest |pre-activation| "
+                          f"{min(mm.margins.values()):.2e}")
+                    if best is None or worst < best[0]:
                         best = (worst, so, dict(mm.margins))
                 _, seed_offset, margins = best
             inputs = scenario.make_inputs(expt, size, stable, seed_offset)      # drawn in fp32, shared by both runs

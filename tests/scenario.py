@@ -144,6 +144,32 @@ def _prepare(step, stable):
         (stabilise_hologan if step.cfg["name"] == "hologan" else stabilise)(step)
 
 
+def seed_views(step, seed):
+    """Seed numpy's global generator (HoloGAN draws its views from it, hologan_generator.py:80-114) so that no
+    sampled azimuth / elevation is a multiple of 90 degrees.  The reference's clamped-corner interpolation is
+    DISCONTINUOUS at the volume faces (a source coordinate of 15 - 1e-6 reads voxel 15, 15.0 reads ~0), and an
+    axis-aligned view puts a whole face of source coordinates exactly there: which side they fall on then depends
+    on the last bit of the host's 4x4 inverse / matmul, i.e. on the CPU model -- the same reference code gives
+    losses 2 % apart on two hosts (measured: Xeon build container vs EPYC GPU box).  Such views are not a
+    well-defined reference input, so the scenarios skip them (by trying seed, seed + 100000, ...)."""
+    args = getattr(getattr(step, "generator", None), "view_args", None)
+    if args is None:
+        np.random.seed(seed)
+        return seed
+    bs = int(args["batch_size"])
+    while True:
+        np.random.seed(seed)
+        az = np.random.randint(args["azimuth_low"], args["azimuth_high"], (bs))
+        ok = bool((az % 90 != 0).all())
+        if ok and args["elevation_low"] < args["elevation_high"]:
+            el = np.random.randint(args["elevation_low"], args["elevation_high"], (bs))
+            ok = bool((el % 90 != 0).all())
+        if ok:
+            np.random.seed(seed)
+            return seed
+        seed += 100000
+
+
 def _toggle(step, idx):
     for p in step.discriminator.parameters():
         p.requires_grad_(idx == 0)
@@ -200,7 +226,7 @@ def run_scenario(step, inputs, device="cpu", full=True, set_alpha=None, pairs=2,
     labels = torch.zeros(len(inputs["real_d0"]), dtype=torch.int64, device=dev)
 
     probe = copy.deepcopy(step)
-    np.random.seed(7000)            # HoloGAN draws its views from numpy's global generator
+    seed_views(step, 7000)          # HoloGAN draws its views from numpy's global generator
     with torch.no_grad():
         fake = probe.generator(inputs["z_d0"].to(dev))
         d_out = probe.discriminator(fake)
@@ -225,10 +251,10 @@ def run_scenario(step, inputs, device="cpu", full=True, set_alpha=None, pairs=2,
                 if set_alpha is not None:
                     set_alpha(shadow, inputs[f"alpha{pair}"])
                 _toggle(shadow, idx)
-                np.random.seed(view_seed)
+                seed_views(step, view_seed)
                 sl = shadow.training_step((inputs[f"real_{tag}{pair}"].detach().clone(), labels.cpu()), 2 * pair + idx, idx)
                 out[f"shadow_loss_{tag}{pair}"] = np.float64(sl.item())
-            np.random.seed(view_seed)
+            seed_views(step, view_seed)
             loss = step.training_step((real, labels), 2 * pair + idx, idx)
             loss.backward()
             out[f"loss_{tag}{pair}"] = np.float64(loss.item())

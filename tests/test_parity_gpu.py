@@ -37,7 +37,7 @@ def test_product_matches_reference_fixture(expt, size):
                                 shadow=build_oracle_step(expt, size))
     scale = float(np.abs(golden["probe/logits"]).max())
     worst = compare(out, golden, TOL, f"hip {expt}/{size}", atol_scale=scale, cond=cond,
-                    final_abs=2 * 2 * LR[expt], grad_floor=5e-3)
+                    final_abs=2 * 2 * LR[expt], grad_floor=5e-3, report=True)
     print(f"{expt}/{size}: worst {worst[3]} err {worst[1]:.2e} (bar {worst[2]:.2e})")
     # second pair: HIP loss vs the CPU oracle evaluated on the SAME (HIP-trained) parameters
     for tag in ("d", "g"):
@@ -95,51 +95,77 @@ def test_product_matches_stable_mask_fixture(expt):
     print(f"{expt}/full/stable: worst {worst[3]} err {worst[1]:.2e} (bar {worst[2]:.2e})")
 
 
-def test_hologan_training_step_gradients_match_oracle_directly():
-    """HOLOGAN.training_step on the HIP path against the CPU oracle holding the SAME state (parameters and the
-    spectral-norm u / v buffers copied over), reference-default width (in_planes 64, z 128), bs 8, default
-    initialisation rescaled as in the stable scenario: D step and G step, every parameter gradient in relative L2,
-    the u / v buffers after the step, both losses."""
+@pytest.mark.parametrize("init", ["closed_form", "default_init", "stable"])
+def test_hologan_step_gradients_with_pinned_masks(init):
+    """HOLOGAN.training_step at the reference's default width (in_planes 64, z 128) and bs 8, HIP vs the CPU oracle
+    holding the same state and taking the SAME ReLU / LeakyReLU decisions (tests/mask_pinning.py): every parameter
+    gradient of the D step and of the G step within 1e-3 relative L2, the spectral-norm buffers and losses within
+    1e-3.  The handful of mask entries on which the two implementations would disagree by themselves are counted
+    and must be rounding-level (|pre-activation| <= 1e-4, fewer than 1 % of all entries; with the default
+    initialisation whole AdaIN rows have scale = shift = 0, i.e. pre-activations of +-0 / 1e-12, and account for
+    almost all of them)."""
     from helpers import FixedNoise, synthetic_noise, synthetic_real
+    from mask_pinning import MaskTape, pinned_oracle_masks, record_product_masks
     kw = dict(batch_size=8, features=64, noise_dim=128)
     steps = {}
-    for name, root, dev in (("hip", None, "cuda"), ("cpu", "oracle.reference_cpu", "cpu")):
+    for name, root in (("hip", None), ("cpu", "oracle.reference_cpu")):
         cfg = make_cfg("hologan", **({"module_root": root} if root else {}), **kw)
         torch.manual_seed(1234)
         steps[name] = locate(cfg.model.lm["_target_"])(cfg, None)
     hip, cpu = steps["hip"], steps["cpu"]
-    scenario.stabilise_hologan(hip)
+    if init != "default_init":
+        scenario._prepare(hip, init == "stable")
     for net in ("generator", "discriminator"):
         getattr(cpu, net).load_state_dict(getattr(hip, net).state_dict())
     hip.to("cuda")
-    worst = {}
+    worst, flips, entries = {}, 0, 0
     for idx, tag in ((0, "d"), (1, "g")):
+        z = synthetic_noise(8, 128, 41 + idx, uniform=True)
+        real = synthetic_real(8, seed=51 + idx)
+        if init == "stable":
+            real = real.abs() * 0.9 + 0.1
+        labels = torch.zeros(8, dtype=torch.int64)
         res = {}
+        tape = MaskTape()
         for name, step, dev in (("hip", hip, "cuda"), ("cpu", cpu, "cpu")):
             scenario._toggle(step, idx)
             step.zero_grad(set_to_none=True)
-            step.noise_distn = FixedNoise(synthetic_noise(8, 128, 41 + idx, uniform=True))
-            real = (synthetic_real(8, seed=51 + idx).abs() * 0.9 + 0.1).to(dev)
-            np.random.seed(61 + idx)
-            loss = step.training_step((real, torch.zeros(8, dtype=torch.int64, device=dev)), idx, idx)
+            step.noise_distn = FixedNoise(z)
+            scenario.seed_views(step, 61 + idx)
+            batch = (real.clone().to(dev), labels.to(dev))
+            if name == "hip":
+                with record_product_masks(tape):
+                    loss = step.training_step(batch, idx, idx)
+            else:
+                with pinned_oracle_masks(step, tape):
+                    loss = step.training_step(batch, idx, idx)
+                assert tape.cursor == len(tape.masks), "the two forward passes took different numbers of mask decisions"
             loss.backward()
             net = step.discriminator if idx == 0 else step.generator
-            res[name] = (float(loss), {n: p.grad.detach().double().cpu() for n, p in net.named_parameters()},
+            res[name] = (float(loss.detach()), {n: p.grad.detach().double().cpu() for n, p in net.named_parameters()},
                          {n: b.detach().double().cpu() for n, b in step.discriminator.named_buffers()})
+        flips += sum(m[1] for m in tape.mismatches)
+        if tape.mismatches:
+            print(f"  {tag}-step mask decisions that differ (tape position, entries, of, max |x|):", tape.mismatches)
+        entries += sum(m.numel() for m in tape.masks)
+        assert all(m[3] <= 1e-4 for m in tape.mismatches), tape.mismatches     # only rounding-level pre-activations
         (lh, gh, bh), (lc, gc, bc) = res["hip"], res["cpu"]
         assert abs(lh - lc) <= TOL * max(1.0, abs(lc)), (tag, lh, lc)
         for n in bc:
-            e = float((bh[n] - bc[n]).abs().max() / bc[n].abs().max())
-            assert e <= TOL, (tag, n, e)
+            assert float((bh[n] - bc[n]).abs().max() / bc[n].abs().max()) <= TOL, (tag, n)
         for n, ref in gc.items():
-            if float(ref.norm()) < 1e-9 * max(float(v.norm()) for v in gc.values()):
-                continue        # conv biases in front of AdaIN / InstanceNorm: exactly zero up to rounding
-            e = float((gh[n] - ref).norm() / ref.norm())
-            worst[f"{tag}/{n}"] = e
-    top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
-    print("hologan step HIP vs oracle, relative L2 of gradients:", [(k, f"{v:.1e}") for k, v in top])
-    # 2.5e-3 = one flipped LeakyReLU element behind an InstanceNorm2d(affine=False) (see the stable-fixture test)
-    assert top[0][1] <= 2.5e-3, top
+            if n.endswith(("convTranspose.bias", "conv2d.bias")) and n.startswith("block"):
+                # a per-channel constant in front of AdaIN / InstanceNorm is removed by the mean subtraction: the
+                # exact gradient is 0 and both implementations hold rounding noise
+                wn = n.rsplit(".", 1)[0] + (".weight_orig" if tag == "d" else ".weight")
+                assert float(gh[n].norm()) <= 1e-3 * float(gh[wn].norm()), (tag, n)
+                continue
+            worst[f"{tag}/{n}"] = float((gh[n] - ref).norm() / ref.norm())
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    print(f"hologan {init}: {flips} of {entries} mask entries differ by themselves; worst gradients (rel L2):",
+          [(k, f"{v:.1e}") for k, v in top])
+    assert flips <= 1e-2 * entries
+    assert top[0][1] <= TOL, top
 
 
 def test_logits_within_1e3_of_cpu_reference():

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Diagnostic (GPU): run the HoloGAN scenario steps on the HIP product and on the CPU oracle from the SAME state and
+report, per step, (a) how many ReLU / LeakyReLU mask entries differ between the two (sign of every block output),
+(b) the relative L2 error of every gradient.  Separates "a mask entry landed on the other side" from kernel errors.
+
+    python tools/hologan_flip_probe.py [tiny|full] [stable]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import scenario  # noqa: E402
+from helpers import FixedNoise  # noqa: E402
+from lightning_gan_zoo_amd.config import locate, make_cfg  # noqa: E402
+
+
+def build(root, size, stable):
+    kw = {"module_root": root} if root else {}
+    cfg = make_cfg("hologan", **kw, **scenario.cfg_kwargs("hologan", size, stable))
+    torch.manual_seed(42)
+    return locate(cfg.model.lm["_target_"])(cfg, None)
+
+
+def hook_outputs(step, store):
+    hs = []
+    for net_name in ("generator", "discriminator"):
+        net = getattr(step, net_name)
+        for name, m in net.named_modules():
+            if name and name.count(".") <= 1 and not isinstance(m, (torch.nn.ReLU, torch.nn.LeakyReLU, torch.nn.Tanh,
+                                                                      torch.nn.Sigmoid)):
+                def fn(mod, inp, out, key=net_name + "." + name):
+                    o = out[0] if isinstance(out, tuple) else out
+                    store.setdefault(key, []).append(o.detach().double().cpu())
+                hs.append(m.register_forward_hook(fn))
+    return hs
+
+
+def main():
+    size = sys.argv[1] if len(sys.argv) > 1 else "full"
+    stable = "stable" in sys.argv[2:]
+    inputs = scenario.make_inputs("hologan", size, stable, 1 if (stable and size == "full") else 0)
+    hip, cpu = build(None, size, stable), build("oracle.reference_cpu", size, stable)
+    scenario._prepare(hip, stable)
+    for net in ("generator", "discriminator"):
+        getattr(cpu, net).load_state_dict(getattr(hip, net).state_dict())
+    hip.to("cuda")
+    bs = len(inputs["real_d0"])
+    for pair in range(2):
+        for idx, tag in ((0, "d"), (1, "g")):
+            acts = {"hip": {}, "cpu": {}}
+            res = {}
+            for name, step, dev in (("hip", hip, "cuda"), ("cpu", cpu, "cpu")):
+                hs = hook_outputs(step, acts[name])
+                scenario._toggle(step, idx)
+                step.zero_grad(set_to_none=True)
+                step.noise_distn = FixedNoise(inputs[f"z_{tag}{pair}"])
+                scenario.seed_views(step, 7001 + 2 * pair + idx)
+                real = inputs[f"real_{tag}{pair}"].clone().to(dev)
+                loss = step.training_step((real, torch.zeros(bs, dtype=torch.int64, device=dev)), 0, idx)
+                loss.backward()
+                for h in hs:
+                    h.remove()
+                net = step.discriminator if idx == 0 else step.generator
+                res[name] = (float(loss.detach()), {n: p.grad.detach().double().cpu() for n, p in net.named_parameters()})
+            # keep the two in the same state (the u / v power iteration advanced in both)
+            print(f"--- pair {pair} {tag}-step: loss hip {res['hip'][0]:.7f} cpu {res['cpu'][0]:.7f}")
+            for key in acts["cpu"]:
+                for i, (a, b) in enumerate(zip(acts["hip"].get(key, []), acts["cpu"][key])):
+                    if a.shape != b.shape:
+                        continue
+                    flips = int(((a > 0) != (b > 0)).sum())
+                    err = float((a - b).norm() / b.norm().clamp_min(1e-30))
+                    if flips or err > 1e-4:
+                        print(f"    {key}[{i}] {tuple(b.shape)}: {flips} sign mismatches, rel L2 {err:.1e}, "
+                              f"min |cpu| {float(b.abs()[b != 0].min()):.1e}")
+            worst = sorted(((float((res['hip'][1][n] - g).norm() / g.norm().clamp_min(1e-30)), n)
+                            for n, g in res["cpu"][1].items() if float(g.norm()) > 0), reverse=True)
+            print("    worst gradients:", [(n, f"{e:.1e}") for e, n in worst[:6] if e < 0.5])
+
+
+if __name__ == "__main__":
+    main()
