@@ -5,15 +5,17 @@ the network being optimised across ranks inside ``loss.backward()``; BatchNorm s
 per-rank (no sync_batchnorm); rank 0's buffers are what a checkpoint / evaluation sees.
 
 MI355X-first shape of the same exchange:
-  * each network's gradients live in ONE flat fp32 buffer (``p.grad`` are views into it), so the
-    exchange is a single all-reduce per step (D: 11 MB, G: 51 MB for the 64-feature nets) -- large
-    messages are what the point-to-point xGMI links want, and there is no per-bucket launch cost;
-  * the all-reduce is issued asynchronously right after backward and is only waited for when the
-    network is next USED (a forward-pre hook on the module): the discriminator's exchange + optimizer
-    step therefore overlap the generator forward that opens the next training_step, which does not
-    read the discriminator;
-  * the optimizer step itself is deferred to that same point, so the result is bit-identical to the
-    "all-reduce, then step" order of DDP.
+  * each network's gradients live in ONE flat fp32 buffer (``p.grad`` are views into it), laid out in the order
+    backward produces them (last layer first) and cut into a few large contiguous buckets (<= 3 for the DCGAN
+    generator: 10.5 / 33.5 / 6.5 MB) -- large messages are what the point-to-point xGMI links want;
+  * a bucket's all-reduce is issued from the autograd thread the moment its last gradient has been accumulated
+    (post-accumulate-grad hooks), so it runs on RCCL's stream underneath the rest of that network's backward: for
+    the generator only the last bucket (block1, 6.5 MB) is still in flight when backward ends;
+  * nothing waits for the exchange until the network is next USED (a forward-pre hook on the module): the
+    discriminator's exchange + optimizer step therefore also overlap the generator forward that opens the next
+    training_step, which does not read the discriminator;
+  * the optimizer step itself is deferred to that same point and takes the 1/world factor as an argument, so the
+    result is bit-identical to the "all-reduce(mean), then step" order of DDP.
 
 Works on any torch.distributed backend ("nccl" = RCCL on ROCm; "gloo" in the CPU tests).
 """
@@ -22,35 +24,50 @@ import os
 import torch
 import torch.distributed as dist
 
+BUCKET_BYTES = int(os.environ.get("GZ_DDP_BUCKET_MB", "16")) << 20
+
 
 class _FlatGrads:
-    def __init__(self, params):
-        self.params = [p for p in params]
+    def __init__(self, params, bucket_bytes=BUCKET_BYTES):
+        self.params = [p for p in params][::-1]        # backward order: the last layer's gradient lands first
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(n, device=ref.device, dtype=ref.dtype)
+        self.offsets = []
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.offsets.append(off)
             off += p.numel()
+        # contiguous buckets: close one when the next parameter would push it over the cap
+        self.buckets = []            # [start, end, first param index, last param index + 1]
+        start = first = 0
+        for i, p in enumerate(self.params):
+            end = self.offsets[i] + p.numel()
+            nxt = self.params[i + 1].numel() if i + 1 < len(self.params) else 0
+            if i + 1 == len(self.params) or (end - start + nxt) * 4 > bucket_bytes:
+                self.buckets.append((start, end, first, i + 1))
+                start, first = end, i + 1
+        self.bucket_of = {}
+        for b, (_, _, lo, hi) in enumerate(self.buckets):
+            for i in range(lo, hi):
+                self.bucket_of[id(self.params[i])] = b
 
     def rebind(self):
         """Re-attach the views if something replaced / dropped ``p.grad``."""
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             view = self.flat[off:off + p.numel()].view_as(p)
             if p.grad is None:
                 p.grad = view
             elif p.grad.data_ptr() != view.data_ptr():
                 view.copy_(p.grad)
                 p.grad = view
-            off += p.numel()
 
 
 class GradSync:
     """Plugs into harness.Trainer: ``before_step``, ``after_backward``, ``flush``."""
 
-    def __init__(self, module, process_group=None, overlap=True):
+    def __init__(self, module, process_group=None, overlap=True, bucket_bytes=BUCKET_BYTES):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -58,27 +75,70 @@ class GradSync:
         # test hook: issue the collective even on a single rank (exercises the RCCL call path)
         self.always_reduce = bool(os.environ.get("GZ_DDP_ALWAYS_REDUCE")) and dist.is_initialized()
         self.nets = [module.discriminator, module.generator]     # optimizer_idx order
-        self.flats = [_FlatGrads(list(n.parameters())) for n in self.nets]
-        self.pending = [None, None]   # (work, optimizer)
+        self.flats = [_FlatGrads(list(n.parameters()), bucket_bytes) for n in self.nets]
+        self.pending = [None, None]   # (works, optimizer)
+        self.active = None            # network whose backward is running
+        self.remaining = [None, None]   # per bucket: gradients still to arrive in this backward
+        self.works = [[], []]
+        self.issued = [set(), set()]
+        self.stats = {"buckets_from_hooks": 0, "buckets_after_backward": 0}
         self.hooks = [n.register_forward_pre_hook(self._make_hook(i)) for i, n in enumerate(self.nets)]
+        for idx, fg in enumerate(self.flats):
+            for p in fg.params:
+                self.hooks.append(p.register_post_accumulate_grad_hook(self._make_grad_hook(idx)))
 
     def _make_hook(self, idx):
         def hook(_module, _inputs):
             self.finalize(idx)
         return hook
 
+    def _make_grad_hook(self, idx):
+        def hook(p):
+            if self.active != idx or not self.overlap:
+                return
+            b = self.flats[idx].bucket_of[id(p)]
+            self.remaining[idx][b] -= 1
+            if self.remaining[idx][b] == 0:
+                self._issue(idx, b)
+                self.stats["buckets_from_hooks"] += 1
+        return hook
+
+    def _reduces(self):
+        return self.world > 1 or self.always_reduce
+
+    def _issue(self, idx, b):
+        if b in self.issued[idx]:
+            return
+        self.issued[idx].add(b)
+        if not self._reduces():
+            return
+        fg = self.flats[idx]
+        start, end = fg.buckets[b][:2]
+        self.works[idx].append(dist.all_reduce(fg.flat[start:end], op=dist.ReduceOp.SUM, group=self.group,
+                                               async_op=True))
+
     def before_step(self, optimizer_idx):
         if getattr(self.module, "mutates_discriminator_before_forward", False):
             self.finalize(0)     # WGAN clamps D's weights at the top of training_step
-        self.flats[optimizer_idx].rebind()
+        self.finalize(optimizer_idx)     # a pending step of the SAME network must land before its next backward
+        fg = self.flats[optimizer_idx]
+        fg.rebind()
+        self.active = optimizer_idx
+        self.remaining[optimizer_idx] = [sum(1 for i in range(lo, hi) if fg.params[i].requires_grad)
+                                         for (_, _, lo, hi) in fg.buckets]
+        self.works[optimizer_idx] = []
+        self.issued[optimizer_idx] = set()
 
     def after_backward(self, optimizer_idx, optimizer):
         fg = self.flats[optimizer_idx]
         fg.rebind()
-        work = None
-        if self.world > 1 or self.always_reduce:
-            work = dist.all_reduce(fg.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.pending[optimizer_idx] = (work, optimizer)
+        self.active = None
+        for b in range(len(fg.buckets)):       # whatever the hooks did not cover (unused parameters, overlap off)
+            if b not in self.issued[optimizer_idx]:
+                self._issue(optimizer_idx, b)
+                self.stats["buckets_after_backward"] += 1
+        self.pending[optimizer_idx] = (self.works[optimizer_idx], optimizer)
+        self.works[optimizer_idx] = []
         if not self.overlap:
             self.finalize(optimizer_idx)
 
@@ -87,11 +147,12 @@ class GradSync:
         if item is None:
             return
         self.pending[idx] = None
-        work, optimizer = item
+        works, optimizer = item
         fg = self.flats[idx]
         scale = 1.0
-        if work is not None:
+        for work in works:
             work.wait()
+        if works:
             scale = 1.0 / self.world
         if scale != 1.0 and getattr(optimizer, "accepts_grad_scale", False):
             optimizer.step(grad_scale=scale)      # the fused optimizers fold the 1/world into their single pass
@@ -107,8 +168,8 @@ class GradSync:
 
     @torch.no_grad()
     def sync_buffers(self, src=0):
-        """Broadcast rank ``src``'s norm buffers (what DDP's broadcast_buffers leaves on every rank);
-        call before evaluation or checkpointing."""
+        """Broadcast rank ``src``'s norm buffers (what DDP's broadcast_buffers leaves on every rank).  A collective:
+        EVERY rank must call it (before evaluation or checkpointing)."""
         if self.world <= 1:
             return
         for net in self.nets:

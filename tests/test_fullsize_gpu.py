@@ -1,0 +1,145 @@
+"""Parity at BASELINE.json's full sizes (features 64; bs 512 for dc_gan, bs 64 / in_planes 64 for hologan): the
+cases the fixture tests are too small to reach -- train-mode BatchNorm statistics over 524,288 elements per
+channel, a whole bs=512 discriminator step against the CPU oracle, the HoloGAN nets at the benchmarked shape."""
+import numpy as np
+import pytest
+import torch
+
+import scenario
+from lightning_gan_zoo_amd.config import locate, make_cfg
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("shape,act", [((512, 128, 32, 32), "relu"), ((512, 64, 32, 32), "lrelu")])
+def test_train_mode_batchnorm_at_bs512(shape, act):
+    """G.block4 / D.block1-sized BatchNorm(train) + activation, forward, backward and the running buffers against
+    float64 on the CPU (statistics over N*H*W = 524,288 values per channel)."""
+    from lightning_gan_zoo_amd import functional as F
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(shape, generator=g) * 1.7 + torch.linspace(-2, 2, C).view(1, C, 1, 1)
+    go = torch.randn(shape, generator=g)
+    gamma = 1 + 0.1 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    rm0, rv0 = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    # float64 reference
+    bn = torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma), bn.bias.copy_(beta), bn.running_mean.copy_(rm0), bn.running_var.copy_(rv0)
+    xr = x.double().requires_grad_()
+    pre = bn(xr)
+    ref = torch.relu(pre) if act == "relu" else torch.nn.functional.leaky_relu(pre, 0.2)
+    ref.backward(go.double())
+    xd = x.cuda().requires_grad_()
+    gd, bd = gamma.cuda().requires_grad_(), beta.cuda().requires_grad_()
+    rm, rv, nbt = rm0.cuda(), rv0.cuda(), torch.zeros((), dtype=torch.int64, device="cuda")
+    out = F.batch_norm_act(xd, gd, bd, rm, rv, nbt, True, 0.1, 1e-5, F.ACT_RELU if act == "relu" else F.ACT_LRELU, 0.2)
+    out.backward(go.cuda())
+    errs = {"out": _rel(out, ref), "dx": _rel(xd.grad, xr.grad), "dgamma": _rel(gd.grad, bn.weight.grad),
+            "dbeta": _rel(bd.grad, bn.bias.grad), "running_mean": _rel(rm, bn.running_mean),
+            "running_var": _rel(rv, bn.running_var)}
+    print(shape, act, {k: f"{v:.1e}" for k, v in errs.items()})
+    assert max(errs.values()) < TOL, errs
+    assert int(nbt) == int(bn.num_batches_tracked) == 1
+
+
+def test_dcgan_bs512_discriminator_step_matches_cpu_oracle():
+    """BASELINE config 2 (dc_gan, features 64, bs 512), optimizer_idx 0 with BatchNorm in TRAIN mode in both networks:
+    loss, D(real) / D(fake) logits via the loss, every discriminator gradient and every BatchNorm buffer of both
+    networks against the CPU oracle on the same inputs (stable-mask scenario: LeakyReLU masks off the threshold, so
+    the plain 1e-3 applies)."""
+    from helpers import FixedNoise, synthetic_noise, synthetic_real
+    bs = 512
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    res = {}
+    for name, root, dev in (("hip", None, "cuda"), ("cpu", "oracle.reference_cpu", "cpu")):
+        cfg = make_cfg("dc_gan", **({"module_root": root} if root else {}), batch_size=bs)
+        torch.manual_seed(42)
+        step = locate(cfg.model.lm["_target_"])(cfg, None)
+        scenario._prepare(step, True)
+        step.to(dev)
+        scenario._toggle(step, 0)
+        step.noise_distn = FixedNoise(synthetic_noise(bs, 100, 4242))
+        real = (synthetic_real(bs, seed=4243).abs() * 0.9 + 0.1).to(dev)
+        loss = step.training_step((real, torch.zeros(bs, dtype=torch.int64, device=dev)), 0, 0)
+        loss.backward()
+        res[name] = (float(loss.detach()),
+                     {n: p.grad.detach().double().cpu() for n, p in step.discriminator.named_parameters()},
+                     {k: b.detach().double().cpu() for net in ("generator", "discriminator")
+                      for k, b in getattr(step, net).named_buffers(prefix=net)})
+    (lh, gh, bh), (lc, gc, bc) = res["hip"], res["cpu"]
+    assert abs(lh - lc) <= TOL * max(1.0, abs(lc)), (lh, lc)
+    worst = {}
+    for n, ref in gc.items():
+        worst["grad " + n] = float((gh[n] - ref).norm() / ref.norm())
+    for n, ref in bc.items():
+        if ref.dtype == torch.float64 and "num_batches" not in n:
+            worst["buffer " + n] = float((bh[n] - ref).abs().max() / ref.abs().max())
+        else:
+            assert torch.equal(bh[n], ref), n          # num_batches_tracked: D saw two batches, G one
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    print("dc_gan bs512 D step vs CPU oracle:", [(k, f"{v:.1e}") for k, v in top])
+    assert top[0][1] <= TOL, top
+
+
+def test_hologan_bs64_batch_consistency():
+    """The benchmarked HoloGAN shape (in_planes 64, z 128, bs 64).  Neither network shares a statistic across samples
+    (AdaIN and InstanceNorm are per sample), so one bs=64 pass -- large tiles, split-K weight gradients -- must equal
+    eight bs=8 passes: images, logits, latent predictions, input gradients and summed parameter gradients.  The bs=8
+    pieces are pinned to the CPU oracle by test_hologan_step_gradients_with_pinned_masks."""
+    from helpers import fill_closed_form
+    cfg = make_cfg("hologan", batch_size=64, features=64, noise_dim=128)
+    torch.manual_seed(42)
+    step = locate(cfg.model.lm["_target_"])(cfg, None)
+    scenario._prepare(step, True)          # masks off the threshold wherever they can be
+    step.to("cuda")
+    step.eval()                            # spectral norm: no power iteration between the passes (same sigma)
+    G, D = step.generator, step.discriminator
+    g = torch.Generator().manual_seed(77)
+    z = (torch.rand(64, 128, generator=g) * 2 - 1).cuda()
+    w = torch.randn(64, generator=g).cuda()
+    scenario.seed_views(step, 9)
+    view = G.sample_view(64)
+
+    up = torch.randn(64, 3, 64, 64, generator=g).cuda()     # a fixed upstream gradient on the image
+    with torch.no_grad():
+        fake64 = G(z, view)
+
+    def run(idx):
+        # generator: forward + backward from a fixed image gradient (its own masks are off the threshold); the
+        # discriminator sees identical images in both tilings, so only ITS masks can differ between them
+        step.zero_grad(set_to_none=True)
+        fake = G(z[idx], view[idx])
+        (fake * up[idx]).sum().backward()
+        x = fake64[idx].clone().requires_grad_()
+        logit, zp = D(x)
+        ((logit.reshape(-1) * w[idx]).sum() + (zp * zp).sum()).backward()
+        grads = {"G." + n: p.grad.detach().clone() for n, p in G.named_parameters()}
+        grads.update({"D." + n: p.grad.detach().clone() for n, p in D.named_parameters() if p.grad is not None})
+        grads["D.input"] = x.grad.detach().clone()
+        return fake.detach(), logit.detach().reshape(-1), zp.detach(), grads
+
+    full = run(slice(0, 64))
+    parts = [run(slice(i, i + 8)) for i in range(0, 64, 8)]
+    worst = {}
+    for k, name in enumerate(("images", "logits", "z prediction")):
+        a, b = full[k], torch.cat([p[k] for p in parts])
+        worst[name] = float((a - b).abs().max() / b.abs().max())
+    for n, gf in full[3].items():
+        gs = torch.cat([p[3][n] for p in parts]) if n == "D.input" else sum(p[3][n] for p in parts)
+        if n.endswith(("convTranspose.bias", "conv2d.bias")) and ".block" in "." + n:
+            continue                        # exact gradient 0 (constant in front of AdaIN / InstanceNorm)
+        worst["grad " + n] = float((gf - gs).norm() / gs.norm().clamp_min(1e-30))
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    print("hologan bs64 vs 8 x bs8:", [(k, f"{v:.1e}") for k, v in top])
+    # LeakyReLU entries behind InstanceNorm2d(affine=False) within rounding of zero can land on either side in the
+    # two tilings (tests/mask_pinning.py): 2.5e-3 = one such entry in a discriminator layer
+    assert max(v for k, v in worst.items() if k.startswith("grad D.")) <= 2.5e-3, top
+    assert max(v for k, v in worst.items() if not k.startswith("grad D.")) <= TOL, top
