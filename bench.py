@@ -9,19 +9,23 @@ optimizer.step with Lightning's per-batch optimizer alternation and toggle).
 A "step" is one G+D pair: training_step(optimizer_idx=0)+backward+Adam on one batch of B reals,
 then training_step(optimizer_idx=1)+backward+Adam on another; images/sec
 counts both batches (2*B*N / t_pair).  Prints ONE JSON line on rank 0.
+
+``--gpus N`` with N > 1 and no torch.distributed environment: this process only spawns the N ranks
+(``python -m torch.distributed.run``, before anything here touches a GPU) and relays their line.
+The timed region is K pairs bracketed by barrier + synchronize, repeated ``--reps`` times (default 3);
+``ms_per_step`` / ``value`` are the MEDIAN repetition (max over ranks inside each).
 """
 import argparse
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 # algorithmic conv/GEMM FLOP per sample per optimizer cycle (BASELINE.md section 3 / SURVEY.md 8-d)
 FLOP_PER_SAMPLE_CYCLE = {
@@ -36,9 +40,57 @@ FLOP_PER_SAMPLE_CYCLE = {
 NATIVE_IMG_SIZE = {"gan_stability_r1": 128}
 DEFAULT_BATCH = {"dc_gan": 512, "wgan": 512, "wgan_gp": 256, "hologan": 64, "gan_stability_r1": 64}
 PEAK_FP32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
+TIMER_EVERY = 4     # per-launch HIP events on every 4th cycle of the timed region (they cost ~5 % when always on)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=3, help="repetitions of the K-step timed region; the median is reported")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="per-GPU batch (default: BASELINE configs: dc_gan 512, wgan_gp 256, hologan 64)")
+    ap.add_argument("--expt", default="dc_gan")
+    ap.add_argument("--img-size", type=int, default=None,
+                    help="default 64 (128 for gan_stability_r1); 128 with --expt hologan is EXT-128, not parity-pinned")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bs128", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay each optimizer step from a captured HIP graph (single GPU)")
+    ap.add_argument("--force-grad-sync", action="store_true",
+                    help="use the data-parallel gradient path (flat buffers, deferred step) even on one rank")
+    args = ap.parse_args(argv)
+    if args.batch is None:
+        args.batch = DEFAULT_BATCH.get(args.expt, 128)
+    if args.img_size is None:
+        args.img_size = NATIVE_IMG_SIZE.get(args.expt, 64)
+    return args
+
+
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` outside a torch.distributed launch: start the N ranks as a child process group and
+    relay rank 0's JSON line.  Nothing in THIS process touches the GPU (no torch import even), so there is no
+    exec-after-HIP-init hazard and the children own the devices."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
+    if line is not None:
+        print(line, flush=True)
+    return r.returncode if line is not None or r.returncode else 1
 
 
 def build_trainer(expt, batch, device, world, force_sync=False, img_size=64, graph=False):
+    import torch
     from lightning_gan_zoo_amd.config import locate, make_cfg
     from lightning_gan_zoo_amd.ddp import GradSync
     from lightning_gan_zoo_amd.harness import GraphedTrainer, Trainer
@@ -52,15 +104,16 @@ def build_trainer(expt, batch, device, world, force_sync=False, img_size=64, gra
 
 
 def synthetic_batch(batch, device, rank, img_size=64):
+    import torch
     g = torch.Generator().manual_seed(1234 + rank)
     real = (torch.rand(batch, 3, img_size, img_size, generator=g) * 2 - 1).to(device)
     return real, torch.zeros(batch, dtype=torch.int64, device=device)
 
 
-TIMER_EVERY = 4     # per-launch HIP events on every 4th cycle of the timed region (they cost ~5 % when always on)
-
-
-def timed_pairs(trainer, batch, steps, warmup, world, timer=None):
+def timed_pairs(trainer, batch, steps, warmup, world, timer=None, reps=1):
+    """-> (per-repetition seconds for ``steps`` cycles, max over ranks; per-rank seconds of the median repetition)."""
+    import torch
+    import torch.distributed as dist
     per_pair = len(trainer.order)         # batches per optimizer cycle (2 for dc_gan)
     if timer is not None:
         timer.enabled = False
@@ -74,22 +127,33 @@ def timed_pairs(trainer, batch, steps, warmup, world, timer=None):
     # generation: later collections only look at the step's own short-lived objects (< 1 ms).
     gc.collect()
     gc.freeze()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(steps * per_pair):
-        if timer is not None:
-            timer.enabled = (i // per_pair) % TIMER_EVERY == 0
-        trainer.step(batch)
-    trainer.finish()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt
+    times, per_rank = [], []
+    for rep in range(reps):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps * per_pair):
+            if timer is not None:
+                timer.enabled = rep == 0 and (i // per_pair) % TIMER_EVERY == 0
+            trainer.step(batch)
+        trainer.finish()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        mine = dt
+        if world > 1:
+            dist.barrier()
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            ranks = [float(x.item()) for x in allt]
+            dt = max(ranks)
+        else:
+            ranks = [mine]
+        times.append(dt)
+        per_rank.append(ranks)
+    med = sorted(range(reps), key=lambda r: times[r])[reps // 2]
+    return times, per_rank[med], times[med]
 
 
 def cpu_baseline(batch=128, budget_s=14.0):
@@ -97,6 +161,7 @@ def cpu_baseline(batch=128, budget_s=14.0):
     box's host cores: same pair, same counting convention.  A reported baseline, not the target.
     The thread count is the best of a short probe (all hardware threads is far from optimal for
     oneDNN on a two-socket host)."""
+    import torch
     from lightning_gan_zoo_amd.config import locate, make_cfg
     from oracle.reference_cpu import run_step
     try:
@@ -148,33 +213,39 @@ def load_traffic(label):
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=None,
-                    help="per-GPU batch (default: BASELINE configs: dc_gan 512, wgan_gp 256, hologan 64)")
-    ap.add_argument("--expt", default="dc_gan")
-    ap.add_argument("--img-size", type=int, default=None,
-                    help="default 64 (128 for gan_stability_r1); 128 with --expt hologan is EXT-128, not parity-pinned")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-bs128", action="store_true")
-    ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay each optimizer step from a captured HIP graph (single GPU; not for hologan)")
-    ap.add_argument("--force-grad-sync", action="store_true",
-                    help="use the data-parallel gradient path (flat buffers, deferred step) even on one rank")
-    args = ap.parse_args()
+def roofline_of(timer, ms_per_step, steps, flop_cycle):
+    """The igemm kernel with the largest total time in the sampled cycles, plus the whole step."""
+    agg = timer.summary()
+    if not agg:
+        return None
+    sampled_cycles = (steps + TIMER_EVERY - 1) // TIMER_EVERY      # cycles 0, 4, 8, ... of the first repetition
+    total_ms = sum(v[1] for v in agg.values())
+    label, (n, ms, fl) = max(agg.items(), key=lambda kv: kv[1][1])
+    achieved = fl / (ms * 1e-3) / 1e12
+    return {
+        "bound": "mfma", "kernel": label, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+        "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+        "traffic": load_traffic(label),
+        "launches": n, "avg_launch_ms": round(ms / n, 4),
+        "sampled_cycles": sampled_cycles,
+        "share_of_step": round(ms / (ms_per_step * sampled_cycles), 3),
+        "all_igemm": {k: {"launches": v[0], "ms": round(v[1], 2),
+                          "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in sorted(agg.items())},
+        "igemm_share_of_step": round(total_ms / (ms_per_step * sampled_cycles), 3),
+        "whole_step": None if flop_cycle != flop_cycle else {
+            "flop_per_step": flop_cycle,
+            "achieved": round(flop_cycle / (ms_per_step * 1e-3) / 1e12, 2),
+            "frac": round(flop_cycle / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
+    }
+
+
+def run_rank(args):
+    import torch
+    import torch.distributed as dist
     # stdout carries exactly one line, the JSON result: library chatter written to file descriptor 1 (RCCL prints its
     # version banner there when the process group is torn down) is sent to stderr instead
     result_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
-    if args.batch is None:
-        args.batch = DEFAULT_BATCH.get(args.expt, 128)
-    if args.img_size is None:
-        args.img_size = NATIVE_IMG_SIZE.get(args.expt, 64)
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -184,30 +255,29 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        dist.init_process_group("nccl", device_id=device)
 
     from lightning_gan_zoo_amd import functional as F
 
     # the host side of the step is launch-only; a big OpenMP team only burns the container's CPU quota
     torch.set_num_threads(min(8, torch.get_num_threads()))
     if args.force_grad_sync and world == 1 and not dist.is_initialized() and "RANK" in os.environ:
-        dist.init_process_group("nccl")
+        dist.init_process_group("nccl", device_id=device)
     module, trainer = build_trainer(args.expt, args.batch, device, world, args.force_grad_sync, args.img_size,
                                     args.graph)
     if args.graph:
         args.no_kernel_timer = True        # per-launch events cannot be recorded inside a replayed graph
     batch = synthetic_batch(args.batch, device, rank, args.img_size)
     timer = F.KernelTimer()
-    # warm-up happens inside timed_pairs; the per-launch HIP events are recorded during the timed region
+    # warm-up happens inside timed_pairs; the per-launch HIP events are recorded during the first timed repetition
     for _ in range(8 if args.graph else 2):     # graph mode: eager warm-up + capture of both optimizer steps
         trainer.step(batch)
     trainer.finish()
     if not args.no_kernel_timer:
         F.set_kernel_timer(timer)
-    dt = timed_pairs(trainer, batch, args.steps, args.warmup, world, timer)
+    times, per_rank, dt = timed_pairs(trainer, batch, args.steps, args.warmup, world, timer, args.reps)
     F.set_kernel_timer(None)
     torch.cuda.synchronize()
-    sampled_cycles = (args.steps + TIMER_EVERY - 1) // TIMER_EVERY      # cycles 0, 4, 8, ... of the timed region
     ms_per_step = dt / args.steps * 1e3
     per_cycle = len(trainer.order)            # batches per optimizer cycle: 2 (dc_gan, wgan_gp), 6 (wgan), 3 (hologan)
     value = per_cycle * args.batch * world * args.steps / dt
@@ -233,45 +303,64 @@ def main():
                                % (args.expt, args.img_size, args.img_size, args.batch, per_cycle),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                    "images_counted": "%d*bs*n_gpus per step (every batch of the cycle)" % per_cycle},
+        "repetitions": {"count": args.reps, "ms_per_step_each": [round(t / args.steps * 1e3, 3) for t in times],
+                        "reported": "median"},
+        "per_rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],
     }
+    if world > 1:
+        out["rccl_ranks"] = dist.get_world_size()
+        sync = trainer.grad_sync
+        out["grad_exchange"] = {"buckets": [[(e - s) * 4 for s, e, _, _ in fg.buckets] for fg in sync.flats],
+                                **sync.stats}
 
     if rank == 0:
-        agg = timer.summary()
-        total_ms = sum(v[1] for v in agg.values())
-        if agg:
-            label, (n, ms, fl) = max(agg.items(), key=lambda kv: kv[1][1])
-            achieved = fl / (ms * 1e-3) / 1e12
-            out["roofline"] = {
-                "bound": "mfma", "kernel": label, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": load_traffic(label),
-                "launches": n, "avg_launch_ms": round(ms / n, 4),
-                "sampled_cycles": sampled_cycles,
-                "share_of_step": round(ms / (ms_per_step * sampled_cycles), 3),
-                "all_igemm": {k: {"launches": v[0], "ms": round(v[1], 2),
-                                  "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in sorted(agg.items())},
-                "igemm_share_of_step": round(total_ms / (ms_per_step * sampled_cycles), 3),
-                "whole_step": None if flop_cycle != flop_cycle else {
-                    "flop_per_step": flop_cycle,
-                    "achieved": round(flop_cycle / (ms_per_step * 1e-3) / 1e12, 2),
-                    "frac": round(flop_cycle / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
-            }
+        roof = roofline_of(timer, times[0] / args.steps * 1e3, args.steps, flop_cycle)
+        if roof is not None:
+            if roof["whole_step"] is not None:     # the whole step is priced on the reported (median) time
+                a = flop_cycle / (ms_per_step * 1e-3) / 1e12
+                roof["whole_step"].update(achieved=round(a, 2), frac=round(a / PEAK_FP32_MFMA_TFLOPS, 4))
+            out["roofline"] = roof
         if world == 1 and not args.no_bs128 and args.batch != 128 and args.expt == "dc_gan":
-            # BASELINE.json's metric string quotes bs=128/GPU: report it beside the bs=512 headline
+            # BASELINE.json's metric string quotes bs=128/GPU: the same measurement at that batch, with its own
+            # per-kernel roofline
             del trainer, module
             torch.cuda.empty_cache()
             m2, t2 = build_trainer(args.expt, 128, device, 1)
             b2 = synthetic_batch(128, device, 0)
-            dt2 = timed_pairs(t2, b2, args.steps, args.warmup, 1)
+            timer2 = F.KernelTimer()
+            if not args.no_kernel_timer:
+                F.set_kernel_timer(timer2)
+            times2, _, dt2 = timed_pairs(t2, b2, args.steps, args.warmup, 1, timer2, args.reps)
+            F.set_kernel_timer(None)
+            ms2 = dt2 / args.steps * 1e3
             out["bs128"] = {"value": round(per_cycle * 128 * args.steps / dt2, 1), "unit": "images/s",
-                            "ms_per_step": round(dt2 / args.steps * 1e3, 3)}
+                            "ms_per_step": round(ms2, 3),
+                            "ms_per_step_each": [round(t / args.steps * 1e3, 3) for t in times2]}
+            roof2 = roofline_of(timer2, times2[0] / args.steps * 1e3, args.steps, FLOP_PER_SAMPLE_CYCLE[args.expt] * 128)
+            if roof2 is not None:
+                a = FLOP_PER_SAMPLE_CYCLE[args.expt] * 128 / (ms2 * 1e-3) / 1e12
+                roof2["whole_step"].update(achieved=round(a, 2), frac=round(a / PEAK_FP32_MFMA_TFLOPS, 4))
+                roof2["traffic"] = None
+                out["bs128"]["roofline"] = roof2
         if world == 1 and not args.no_cpu_baseline and args.expt == "dc_gan":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), file=result_out, flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launcher started %d rank(s); reporting what actually runs (n_gpus=%d)"
+              % (args.gpus, world, world), file=sys.stderr)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

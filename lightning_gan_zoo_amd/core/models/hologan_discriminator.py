@@ -41,10 +41,15 @@ class BasicBlock(nn.Module):
 
 
 class Discriminator(nn.Module):
-    def __init__(self, in_planes, out_planes, z_planes, img_size=64):
+    def __init__(self, in_planes, out_planes, z_planes, img_size=64, final_sigmoid=False):
         """``img_size`` other than 64 is the EXT-128 extension (heads sized for the 8x8 final map); the
-        reference hard-wires 4x4 (hologan_discriminator.py:41,45)."""
+        reference hard-wires 4x4 (hologan_discriminator.py:41,45).  ``img_size`` / ``final_sigmoid`` are what the
+        reference's ROOT config injects into every ``discriminator`` node (conf/config.yaml:35-37); the reference's
+        own class (:28) rejects them, i.e. ``+expt=hologan`` does not construct there as shipped -- accepted here so
+        that the shipped tree composes (the heads never apply a sigmoid: the criterion is BCE-with-logits)."""
         super().__init__()
+        if final_sigmoid:
+            raise ValueError("HoloGAN's discriminator returns logits (reference hologan_discriminator.py:64-70)")
         fmap = (img_size // 16) ** 2
         self.conv2d = nn.Conv2d(in_planes, out_planes, kernel_size=5, stride=2, padding=2)
         truncated_normal_initializer(self.conv2d.weight)

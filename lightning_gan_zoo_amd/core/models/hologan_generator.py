@@ -121,6 +121,7 @@ class Generator(nn.Module):
         nn.init.constant_(self.final_layer.bias, val=0.0)
         self.relu = nn.ReLU()
         self.tanh = nn.Tanh()
+        self.staged_minv = None     # harness.GraphedTrainer: the step's inverse view matrices, already on the device
 
     def sample_view(self, batch_size):
         """Transformation parameters from numpy's global generator, reference :80-114 (call order kept)."""
@@ -141,10 +142,13 @@ class Generator(nn.Module):
 
     def forward(self, z, view_in=None):
         n = z.shape[0]
-        if view_in is None:
-            view_in = self.sample_view(n)
         dev = self.x.device
-        minv = draw_on_host(lambda: view_inverse_matrices(view_in).reshape(n, 16).contiguous(), dev)
+        if view_in is None and self.staged_minv is not None and self.staged_minv.shape[0] == n:
+            minv = self.staged_minv          # drawn and inverted on the host by the trainer, in the reference's order
+        else:
+            if view_in is None:
+                view_in = self.sample_view(n)
+            minv = draw_on_host(lambda: view_inverse_matrices(view_in).reshape(n, 16).contiguous(), dev)
 
         s0, b0 = self.zMapping(z)
         h = F.adain_act(self.x.repeat(n, 1, 1, 1, 1), s0, b0, 1e-8, F.ACT_RELU)

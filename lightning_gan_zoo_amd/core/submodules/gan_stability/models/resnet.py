@@ -107,7 +107,10 @@ class Generator(nn.Module):
 class Discriminator(nn.Module):
     """resnet.py:54-93"""
 
-    def __init__(self, z_dim, nlabels, size, embed_size=256, nfilter=64, nfilter_max=1024):
+    def __init__(self, z_dim, nlabels, size, embed_size=256, nfilter=64, nfilter_max=1024, **root_config_keys):
+        # ``img_size`` / ``final_sigmoid`` arrive from the reference's root config (conf/config.yaml:35-37); its own class
+        # (resnet.py:55) takes no **kwargs and cannot be constructed from the shipped tree -- ignored here, as the
+        # reference's Generator (:10) already does
         super().__init__()
         self.embed_size = embed_size
         s0 = self.s0 = 4

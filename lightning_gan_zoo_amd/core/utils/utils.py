@@ -41,7 +41,11 @@ def gradient_penalty(critic, real, fake, device="cpu", alpha=None):
         create_graph=True,
         retain_graph=True,
     )[0]
-    gradient_norm = F.row_sumsq(gradient.reshape(bs, -1)).sqrt()
+    sumsq = F.row_sumsq(gradient.reshape(bs, -1))
+    # torch.norm's subgradient at an exactly-zero gradient is 0 (reference :55); a bare sqrt would give 0.5 / 0 = inf
+    # there and NaN after the chain rule
+    nonzero = sumsq > 0
+    gradient_norm = torch.where(nonzero, sumsq, torch.ones_like(sumsq)).sqrt() * nonzero
     return torch.mean((gradient_norm - 1) ** 2)
 
 

@@ -181,17 +181,24 @@ class GraphedTrainer(Trainer):
     What stays outside the graph, in the reference's order, is exactly the host-side work: the latent noise (and
     WGAN-GP's alpha) is still drawn from the HOST generator each step and copied into static device buffers the
     captured step reads; the batch is copied into a static buffer unless it already is that buffer.
-    Restrictions: single process (no GradSync), fused optimizers (Adam with a device-side step counter, RMSprop),
-    step classes whose training_step does no host synchronisation (DCGAN, WGAN, WGANGP, GANStabilityR1 -- HOLOGAN
-    builds its view matrices with numpy on the host)."""
+    HOLOGAN's per-step view matrices are host work too (numpy generator + 4x4 inverses): they are drawn in the
+    reference's order and staged into a static buffer the captured generator reads (``Generator.staged_minv``).
+    The learning rate is a by-value kernel argument of the captured optimizer launch, so a graph is keyed by the
+    learning rates (and the batch shape) it was captured with: after ``end_epoch()`` has moved a scheduler, or when
+    the data set's last batch is smaller, the step is captured again instead of replaying stale arguments.
+    Restrictions (enforced): single process (no GradSync), fused optimizers (Adam with a device-side step counter,
+    RMSprop)."""
 
-    def __init__(self, module, warmup=2):
+    def __init__(self, module, warmup=2, grad_sync=None):
+        if grad_sync is not None:
+            raise RuntimeError("GraphedTrainer is single-process: the data-parallel gradient exchange is not captured")
         super().__init__(module)
         from . import functional as F
         self._F = F
         self.warmup = warmup
-        self.graphs = {}        # optimizer_idx -> (graph, loss)
+        self.graphs = {}        # (optimizer_idx, batch shape, learning rates) -> (graph, loss)
         self.seen = {}
+        self.static_minv = None
         self.static_batch = None
         self.static_noise = None
         self.static_alpha = None
@@ -202,8 +209,9 @@ class GraphedTrainer(Trainer):
     def _stage(self, batch):
         m = self.module
         real, labels = batch
-        if self.static_batch is None:
+        if self.static_batch is None or self.static_batch[0].shape != real.shape:
             self.static_batch = (real.clone(), labels.clone() if torch.is_tensor(labels) else labels)
+            self.static_noise = self.static_alpha = self.static_minv = None
         elif real.data_ptr() != self.static_batch[0].data_ptr():
             with torch.no_grad():         # R1 turns the batch into a leaf that requires grad
                 self.static_batch[0].copy_(real, non_blocking=True)
@@ -213,6 +221,16 @@ class GraphedTrainer(Trainer):
             self.static_noise = z.clone()
         else:
             self.static_noise.copy_(z, non_blocking=True)
+        gen = getattr(m, "generator", None)
+        if hasattr(gen, "sample_view") and hasattr(gen, "staged_minv"):        # HoloGAN: numpy draw + host inverses
+            from .core.models.hologan_generator import view_inverse_matrices
+            minv = draw_on_host(lambda: view_inverse_matrices(gen.sample_view(len(real))).reshape(len(real), 16)
+                                .contiguous(), real.device)
+            if self.static_minv is None:
+                self.static_minv = minv.clone()
+            else:
+                self.static_minv.copy_(minv, non_blocking=True)
+            gen.staged_minv = self.static_minv
         if hasattr(m, "gp_alpha") and self.active_optimizer() == 0:
             a = draw_on_host(lambda: torch.rand((len(real), 1, 1, 1)), real.device)
             if self.static_alpha is None:
@@ -238,10 +256,11 @@ class GraphedTrainer(Trainer):
         opt = self.optim[idx]["optimizer"]
         n = self.seen.get(idx, 0)
         self.seen[idx] = n + 1
+        key = (idx, tuple(self.static_batch[0].shape), tuple(float(g["lr"]) for g in opt.param_groups))
         if n < self.warmup:                                    # eager warm-up steps (allocator, lazy state)
             loss = self._body(idx)
             opt.zero_grad(set_to_none=True)
-        elif idx not in self.graphs:
+        elif key not in self.graphs:
             opt.make_capturable()
             self._F.set_pack_cache(False)
             opt.zero_grad(set_to_none=True)
@@ -251,11 +270,11 @@ class GraphedTrainer(Trainer):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 loss = self._body(idx)
-            self.graphs[idx] = (g, loss)
+            self.graphs[key] = (g, loss)
             # the capture itself does not execute: run it once so that this step takes effect
             g.replay()
         else:
-            g, loss = self.graphs[idx]
+            g, loss = self.graphs[key]
             g.replay()
         self.batch_idx += 1
         return loss.detach(), idx

@@ -1,81 +1,160 @@
 """Thin runner with the reference's command-line grammar (run_network.py:25-75 + Hydra overrides):
 
-    python -m lightning_gan_zoo_amd.run_network +expt=dc_gan train.batch_size=64 max_steps=200 \\
-           dataset=synthetic save_ckpts=true train.ckpt_dir=output/ckpt
+    python -m lightning_gan_zoo_amd.run_network +expt=dc_gan train.batch_size=64 +max_steps=200 \\
+           dataset=synthetic train.ckpt_dir=output/ckpt
+    python -m lightning_gan_zoo_amd.run_network --config-dir /path/to/lightning_gan_zoo/conf \\
+           +expt=dc_gan dataset=celeb_a filepaths=local
 
-``+expt=<name>`` selects the experiment (dc_gan | wgan | wgan_gp | hologan); ``a.b.c=value`` overrides
-any config leaf (values parsed as YAML scalars); ``num_gpus`` > 1 expects a torch.distributed launch
-(one process per GPU).  What the reference delegates to pytorch_lightning is done by harness.Trainer:
-per-batch optimizer alternation, toggle, backward, step, per-epoch LR scheduler, checkpoint save /
-resume (``find_ckpt`` semantics: the single ``*.ckpt`` under ``train.ckpt_dir``).
+Without ``--config-dir`` the experiment is composed from the built-in restatement of the reference's tree
+(config.make_cfg); with it, from the user's own ``conf/``-shaped directory (config.compose_tree: defaults lists,
+``+expt=``, ``group=option``, ``${a.b}``), whose ``core.*`` ``_target_`` strings are served by this package
+(dropin.install).  ``num_gpus`` > 1 expects a torch.distributed launch (one process per GPU).
 
-Checkpoints are plain ``torch.save`` dicts with a Lightning-style ``state_dict`` whose keys are
-``generator.<...>`` / ``discriminator.<...>`` exactly as the reference's LightningModule would
-produce, so the weights interchange with the reference.
+What the reference delegates to pytorch_lightning is done by harness.Trainer: per-batch optimizer alternation, toggle,
+backward, step, per-epoch LR scheduler, ``max_epochs=cfg.train.num_epochs``, checkpoint save / resume
+(``find_ckpt``: the single ``*.ckpt`` under ``train.ckpt_dir``; ``ModelCheckpoint(monitor='fid',
+filename='model_best-{fid:.2f}')`` keeps the best-scoring file when the metric is available, else the latest), the
+DistributedSampler's per-rank sharding of the dataset.  Checkpoints are ``torch.save`` dicts in Lightning's envelope
+(``epoch, global_step, pytorch-lightning_version, state_dict, optimizer_states, lr_schedulers, callbacks``) whose
+``state_dict`` keys are ``generator.<...>`` / ``discriminator.<...>`` exactly as the reference's LightningModule
+produces them.
+
+The product runner only ever builds the HIP modules on a GPU; tests drive ``fit()`` with their own module / data.
 """
 import glob
+import math
 import os
+import random
 import sys
 import time
 
+import numpy as np
 import torch
-import yaml
 
-from .config import locate, make_cfg
+from .config import ConfigError, compose_tree, locate, make_cfg, parse_value
 
-RUNNER_KEYS = {"max_steps": 100, "log_every": 10, "dataset": "synthetic", "dataset_path": None, "seed": 42,
-               "device": "cuda", "module_root": None, "steps_per_epoch": 100}
+# keys of this runner, not of the reference's config (accepted with or without Hydra's "+")
+RUNNER_KEYS = {"max_steps": None, "log_every": 10, "dataset_path": None, "seed": 42, "steps_per_epoch": 100}
+BUILTIN_DATASETS = ("synthetic", "image_folder", "tensor_file", "celeb_a")
+LIGHTNING_VERSION_TAG = "1.2.0"       # envelope layout written below (Lightning 1.1 / 1.2 generation)
 
 
 def parse_overrides(argv):
-    expt, overrides, runner = None, {}, dict(RUNNER_KEYS)
-    for arg in argv:
-        if "=" not in arg:
+    """-> (conf_dir or None, expt, [override strings for the composer], runner keys)."""
+    argv = list(argv)
+    conf_dir, rest, runner = None, [], dict(RUNNER_KEYS)
+    i = 0
+    while i < len(argv):
+        arg = argv[i]
+        if arg in ("--config-dir", "-cd", "--config-path", "-cp"):
+            conf_dir = argv[i + 1]
+            i += 2
+            continue
+        if arg.startswith(("--config-dir=", "--config-path=")):
+            conf_dir = arg.split("=", 1)[1]
+            i += 1
+            continue
+        i += 1
+        if "=" not in arg and not arg.startswith("~"):
             raise SystemExit("cannot parse %r (expected key=value or +expt=name)" % arg)
-        key, val = arg.split("=", 1)
-        val = yaml.safe_load(val)
-        if key in ("+expt", "expt"):
-            expt = val
-        elif key in runner:
-            runner[key] = val
+        key = arg.split("=", 1)[0].lstrip("+")
+        if key in runner:
+            runner[key] = parse_value(arg.split("=", 1)[1])
         else:
-            overrides[key] = val
+            rest.append(arg)
+    expt = next((parse_value(a.split("=", 1)[1]) for a in rest if a.split("=", 1)[0] in ("+expt", "expt")), None)
     if expt is None:
-        raise SystemExit("missing +expt=<dc_gan|wgan|wgan_gp|hologan>")
-    return expt, overrides, runner
+        raise SystemExit("missing +expt=<dc_gan|wgan|wgan_gp|hologan|gan_stability_r1>")
+    return conf_dir, expt, rest, runner
 
 
-def compose(expt, overrides, module_root=None):
-    kw = {}
-    if module_root:
-        kw["module_root"] = module_root
-    cfg = make_cfg(expt, **kw)
-    derived = {"train.features_disc": ("discriminator", "features_d"), "train.features_gen": ("generator", "features_g"),
-               "train.img_size": None, "model.noise_dim": ("generator", "channels_noise")}
-    for dotted, v in overrides.items():
-        node = cfg
-        keys = dotted.split(".")
-        for k in keys[:-1]:
+def _builtin_dataset(name, run, filepaths):
+    if name == "synthetic":
+        return {"_target_": "lightning_gan_zoo_amd.run_network.SyntheticImages", "n_channels": 3}
+    if name == "tensor_file":
+        return {"_target_": "lightning_gan_zoo_amd.run_network.TensorFileImages", "n_channels": 3,
+                "root": run["dataset_path"], "train": {"root": run["dataset_path"]}}
+    if name == "image_folder":
+        root = run["dataset_path"]
+        return {"_target_": "torchvision.datasets.ImageFolder", "n_channels": 3, "root": root, "train": {"root": root}}
+    if name == "celeb_a":                 # conf/dataset/celeb_a.yaml:1-12
+        root = filepaths.get("celeb_a_root")
+        if not root:
+            raise SystemExit("dataset=celeb_a needs filepaths.celeb_a_root=<dir> (conf/filepaths/example.yaml)")
+        return {"_target_": "torchvision.datasets.ImageFolder", "n_channels": 3, "root": root,
+                "train": {"root": root + "/train"}, "val": {"root": root + "/train"}, "test": {"root": root + "/train"}}
+    raise SystemExit("unknown dataset %r (built in: %s)" % (name, ", ".join(BUILTIN_DATASETS)))
+
+
+def compose(conf_dir, expt, overrides, run=None):
+    """The experiment's config: from ``conf_dir`` when given, else from the built-in tree."""
+    run = run or dict(RUNNER_KEYS)
+    if conf_dir:
+        from . import dropin
+        dropin.install()
+        try:
+            return compose_tree(conf_dir, overrides)
+        except ConfigError as e:
+            raise SystemExit("config error: %s" % e) from e
+    dotted, dataset, filepaths = {}, "synthetic", {}
+    for arg in overrides:
+        key, text = arg.split("=", 1)
+        key = key.lstrip("+")
+        if key == "expt":
+            continue
+        if key == "dataset":
+            dataset = parse_value(text)
+        elif key.startswith("filepaths."):
+            filepaths[key.split(".", 1)[1]] = parse_value(text)
+        elif key == "filepaths":
+            continue                      # a group choice of the yaml tree; the built-in tree has no file to pick
+        else:
+            dotted[key] = parse_value(text)
+    probe = make_cfg(expt)
+    for key in dotted:                    # Hydra refuses to override a key that does not exist
+        node = probe
+        parts = key.split(".")
+        ok = True
+        for k in parts[:-1]:
+            if not isinstance(node, dict) or k not in node:
+                ok = False
+                break
             node = node[k]
-        if keys[-1] not in node and dotted not in ("train.weight_clip", "train.ckpt_dir"):
-            raise SystemExit("unknown config key %r" % dotted)
-        node[keys[-1]] = v
-        tgt = derived.get(dotted)
-        if tgt and tgt[1] in cfg[tgt[0]]:        # the ${...} interpolations of the reference's yaml
-            cfg[tgt[0]][tgt[1]] = v
-        if dotted == "train.img_size":
-            for net in ("discriminator", "generator"):
-                for key in ("img_size", "size"):       # `size: ${train.img_size}` in gan_stability_r1.yaml
-                    if key in cfg[net]:
-                        cfg[net][key] = v
-        if dotted == "model.noise_dim":
-            for net in ("discriminator", "generator"):
-                if "z_dim" in cfg[net]:                # `z_dim: ${model.noise_dim}`
-                    cfg[net]["z_dim"] = v
-        if dotted.startswith("optimisation.lr"):
-            for o in ("disc_optimiser", "gen_optimiser", "optimiser"):
-                cfg[o]["lr"] = v
+        if not ok or (parts[-1] not in node and key not in ("train.weight_clip", "train.ckpt_dir", "save_ckpts")
+                      and not key.startswith("loss_weight.")):
+            raise SystemExit("unknown config key %r" % key)
+    cfg = make_cfg(expt, dotted=dotted)
+    cfg["dataset"] = _to_cfg(_builtin_dataset(dataset, run, filepaths))
+    cfg.train["channels_img"] = cfg.dataset.get("n_channels", 3) if "train.channels_img" not in dotted else \
+        cfg.train["channels_img"]
     return cfg
+
+
+def _to_cfg(obj):
+    from .config import to_cfg
+    return to_cfg(obj)
+
+
+def seed_everything(seed):
+    """pytorch_lightning.seed_everything (reference run_network.py:27): python, numpy and torch generators -- the
+    SAME seed on every rank, as the reference does."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# data
+# ---------------------------------------------------------------------------------------------------------
+def shard_indices(n, rank, world):
+    """torch.utils.data.DistributedSampler(shuffle=False, drop_last=False): pad to a multiple of ``world`` by
+    wrapping around, then every ``world``-th index from ``rank`` (what Lightning's DDP inserts)."""
+    if world <= 1:
+        return list(range(n))
+    total = int(math.ceil(n / world)) * world
+    idx = list(range(n))
+    idx += idx[:total - n]
+    return idx[rank:total:world]
 
 
 class SyntheticImages:
@@ -86,6 +165,9 @@ class SyntheticImages:
         self.real = (torch.rand(batch, channels, size, size, generator=g) * 2 - 1).to(device)
         self.labels = torch.zeros(batch, dtype=torch.int64, device=device)
 
+    def __len__(self):
+        return 0          # no epoch structure of its own: the runner's steps_per_epoch applies
+
     def __iter__(self):
         while True:
             yield self.real, self.labels
@@ -94,17 +176,22 @@ class SyntheticImages:
 class TensorFileImages:
     """A ``.pt`` / ``.npy`` file holding [M, C, H, W] floats already normalised to [-1, 1]."""
 
-    def __init__(self, path, batch, device):
-        import numpy as np
+    def __init__(self, path, batch, device, rank=0, world=1):
         data = torch.load(path) if path.endswith(".pt") else torch.from_numpy(np.load(path))
         self.data, self.batch, self.device = data.float(), batch, device
+        self.order = shard_indices(len(self.data), rank, world)
+
+    def __len__(self):
+        return len(self.order)
 
     def __iter__(self):
-        n = len(self.data) // self.batch * self.batch
+        order = torch.tensor(self.order)
         while True:
-            for i in range(0, n, self.batch):        # no shuffling, as the reference's train_dataloader (:89-92)
-                real = self.data[i:i + self.batch].pin_memory().to(self.device, non_blocking=True)
-                yield real, torch.zeros(self.batch, dtype=torch.int64, device=self.device)
+            for i in range(0, len(order), self.batch):        # no shuffling, as the reference's train_dataloader (:89-92)
+                real = self.data[order[i:i + self.batch]]
+                if torch.device(self.device).type == "cuda":
+                    real = real.pin_memory().to(self.device, non_blocking=True)
+                yield real, torch.zeros(len(real), dtype=torch.int64, device=self.device)
 
 
 IMG_EXTENSIONS = (".jpg", ".jpeg", ".png", ".ppm", ".bmp", ".pgm", ".tif", ".tiff", ".webp")
@@ -127,19 +214,24 @@ def image_folder_samples(root):
 
 class ImageFolderImages:
     """The reference's real-data input step -- ImageFolder -> Resize((S, S)) -> ToTensor -> Normalize(mean, std),
-    DataLoader without shuffling, incomplete last batch kept (core/lightning_module.py:42-47,89-92) -- with the
-    decode + resize on a background host thread and ToTensor / Normalize / HWC->CHW on the device
-    (functional.normalize_u8_images): the host hands over 1 byte per element through a ring of pinned buffers."""
+    DataLoader without shuffling, incomplete last batch kept (core/lightning_module.py:42-47,89-92), sharded over the
+    data-parallel ranks like DistributedSampler(shuffle=False) -- with the decode + resize on a background host thread
+    and ToTensor / Normalize / HWC->CHW on the device (functional.normalize_u8_images): the host hands over 1 byte per
+    element through a ring of pinned buffers.  ``host_batches()`` is the host half (uint8, testable anywhere);
+    iterating the object is the device half and needs the GPU."""
 
-    def __init__(self, root, batch, img_size, channels, mean, std, device, prefetch=3):
+    def __init__(self, root, batch, img_size, channels, mean, std, device, prefetch=3, rank=0, world=1):
         self.samples, self.classes = image_folder_samples(root)
         if not self.samples:
             raise FileNotFoundError("no images under %r" % root)
+        self.order = shard_indices(len(self.samples), rank, world)
         self.batch, self.size, self.channels = batch, img_size, channels
         self.mean, self.std, self.device, self.prefetch = mean, std, torch.device(device), prefetch
 
+    def __len__(self):
+        return len(self.order)
+
     def decode(self, path):
-        import numpy as np
         from PIL import Image
         with open(path, "rb") as f:
             img = Image.open(f).convert("RGB" if self.channels == 3 else "L")    # ImageFolder's pil_loader gives RGB
@@ -148,17 +240,19 @@ class ImageFolderImages:
         return a if a.ndim == 3 else a[:, :, None]
 
     def host_batches(self):
-        """uint8 [b, S, S, C] arrays and int64 labels, epoch after epoch, in dataset order."""
-        import numpy as np
+        """uint8 [b, S, S, C] arrays and int64 labels, epoch after epoch, in (sharded) dataset order."""
         while True:
-            for i in range(0, len(self.samples), self.batch):
-                chunk = self.samples[i:i + self.batch]
+            for i in range(0, len(self.order), self.batch):
+                chunk = [self.samples[j] for j in self.order[i:i + self.batch]]
                 yield (np.stack([self.decode(p) for p, _ in chunk]), np.array([c for _, c in chunk], dtype=np.int64))
 
     def __iter__(self):
         import queue
         import threading
         from . import functional as F
+        if self.device.type != "cuda":
+            raise RuntimeError("lightning_gan_zoo_amd: the input step normalises on the GPU (no CPU fallback); "
+                               "host_batches() yields the decoded uint8 batches")
         q = queue.Queue(maxsize=self.prefetch)
 
         def producer():
@@ -169,10 +263,6 @@ class ImageFolderImages:
         ring, cursor = {}, 0
         while True:
             imgs, labels = q.get()
-            if self.device.type != "cuda":        # CPU oracle runs: same arithmetic with torch
-                x = torch.from_numpy(imgs).permute(0, 3, 1, 2).float().div(255).sub(self.mean).div(self.std)
-                yield x, torch.from_numpy(labels)
-                continue
             key = imgs.shape
             slots = ring.setdefault(key, [[torch.empty(key, dtype=torch.uint8).pin_memory(), None]
                                           for _ in range(self.prefetch + 1)])
@@ -189,24 +279,53 @@ class ImageFolderImages:
                    torch.from_numpy(labels).to(self.device, non_blocking=True))
 
 
+def build_data(cfg, run, device, rank=0, world=1):
+    """The training set of ``cfg.dataset`` (reference ``instantiate(cfg.dataset.train, transform=...)``, :89-92)."""
+    t = cfg.train
+    node = cfg.get("dataset") or {}
+    target = str(node.get("_target_", ""))
+    if run.get("synthetic") or target.endswith("SyntheticImages") or not target:
+        return SyntheticImages(t.batch_size, t.channels_img, t.img_size, device, 1234 + rank)
+    train = node.get("train", node)
+    if target.endswith("TensorFileImages"):
+        return TensorFileImages(train["root"], t.batch_size, device, rank, world)
+    if target.endswith("ImageFolder"):
+        return ImageFolderImages(train["root"], t.batch_size, t.img_size, t.channels_img, t.data_mean, t.data_std,
+                                 device, rank=rank, world=world)
+    raise SystemExit("dataset target %r is not supported by this runner (ImageFolder-shaped datasets, tensor files "
+                     "and synthetic batches are)" % target)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# checkpoints
+# ---------------------------------------------------------------------------------------------------------
 def find_ckpt(ckpt_dir):
-    """reference run_network.py:19-23: exactly one *.ckpt in the directory, else none."""
+    """reference run_network.py:19-23: every *.ckpt below the directory; more than one is an error."""
     if not ckpt_dir:
         return None
-    hits = glob.glob(os.path.join(ckpt_dir, "*.ckpt"))
-    return hits[0] if len(hits) == 1 else None
+    hits = [y for x in os.walk(ckpt_dir) for y in glob.glob(os.path.join(x[0], "*.ckpt"))]
+    assert len(hits) <= 1, "Multiple ckpts found!"
+    return hits[0] if hits else None
 
 
-def save_checkpoint(path, module, trainer, step, epoch):
-    state = {}
-    for prefix, net in (("discriminator.", module.discriminator), ("generator.", module.generator)):
-        for k, v in net.state_dict().items():
-            state[prefix + k] = v.detach().cpu()
-    blob = {"state_dict": state, "global_step": step, "epoch": epoch,
+def checkpoint_blob(module, trainer, step, epoch, keeper=None):
+    """Lightning's checkpoint envelope (``trainer.checkpoint_connector.dump_checkpoint`` of the 1.1 / 1.2 generation)."""
+    state = {k: v.detach().cpu() for k, v in module.state_dict().items()}       # generator.* / discriminator.*
+    blob = {"epoch": epoch, "global_step": step, "pytorch-lightning_version": LIGHTNING_VERSION_TAG,
+            "state_dict": state,
             "optimizer_states": [o["optimizer"].state_dict() for o in trainer.optim],
-            "lr_schedulers": [o["lr_scheduler"].state_dict() for o in trainer.optim]}
+            "lr_schedulers": [o["lr_scheduler"].state_dict() for o in trainer.optim],
+            "callbacks": {}}
+    if keeper is not None:
+        blob["callbacks"]["ModelCheckpoint"] = keeper.state()
+    return blob
+
+
+def save_checkpoint(path, module, trainer, step, epoch, keeper=None):
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-    torch.save(blob, path)
+    tmp = path + ".tmp"
+    torch.save(checkpoint_blob(module, trainer, step, epoch, keeper), tmp)
+    os.replace(tmp, path)
 
 
 def load_checkpoint(path, module, trainer):
@@ -218,68 +337,139 @@ def load_checkpoint(path, module, trainer):
         o["optimizer"].load_state_dict(s)
     for o, s in zip(trainer.optim, blob.get("lr_schedulers", [])):
         o["lr_scheduler"].load_state_dict(s)
-    return blob.get("global_step", 0), blob.get("epoch", 0)
+    return blob.get("global_step", 0), blob.get("epoch", 0), blob.get("callbacks", {}).get("ModelCheckpoint")
 
 
-def main(argv=None):
+class CheckpointKeeper:
+    """``ModelCheckpoint(monitor='fid', filename='model_best-{fid:.2f}')`` with Lightning's defaults (mode min,
+    save_top_k 1), reference run_network.py:48-50: a new file when the monitored metric improves, the previous best
+    removed AFTER the new one is on disk.  While the metric is not being produced (no InceptionV3 weights offline)
+    the latest state is kept instead, as ``step=<n>.ckpt`` -- either way the directory holds exactly one ``*.ckpt``,
+    which is what ``find_ckpt`` resumes from."""
+
+    def __init__(self, dirpath, monitor="fid", filename="model_best-{fid:.2f}"):
+        self.dirpath, self.monitor, self.filename = dirpath, monitor, filename
+        self.best_score, self.best_path = None, None
+
+    def state(self):
+        return {"monitor": self.monitor, "best_model_score": self.best_score, "best_model_path": self.best_path}
+
+    def load_state(self, st, current_path=None):
+        if st:
+            self.best_score, self.best_path = st.get("best_model_score"), st.get("best_model_path")
+        if current_path:
+            self.best_path = current_path
+
+    def update(self, metrics, step, save_fn):
+        """``save_fn(path)`` writes the checkpoint; returns the path written or None."""
+        score = metrics.get(self.monitor) if metrics else None
+        if score is not None:
+            score = float(score)
+            if self.best_score is not None and not score < self.best_score:
+                return None
+            name = self.filename.replace("{%s:.2f}" % self.monitor, "%s=%.2f" % (self.monitor, score)) + ".ckpt"
+            self.best_score = score
+        else:
+            name = "step=%d.ckpt" % step
+        path = os.path.join(self.dirpath, name)
+        old, self.best_path = self.best_path, path
+        save_fn(path)
+        for stale in glob.glob(os.path.join(self.dirpath, "*.ckpt")):
+            if os.path.abspath(stale) != os.path.abspath(path):
+                os.remove(stale)
+        del old
+        return path
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the loop
+# ---------------------------------------------------------------------------------------------------------
+def fit(module, cfg, data, run, sync=None, rank=0, world=1, evaluate=None):
+    """``pl.Trainer(max_epochs=cfg.train.num_epochs, resume_from_checkpoint=find_ckpt(...)).fit(model)`` for the
+    step classes of this package (reference run_network.py:61-72).  Returns (module, trainer, global_step)."""
     from .harness import Trainer
-    expt, overrides, run = parse_overrides(sys.argv[1:] if argv is None else argv)
-    cfg = compose(expt, overrides, run["module_root"])
-    torch.manual_seed(run["seed"])                  # seed_everything(42), reference :27
-    device = torch.device(run["device"])
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    sync = None
-    if world > 1:
-        import torch.distributed as dist
-        from .ddp import GradSync
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
-    module = locate(cfg.model.lm["_target_"])(cfg, logging_dir="output").to(device)
-    if world > 1:
-        sync = GradSync(module)
-    trainer = Trainer(module, grad_sync=sync)
     t = cfg.train
-    if run["dataset"] == "synthetic":
-        data = SyntheticImages(t.batch_size, t.channels_img, t.img_size, device, 1234 + int(os.environ.get("RANK", "0")))
-    elif run["dataset"] == "image_folder":          # the reference's ImageFolder(root=cfg.dataset.root) (:89-91)
-        data = ImageFolderImages(run["dataset_path"], t.batch_size, t.img_size, t.channels_img, t.data_mean, t.data_std,
-                                 device)
-    else:
-        data = TensorFileImages(run["dataset_path"], t.batch_size, device)
+    trainer = Trainer(module, grad_sync=sync)
+    n = len(data) if hasattr(data, "__len__") else 0
+    steps_per_epoch = int(math.ceil(n / t.batch_size)) if n else int(run["steps_per_epoch"])
     step = epoch = 0
-    ckpt = find_ckpt(t.get("ckpt_dir"))
+    ckpt_dir = t.get("ckpt_dir")
+    keeper = CheckpointKeeper(ckpt_dir) if (ckpt_dir and cfg.get("save_ckpts", True)) else None
+    ckpt = find_ckpt(ckpt_dir)
     if ckpt:
-        step, epoch = load_checkpoint(ckpt, module, trainer)
+        step, epoch, kst = load_checkpoint(ckpt, module, trainer)
         trainer.batch_idx = step
-        print("resumed from %s at step %d" % (ckpt, step))
+        if keeper is not None:
+            keeper.load_state(kst, ckpt)
+        if rank == 0:
+            print("resumed from %s at step %d (epoch %d)" % (ckpt, step, epoch))
     # a full Python garbage collection walks every object torch has created (~70 ms, several training steps):
     # park the set-up's survivors in the permanent generation so that later collections stay short
     import gc
     gc.collect()
     gc.freeze()
     t0 = time.time()
-    last = {}
+    last, first_step = {}, step
+    max_steps, max_epochs = run.get("max_steps"), int(t.get("num_epochs", 99999))
+
+    def checkpoint(metrics=None):
+        if keeper is None:
+            return
+        if sync is not None:
+            sync.flush()
+            sync.sync_buffers()           # a collective: every rank takes part, rank 0 writes
+        if rank == 0:
+            keeper.update(metrics, step, lambda path: save_checkpoint(path, module, trainer, step, epoch, keeper))
+        if world > 1:
+            torch.distributed.barrier()
+
     for batch in data:
-        if step >= run["max_steps"]:
+        if (max_steps is not None and step >= max_steps) or epoch >= max_epochs:
             break
         loss, idx = trainer.step(batch)
         last[("d_loss", "g_loss")[idx]] = loss
         step += 1
-        if step % run["steps_per_epoch"] == 0:
-            trainer.end_epoch()
-            epoch += 1
-        if step % run["log_every"] == 0 and int(os.environ.get("RANK", "0")) == 0:
+        if step % run["log_every"] == 0 and rank == 0:
             msg = " ".join("%s=%.4f" % (k, float(v)) for k, v in sorted(last.items()))
-            print("step %d epoch %d %s (%.1f img/s)" % (step, epoch, msg, step * t.batch_size * world / (time.time() - t0)))
+            rate = (step - first_step) * t.batch_size * world / (time.time() - t0)
+            print("step %d epoch %d %s (%.1f img/s)" % (step, epoch, msg, rate))
+        if step % steps_per_epoch == 0:
+            trainer.end_epoch()           # lr_scheduler.step(), current_epoch += 1
+            epoch += 1
+            metrics = evaluate(module, epoch) if evaluate is not None else None
+            checkpoint(metrics)
     trainer.finish()
-    if cfg.get("save_ckpts", True) and t.get("ckpt_dir") and int(os.environ.get("RANK", "0")) == 0:
-        if sync is not None:
-            sync.sync_buffers()
-        for old in glob.glob(os.path.join(t["ckpt_dir"], "*.ckpt")):
-            os.remove(old)
-        save_checkpoint(os.path.join(t["ckpt_dir"], "step=%d.ckpt" % step), module, trainer, step, epoch)
+    if step % steps_per_epoch:            # a run cut short by max_steps still leaves a resumable state
+        checkpoint(None)
     return module, trainer, step
+
+
+def main(argv=None):
+    conf_dir, expt, overrides, run = parse_overrides(sys.argv[1:] if argv is None else argv)
+    cfg = compose(conf_dir, expt, overrides, run)
+    seed_everything(run["seed"])                    # seed_everything(42), reference :27
+    if not torch.cuda.is_available():
+        raise SystemExit("lightning_gan_zoo_amd.run_network needs an MI355X: the step runs on the HIP kernels and has "
+                         "no CPU fallback")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    sync = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    module = locate(cfg.model.lm["_target_"])(cfg, logging_dir="output").to(device)
+    if world > 1:
+        from .ddp import GradSync
+        sync = GradSync(module)
+    data = build_data(cfg, run, device, rank, world)
+    out = fit(module, cfg, data, run, sync=sync, rank=rank, world=world)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

@@ -23,7 +23,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, overlap, ret):
+def _worker(rank, world, port, overlap, ret, bucket_bytes=16 << 20):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -47,11 +47,13 @@ def _worker(rank, world, port, overlap, ret):
 
         # A: the product harness with GradSync
         a = build()
-        tr = Trainer(a, grad_sync=GradSync(a, overlap=overlap))
+        sync = GradSync(a, overlap=overlap, bucket_bytes=bucket_bytes)
+        tr = Trainer(a, grad_sync=sync)
         for k in range(4):
             a.noise_distn = FixedNoise(noises[k])
             tr.step(batches[k])
         tr.finish()
+        layout = ([len(fg.buckets) for fg in sync.flats], dict(sync.stats))
 
         # B: explicit DDP semantics -- all-reduce(mean) every gradient, then step
         b = build()
@@ -76,7 +78,7 @@ def _worker(rank, world, port, overlap, ret):
         other = flat.clone()
         dist.broadcast(other, src=0)
         same = bool(torch.equal(flat, other))
-        ret[rank] = (worst, same)
+        ret[rank] = (worst, same, layout)
     finally:
         dist.destroy_process_group()
 
@@ -87,9 +89,58 @@ def test_gradsync_equals_ddp_mean_then_step(overlap):
     ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), overlap, ret), nprocs=world, join=True)
     for rank in range(world):
-        worst, same = ret[rank]
+        worst, same, (nbuckets, stats) = ret[rank]
         assert same, "ranks diverged"
         assert worst < 1e-6, worst
+        assert nbuckets == [1, 1]                    # the 8-feature nets fit one 16 MB bucket each
+        assert stats["buckets_from_hooks"] == (4 if overlap else 0)
+
+
+def test_gradsync_many_buckets_reduced_from_backward_hooks():
+    """Small buckets: each one's all-reduce is issued from the autograd thread as soon as its last gradient has been
+    accumulated (so it overlaps the rest of backward); the result still equals mean-then-step and ranks agree."""
+    world = 2
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), True, ret, 4096), nprocs=world, join=True)
+    for rank in range(world):
+        worst, same, (nbuckets, stats) = ret[rank]
+        assert same and worst < 1e-6, (same, worst)
+        assert nbuckets[0] >= 4 and nbuckets[1] >= 4, nbuckets
+        # two D steps and two G steps: every bucket of the active network came from a hook, none was left over
+        assert stats["buckets_from_hooks"] == 2 * nbuckets[0] + 2 * nbuckets[1] and stats["buckets_after_backward"] == 0
+
+
+def _ckpt_worker(rank, world, port, ckpt_dir, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cpu_harness import run_on_cpu
+        from lightning_gan_zoo_amd.ddp import GradSync
+        module, trainer, step, _ = run_on_cpu(
+            "dc_gan", ["train.features_gen=8", "train.features_disc=8", "model.noise_dim=16", "log_every=1000",
+                       "train.batch_size=2", "train.ckpt_dir=" + ckpt_dir, "max_steps=5", "steps_per_epoch=2"],
+            sync_factory=GradSync, rank=rank, world=world)
+        bufs = torch.cat([b.detach().float().reshape(-1) for b in module.buffers()])
+        other = bufs.clone()
+        dist.broadcast(other, src=0)
+        ret[rank] = (step, bool(torch.equal(bufs, other)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_checkpoint_without_deadlock(tmp_path):
+    """Round-1 advisor finding: ``sync_buffers`` (a broadcast per norm buffer) sat inside the rank-0 guard, so a
+    multi-rank run that saved a checkpoint hung.  Now every rank joins the broadcast, rank 0 writes, all meet at a
+    barrier; the per-rank BatchNorm buffers equal rank 0's afterwards and the file is Lightning-shaped."""
+    world = 2
+    ck = str(tmp_path / "ck")
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_ckpt_worker, args=(world, _free_port(), ck, ret), nprocs=world, join=True)
+    assert [ret[r] for r in range(world)] == [(5, True), (5, True)]
+    assert os.listdir(ck) == ["step=5.ckpt"]
+    blob = torch.load(os.path.join(ck, "step=5.ckpt"), weights_only=False)
+    assert blob["global_step"] == 5 and blob["epoch"] == 2
 
 
 def test_optimizer_schedule_follows_frequencies():

@@ -32,8 +32,11 @@ def test_image_folder_order_and_transform(tmp_path):
     rel = [(os.path.relpath(p, root), c) for p, c in samples]
     assert rel == [("a_class/10.png", 0), ("a_class/2.png", 0), ("b_class/a.png", 1), ("b_class/m.jpg", 1),
                    ("b_class/z.png", 1), ("c_class/sub/k.png", 2)]
+    from cpu_harness import HostNormalisedFolder
     data = ImageFolderImages(root, batch=4, img_size=16, channels=3, mean=0.5, std=0.5, device="cpu")
-    it = iter(data)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):       # the device half needs the GPU
+        next(iter(data))
+    it = iter(HostNormalisedFolder(data))
     (x0, l0), (x1, l1), (x2, l2) = next(it), next(it), next(it)
     assert x0.shape == (4, 3, 16, 16) and x1.shape == (2, 3, 16, 16)       # the incomplete last batch is kept
     assert l0.tolist() == [0, 0, 1, 1] and l1.tolist() == [1, 2] and l2.tolist() == l0.tolist()   # next epoch, same order
@@ -41,7 +44,10 @@ def test_image_folder_order_and_transform(tmp_path):
     ref = (np.asarray(img, dtype=np.float32).transpose(2, 0, 1) / 255.0 - 0.5) / 0.5
     assert np.abs(x0[2].numpy() - ref).max() < 1e-6 and float(x0.min()) >= -1.0 and float(x0.max()) <= 1.0
     grey = ImageFolderImages(root, batch=3, img_size=8, channels=1, mean=0.5, std=0.5, device="cpu")
-    assert next(iter(grey))[0].shape == (3, 1, 8, 8)
+    assert next(iter(HostNormalisedFolder(grey)))[0].shape == (3, 1, 8, 8)
+    # two data-parallel ranks see disjoint halves in DistributedSampler(shuffle=False) order
+    halves = [ImageFolderImages(root, 4, 16, 3, 0.5, 0.5, "cpu", rank=r, world=2) for r in range(2)]
+    assert [h.order for h in halves] == [[0, 2, 4], [1, 3, 5]]
 
 
 @pytest.mark.gpu
@@ -54,7 +60,8 @@ def test_device_side_normalisation_and_prefetch(tmp_path):
     assert out.shape == (5, 3, 12, 20) and float((out.cpu() - ref).abs().max()) < 1e-5
     root = str(tmp_path)
     make_folder(root)
-    cpu = iter(ImageFolderImages(root, 4, 16, 3, 0.5, 0.5, "cpu"))
+    from cpu_harness import HostNormalisedFolder
+    cpu = iter(HostNormalisedFolder(ImageFolderImages(root, 4, 16, 3, 0.5, 0.5, "cpu")))
     gpu = iter(ImageFolderImages(root, 4, 16, 3, 0.5, 0.5, "cuda"))
     for _ in range(5):                      # more batches than pinned buffers: the ring is reused
         (xc, lc), (xg, lg) = next(cpu), next(gpu)

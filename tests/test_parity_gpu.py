@@ -279,16 +279,20 @@ def test_loss_trajectory_tracks_oracle(expt):
     assert float((a - b).abs().max()) < TOL * max(1.0, float(b.abs().max()))
 
 
-@pytest.mark.parametrize("expt", ["dc_gan", "wgan", "wgan_gp", scenario.R1_EXPT])
+@pytest.mark.parametrize("expt", ["dc_gan", "wgan", "wgan_gp", scenario.R1_EXPT, "hologan"])
 def test_graphed_trainer_matches_eager_trainer(expt):
     """harness.GraphedTrainer (each optimizer step captured once in a HIP graph and replayed) against the eager
     Trainer: same seed, same host RNG stream, same batches -> the same kernels in the same order, so the loss
-    trajectory and the final parameters must agree to rounding (bit-identical in practice)."""
+    trajectory and the final parameters must agree to rounding (bit-identical in practice).  hologan: the view
+    matrices are staged like the noise, and its LambdaLR changes the learning rate at every ``end_epoch()`` of this
+    run (num_epochs 4), which must reach the replayed optimizer launches (round-1 advisor finding)."""
     from helpers import synthetic_real
     from lightning_gan_zoo_amd.harness import GraphedTrainer, Trainer
     kw = dict(batch_size=8, features=8, noise_dim=16)
     if expt == scenario.R1_EXPT:
         kw.update(features=4, img_size=32)
+    if expt == "hologan":
+        kw["dotted"] = {"train.num_epochs": 4}
     img = kw.get("img_size", 64)
     results = {}
     for name, cls in (("eager", Trainer), ("graph", GraphedTrainer)):
@@ -297,12 +301,17 @@ def test_graphed_trainer_matches_eager_trainer(expt):
         module = locate(cfg.model.lm["_target_"])(cfg, None).to("cuda")
         trainer = cls(module)
         torch.manual_seed(7)                      # host generator: latent noise / alpha draws
+        np.random.seed(7)                         # HoloGAN's views
         labels = torch.zeros(8, dtype=torch.int64, device="cuda")
         losses = []
-        for k in range(5 * len(trainer.order)):
+        for k in range(6 * len(trainer.order)):
             real = synthetic_real(8, size=img, seed=600 + k).cuda()
             loss, idx = trainer.step((real, labels))
             losses.append(float(loss.item()))
+            if (k + 1) % (2 * len(trainer.order)) == 0:
+                trainer.end_epoch()
+        if expt == "hologan":
+            assert trainer.optim[0]["optimizer"].param_groups[0]["lr"] < 1e-4       # the schedule did move
         results[name] = (np.array(losses), {k: v.detach().cpu().clone() for k, v in module.state_dict().items()})
     (le, se), (lg, sg) = results["eager"], results["graph"]
     assert np.abs(le - lg).max() <= 1e-6 * max(1.0, np.abs(le).max()), (le, lg)

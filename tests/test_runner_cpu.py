@@ -1,50 +1,117 @@
-"""Host logic of the thin runner on CPU (using the oracle networks as the model): Hydra-style override
-grammar, derived config values, Lightning-style checkpoint keys, save / resume round trip."""
+"""Host logic of the thin runner on CPU (tests/cpu_harness.py supplies the oracle networks as the model): Hydra-style
+override grammar, derived config values, epochs / LR schedule / stop conditions, Lightning's checkpoint envelope,
+save / resume round trip, best-score bookkeeping, per-rank sharding."""
 import os
 
 import pytest
 import torch
 
+from cpu_harness import run_on_cpu
 from lightning_gan_zoo_amd import run_network as R
+
+SMALL = ["train.features_gen=8", "train.features_disc=8", "model.noise_dim=16", "log_every=1000"]
 
 
 def test_override_grammar_and_derived_values():
-    expt, ov, run = R.parse_overrides(["+expt=wgan_gp", "train.batch_size=16", "train.features_gen=8",
-                                       "train.features_disc=8", "model.noise_dim=16", "max_steps=3",
-                                       "optimisation.lr=0.001"])
-    assert expt == "wgan_gp" and run["max_steps"] == 3 and ov["train.batch_size"] == 16
-    cfg = R.compose(expt, ov)
-    assert cfg.generator.features_g == 8 and cfg.discriminator.features_d == 8
+    conf, expt, ov, run = R.parse_overrides(["+expt=wgan_gp", "train.batch_size=16", "train.features_gen=8",
+                                             "train.features_disc=8", "model.noise_dim=16", "+max_steps=3",
+                                             "optimisation.lr=1e-3"])
+    assert conf is None and expt == "wgan_gp" and run["max_steps"] == 3
+    cfg = R.compose(conf, expt, ov, run)
+    assert cfg.generator.features_g == 8 and cfg.discriminator.features_d == 8 and cfg.train.batch_size == 16
     assert cfg.generator.channels_noise == 16 and cfg.discriminator.norm == "instance_norm2d"
-    assert cfg.disc_optimiser.lr == 0.001 and cfg.loss_weight.lambda_gp == 10
-    expt, ov, _ = R.parse_overrides(["+expt=gan_stability_r1", "train.img_size=32", "model.noise_dim=24",
-                                     "loss_weight.reg=3.5"])
-    cfg = R.compose(expt, ov)
+    assert cfg.disc_optimiser.lr == 0.001 and cfg.gen_optimiser.lr == 0.001 and cfg.loss_weight.lambda_gp == 10
+    conf, expt, ov, run = R.parse_overrides(["+expt=gan_stability_r1", "train.img_size=32", "model.noise_dim=24",
+                                             "loss_weight.reg=3.5"])
+    cfg = R.compose(conf, expt, ov, run)
     assert cfg.generator.size == 32 and cfg.discriminator.size == 32 and cfg.generator.z_dim == 24
     assert cfg.loss_weight.reg == 3.5 and cfg.model.lm["_target_"].endswith("GANStabilityR1")
+    cfg = R.compose(*R.parse_overrides(["+expt=hologan", "train.num_epochs=10", "optimisation.beta1=0.5"])[:3])
+    assert cfg.optimisation.lr_scheduler.total_epochs == 10 and cfg.disc_optimiser.betas == [0.5, 0.999]
     with pytest.raises(SystemExit):
-        R.compose("dc_gan", {"train.no_such_key": 1})
+        R.compose(None, "dc_gan", ["train.no_such_key=1"])
     with pytest.raises(SystemExit):
         R.parse_overrides(["train.batch_size=4"])          # +expt is mandatory
+    # BASELINE config 1's literal command line parses (built-in tree): +expt=dc_gan dataset=celeb_a
+    cfg = R.compose(*R.parse_overrides(["+expt=dc_gan", "dataset=celeb_a", "filepaths.celeb_a_root=/data/celeba"])[:3])
+    assert cfg.dataset._target_ == "torchvision.datasets.ImageFolder" and cfg.dataset.train.root == "/data/celeba/train"
+
+
+def test_product_command_line_cannot_reach_the_oracle_or_a_cpu_device():
+    """oracle-vs-kernels is a TEST switch.  The runner has no module_root / device keys, its main()
+    refuses to run without a GPU, and the real-data input step has no CPU arithmetic."""
+    with pytest.raises(SystemExit):
+        R.compose(*R.parse_overrides(["+expt=dc_gan", "module_root=oracle.reference_cpu"])[:3])
+    with pytest.raises(SystemExit):
+        R.compose(*R.parse_overrides(["+expt=dc_gan", "device=cpu"])[:3])
+    if not torch.cuda.is_available():
+        with pytest.raises(SystemExit, match="no CPU fallback"):
+            R.main(["+expt=dc_gan", "+max_steps=1"])
 
 
 def test_train_checkpoint_resume_roundtrip(tmp_path):
     ck = str(tmp_path / "ckpt")
-    args = ["+expt=dc_gan", "module_root=oracle.reference_cpu", "device=cpu", "train.batch_size=4",
-            "train.features_gen=8", "train.features_disc=8", "model.noise_dim=16", "train.ckpt_dir=" + ck,
-            "log_every=1000"]
+    args = SMALL + ["train.batch_size=4", "train.ckpt_dir=" + ck]
     torch.set_num_threads(2)
-    m1, t1, s1 = R.main(args + ["max_steps=4"])
+    m1, t1, s1, _ = run_on_cpu("dc_gan", args + ["max_steps=4"])
     files = os.listdir(ck)
     assert files == ["step=4.ckpt"]
     blob = torch.load(os.path.join(ck, files[0]), weights_only=False)
+    # Lightning's envelope (pl.Trainer.save_checkpoint of the 1.1 / 1.2 generation)
+    assert {"epoch", "global_step", "pytorch-lightning_version", "state_dict", "optimizer_states", "lr_schedulers",
+            "callbacks"} <= set(blob)
+    assert blob["global_step"] == 4 and blob["callbacks"]["ModelCheckpoint"]["monitor"] == "fid"
     keys = set(blob["state_dict"])
     assert "generator.net.block1.transpose_conv.weight" in keys            # Lightning-style names
     assert "discriminator.disc.block3.batch_norm.running_var" in keys
+    assert len(blob["optimizer_states"]) == 2 and "param_groups" in blob["optimizer_states"][0]
     # resume: picks the single *.ckpt, continues the optimizer alternation where it stopped
-    m2, t2, s2 = R.main(args + ["max_steps=6"])
+    m2, t2, s2, _ = run_on_cpu("dc_gan", args + ["max_steps=6"])
     assert s2 == 6 and os.listdir(ck) == ["step=6.ckpt"]
     assert t2.optim[0]["optimizer"].state_dict()["state"][0]["step"] >= 3  # Adam state was restored, then advanced
+    open(os.path.join(ck, "second.ckpt"), "w").write("x")
+    with pytest.raises(AssertionError, match="Multiple ckpts"):            # reference run_network.py:21
+        R.find_ckpt(ck)
+
+
+def test_epochs_scheduler_and_stop_at_num_epochs(tmp_path):
+    """An epoch is ceil(len(dataset) / batch) steps (synthetic: steps_per_epoch); the LR schedulers step per epoch and
+    training stops at train.num_epochs -- HoloGAN's LambdaLR reaches 0 there and would turn negative beyond."""
+    torch.set_num_threads(2)
+    m, tr, steps, cfg = run_on_cpu("hologan", ["train.features_gen=8", "train.features_disc=8", "log_every=1000",
+                                               "train.batch_size=2", "train.num_epochs=4", "steps_per_epoch=3",
+                                               "model.noise_dim=16"])
+    assert steps == 12                                             # 4 epochs x 3 steps, no max_steps given
+    lrs = [o["optimizer"].param_groups[0]["lr"] for o in tr.optim]
+    assert all(lr >= 0 for lr in lrs) and lrs[0] == pytest.approx(0.0)      # 1 - (4 - 2) / 2
+
+
+def test_best_score_bookkeeping_follows_model_checkpoint(tmp_path):
+    """ModelCheckpoint(monitor='fid', filename='model_best-{fid:.2f}'), mode min, save_top_k 1."""
+    ck = str(tmp_path / "ckpt")
+    scores = iter([31.237, 40.0, 12.5])
+    torch.set_num_threads(2)
+    seen = []
+
+    def evaluate(module, epoch):
+        s = next(scores)
+        seen.append(sorted(os.listdir(ck)) if os.path.isdir(ck) else [])
+        return {"fid": s}
+
+    run_on_cpu("dc_gan", SMALL + ["train.batch_size=2", "train.ckpt_dir=" + ck, "steps_per_epoch=2", "max_steps=6"],
+               evaluate=evaluate)
+    assert seen == [[], ["model_best-fid=31.24.ckpt"], ["model_best-fid=31.24.ckpt"]]      # 40.0 did not replace it
+    assert os.listdir(ck) == ["model_best-fid=12.50.ckpt"]
+    st = torch.load(os.path.join(ck, "model_best-fid=12.50.ckpt"), weights_only=False)["callbacks"]["ModelCheckpoint"]
+    assert st["best_model_score"] == 12.5 and st["best_model_path"].endswith("model_best-fid=12.50.ckpt")
+
+
+def test_shard_indices_match_distributed_sampler():
+    from torch.utils.data.distributed import DistributedSampler
+    for n, world in ((10, 4), (7, 2), (8, 8), (3, 4), (5, 1)):
+        for rank in range(world):
+            ref = list(DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=False))
+            assert R.shard_indices(n, rank, world) == ref, (n, world, rank)
 
 
 def test_runner_trains_from_an_image_folder(tmp_path):
@@ -54,8 +121,8 @@ def test_runner_trains_from_an_image_folder(tmp_path):
     root = str(tmp_path / "imgs")
     make_folder(root)
     torch.set_num_threads(2)
-    module, trainer, step = R.main(["+expt=dc_gan", "module_root=oracle.reference_cpu", "device=cpu",
-                                    "dataset=image_folder", "dataset_path=" + root, "train.batch_size=3",
-                                    "train.features_gen=8", "train.features_disc=8", "model.noise_dim=16",
-                                    "max_steps=4", "log_every=1000"])
+    module, trainer, step, cfg = run_on_cpu("dc_gan", SMALL + ["dataset=image_folder", "dataset_path=" + root,
+                                                               "train.batch_size=3", "max_steps=4"])
     assert step == 4 and all(torch.isfinite(p).all() for p in module.parameters())
+    # 6 images, batch 3 -> 2 steps per epoch -> the 4 steps were 2 epochs
+    assert trainer.optim[0]["lr_scheduler"].last_epoch == 2
