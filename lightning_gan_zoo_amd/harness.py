@@ -268,8 +268,18 @@ class GraphedTrainer(Trainer):
                 self.static_batch[0].grad = None     # R1 asks for d/d(real): let the capture (re)create it
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                loss = self._body(idx)
+            # no cyclic-garbage collection while capturing: a collection that frees device tensors / events left
+            # over from earlier work would call into the HIP runtime in the middle of the capture (abort)
+            import gc
+            was_enabled = gc.isenabled()
+            gc.collect()
+            gc.disable()
+            try:
+                with torch.cuda.graph(g):
+                    loss = self._body(idx)
+            finally:
+                if was_enabled:
+                    gc.enable()
             self.graphs[key] = (g, loss)
             # the capture itself does not execute: run it once so that this step takes effect
             g.replay()
