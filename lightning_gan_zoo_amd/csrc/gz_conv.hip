@@ -42,9 +42,11 @@ static int min_wgs() {
     return t;
 }
 
-// Tile choice: the chip has 256 CUs and the kernels only approach the MFMA rate with ~3+ workgroups
-// per CU in flight (their load and MFMA phases overlap across workgroups), so prefer the largest
-// tile that still yields >= min_wgs() workgroups; narrow N gets narrow tiles.
+// Tile choice.  Measured on the DCGAN layers at bs 512 (tools/conv_bench.py, round 2, 4 / 6 / 8 co-resident
+// workgroups per CU for the three shapes): a launch that fills the chip runs at ~125 (128x128), ~112 (128x64) and
+// ~108 TFLOP/s (64x64); one that leaves workgroup slots empty loses in proportion (D.block3's dgrad: 512 tiles of
+// 128x128 on 1024 slots -> the 2048 64x64 tiles win), and between one and two rounds part of the second round is
+// exposed.  Score = shape efficiency x fill and take the best; narrow N gets narrow tiles.
 static TileId pick_tile(long long M, long long N, int ny) {
     int f = forced_tile();
     if (f >= 0 && f <= 3) {
@@ -52,11 +54,25 @@ static TileId pick_tile(long long M, long long N, int ny) {
     }
     if (N <= 32) return T128x32;
     auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * ny; };
-    const long long want = min_wgs();
-    if (N <= 64) return tiles(128, 64) >= want ? T128x64 : T64x64;
-    if (tiles(128, 128) >= want) return T128x128;
-    if (tiles(128, 64) >= want) return T128x64;
-    return T64x64;
+    if (getenv("GZ_MIN_WGS")) {           // round-1 rule, kept for experiments
+        const long long want = min_wgs();
+        if (N <= 64) return tiles(128, 64) >= want ? T128x64 : T64x64;
+        if (tiles(128, 128) >= want) return T128x128;
+        if (tiles(128, 64) >= want) return T128x64;
+        return T64x64;
+    }
+    auto score = [&](int bm, int bn, double eff, int per_cu) {
+        const double rounds = (double)tiles(bm, bn) / (256.0 * per_cu);
+        double fill = 1.0;
+        if (rounds <= 1.0) fill = rounds;
+        else if (rounds < 2.0) fill = 0.5 + 0.5 * rounds / 2.0;      // 1 < rounds < 2: half of the tail is hidden
+        return eff * fill;
+    };
+    const double s64 = score(64, 64, 0.86, 8), s128x64 = score(128, 64, 0.90, 6);
+    if (N <= 64) return s128x64 >= s64 ? T128x64 : T64x64;
+    const double s128 = score(128, 128, 1.0, 4);
+    if (s128 >= s128x64 && s128 >= s64) return T128x128;
+    return s128x64 >= s64 ? T128x64 : T64x64;
 }
 
 // Split-K for F / Dg / GEMM launches whose output has too few tiles to fill 256 CUs (deep 4x4 / 8x8 feature
@@ -385,10 +401,111 @@ __global__ __launch_bounds__(256) void dgrad_smallc_k4s2p1_kernel(const float* _
     }
 }
 
+// Same operation, 4 input positions per lane (round 2).  The one-position kernel issues 9 dword loads per lane
+// and feature channel -- every y value is requested 9 times, and at 256 B per wave-instruction the vector cache,
+// not HBM, sets the pace (186 us for the 268 MB of G's last layer = 1.6 TB/s).  Here a lane owns (n, a, b..b+3):
+// per channel it loads the three rows a-1, a, a+1 as ONE aligned 16-byte vector each and takes the two halo
+// columns from its neighbour lanes (wave shuffles; at the image edge they are zero), i.e. 0.75 load instructions
+// per position instead of 9, then runs the same 48 FMAs per position.  The eight outputs of an output row are two
+// 16-byte stores.  Needs OW % 4 == 0 and 16-byte aligned rows.
+template <int C>
+__global__ __launch_bounds__(256) void dgrad_smallc4_k4s2p1_kernel(const float* __restrict__ y,
+                                                                   const float* __restrict__ wp,
+                                                                   const float* __restrict__ bias,
+                                                                   float* __restrict__ x, ConvShape s,
+                                                                   FastDiv div_ohw4, FastDiv div_ow4, int act,
+                                                                   float slope) {
+    const int OW4 = s.OW >> 2, OHW = s.OH * s.OW;
+    const uint32_t M4 = (uint32_t)s.N * s.OH * OW4;
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    const bool m_ok = m < M4;
+    const uint32_t n = fdiv(m, div_ohw4);
+    const uint32_t pix = m - n * (uint32_t)(s.OH * OW4);
+    const int a = (int)fdiv(pix, div_ow4);
+    const int b = (int)(pix - (uint32_t)a * (uint32_t)OW4) * 4;
+    __amdgpu_buffer_rsrc_t rsrc = make_rsrc(y, (uint32_t)s.N * s.K * OHW * 4u);
+    uint32_t voff[3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        int oy = a + dy - 1;
+        bool ok = m_ok && (unsigned)oy < (unsigned)s.OH;
+        voff[dy] = ok ? (n * (uint32_t)(s.K * OHW) + (uint32_t)(oy * s.OW + b)) * 4u : OOB;
+    }
+    // halo columns come from the neighbour lanes; a lane at the left / right image edge has none (the lane next to
+    // it then belongs to another row, or to another wave: both cases are exactly the edge cases)
+    const bool has_l = b > 0, has_r = b + 4 < s.OW;
+    float acc[4][2][2][C];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[q][i][j][c] = 0.f;
+    const long long phase_stride = (long long)s.K * 16;    // floats: K * 4 taps * ldc(4)
+    for (int ko = 0; ko < s.K; ++ko) {
+        float v[3][6];
+        const uint32_t soff = (uint32_t)ko * (uint32_t)OHW * 4u;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const f32x4 r = bload4(rsrc, voff[dy], soff);
+            const float l = __shfl_up(r.w, 1), rr = __shfl_down(r.x, 1);
+            v[dy][0] = has_l ? l : 0.f;
+            v[dy][1] = r.x; v[dy][2] = r.y; v[dy][3] = r.z; v[dy][4] = r.w;
+            v[dy][5] = has_r ? rr : 0.f;
+        }
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                const float* wrow = wp + (py * 2 + px) * phase_stride + (long long)ko * 16;
+#pragma unroll
+                for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < 2; ++tx) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wrow + (ty * 2 + tx) * 4);
+                        const int ry = (py + 1) / 2 - ty + 1, rx = (px + 1) / 2 - tx + 1;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int c = 0; c < C; ++c)
+                                acc[q][py][px][c] = fmaf(v[ry][q + rx], w4[c], acc[q][py][px][c]);
+                    }
+            }
+    }
+    if (!m_ok) return;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+            float* dst = x + (((long long)n * C + c) * s.H + (2 * a + py)) * s.W + 2 * b;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 o;
+                o.x = act_fwd(acc[2 * h][py][0][c] + bv, act, slope);
+                o.y = act_fwd(acc[2 * h][py][1][c] + bv, act, slope);
+                o.z = act_fwd(acc[2 * h + 1][py][0][c] + bv, act, slope);
+                o.w = act_fwd(acc[2 * h + 1][py][1][c] + bv, act, slope);
+                *reinterpret_cast<f32x4*>(dst + 4 * h) = o;
+            }
+        }
+    }
+}
+
 template <int C>
 static int run_dgrad_smallc(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s, int act,
                             float slope, hipStream_t st) {
     long long M = (long long)s.N * s.OH * s.OW;
+    static const bool one_pos = getenv("GZ_SMALLC_ONE_POS") != nullptr;          // experiment: the round-1 kernel
+    // a row of OW/4 lanes must not straddle two wavefronts (the halo columns come from the neighbour LANES)
+    if (!one_pos && s.OW % 4 == 0 && 64 % (s.OW / 4) == 0 && (((uintptr_t)y | (uintptr_t)x) & 15) == 0) {
+        const long long M4 = M / 4;
+        hipLaunchKernelGGL(dgrad_smallc4_k4s2p1_kernel<C>, dim3((unsigned)((M4 + 255) / 256)), dim3(256), 0, st, y, wp,
+                           bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope);
+        return launch_status();
+    }
     hipLaunchKernelGGL(dgrad_smallc_k4s2p1_kernel<C>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, y, wp, bias,
                        x, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW), act, slope);
     return launch_status();
@@ -760,7 +877,7 @@ static int wg_target() {
     static int t = -1;
     if (t < 0) {
         const char* e = getenv("GZ_WG_TARGET");
-        t = e ? atoi(e) : 1536;
+        t = e ? atoi(e) : 1024;      // 4 workgroups of the 128x128 shape per CU (round 2; was 1536 at 2 per CU)
         if (t < 1) t = 1;
     }
     return t;
@@ -1038,7 +1155,7 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
         // split-K supplies the parallelism; with few pixels per split (small batches) the narrower
         // tile keeps more workgroups busy per slab byte
         long long pixels = (long long)N * OH * OW;
-        t = pixels >= 65536 ? T128x128 : T128x64;
+        t = pixels >= 8192 ? T128x128 : T128x64;     // round 2: 128x128 now holds 4 workgroups per CU (was 65536)
     }
     int f = forced_tile();
     if (f >= 0 && f <= 3 && !(f == T128x128 && NTOT <= 64)) t = f;

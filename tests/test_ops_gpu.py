@@ -68,6 +68,24 @@ def test_conv_family(geom, case):
     assert rel(dw, dw_ref) < TOL
 
 
+@pytest.mark.parametrize("case", [(3, 1, 8, 6), (2, 2, 16, 9), (4, 3, 64, 16), (2, 4, 32, 7), (5, 3, 128, 4),
+                                  (2, 3, 24, 5), (1, 3, 8, 128)])
+def test_small_channel_transposed_conv(case):
+    """ConvTranspose2d k4 s2 p1 onto <= 4 image channels (G's output layer, the critic's input gradient): the
+    4-positions-per-lane direct kernel (feature rows of 4 .. 64 columns; 24 columns -> 6 lanes per row do not divide
+    a wavefront, which takes the one-position kernel) with bias + tanh, against torch."""
+    F = _F()
+    N, C, H, K = case                      # image side [N, C, H, H], feature side [N, K, H/2, H/2]
+    gy = rnd(N, K, H // 2, H // 2, seed=7)
+    w = rnd(K, C, 4, 4, seed=8, scale=0.2)
+    b = rnd(C, seed=9)
+    ref = torch.tanh(TF.conv_transpose2d(gy, w, b, 2, 1))
+    out = F._conv_dgrad_raw(gy.cuda(), w.cuda(), b.cuda(), F.K4S2P1, (H, H), F.ACT_TANH, 0.0)
+    assert out.shape == ref.shape and rel(out, ref) < TOL
+    assert rel(F._conv_dgrad_raw(gy.cuda(), w.cuda(), None, F.K4S2P1, (H, H), F.ACT_NONE, 0.0),
+               TF.conv_transpose2d(gy, w, None, 2, 1)) < TOL
+
+
 def test_conv_bias_act_epilogues():
     F = _F()
     g = F.K4S2P1
