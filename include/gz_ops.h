@@ -115,9 +115,12 @@ int gz_conv3d_wgrad(const float* x, const float* y, float* dw, float* workspace,
  * int64 [8][N*S^3], the clamped corner indices in the reference's idx_a..idx_h order. */
 int gz_rigid_resample_fwd(const float* vox, const float* minv, float* out2d, long long* idx_out, int N, int C, int S,
                           hipStream_t stream);
-/* gvox [N,C,S,S,S] = adjoint of the above (accumulated in LDS per (sample, channel pair); every element written) */
-int gz_rigid_resample_bwd(const float* gout2d, const float* minv, float* gvox, int N, int C, int S,
-                          hipStream_t stream);
+/* gvox [N,C,S,S,S] = adjoint of the above in gather form (no atomics, every element written once): per-voxel hit
+ * lists in `workspace` (gz_rigid_resample_bwd_workspace_bytes), gradient volumes staged through LDS.  workspace
+ * NULL / too small: the same result from the slower direct gather. */
+size_t gz_rigid_resample_bwd_workspace_bytes(int N, int S);
+int gz_rigid_resample_bwd(const float* gout2d, const float* minv, float* gvox, float* workspace, size_t ws_bytes,
+                          int N, int C, int S, hipStream_t stream);
 
 /* ---- normalisation + activation -------------------------------------------------------------
  * A tensor [N, C, inner] is N*C rows of `inner` contiguous floats (inner % 4 == 0).

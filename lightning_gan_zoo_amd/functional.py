@@ -1031,7 +1031,9 @@ class _RigidResample(torch.autograd.Function):
         N, C, S = ctx.shape
         g = _req(g)
         gv = torch.empty((N, C, S, S, S), device=g.device, dtype=torch.float32)
-        check(lib.gz_rigid_resample_bwd(_p(g), _p(minv), _p(gv), N, C, S, _stream()), "rigid_resample_bwd")
+        ws, nbytes = _scratch((lib.gz_rigid_resample_bwd_workspace_bytes(N, S) + 3) // 4 * 4, g.device)
+        check(lib.gz_rigid_resample_bwd(_p(g), _p(minv), _p(gv), _p(ws), nbytes, N, C, S, _stream()),
+              "rigid_resample_bwd")
         return gv, None
 
 

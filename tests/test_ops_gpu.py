@@ -287,6 +287,8 @@ def test_rigid_resample_matches_oracle_and_indices_are_bit_exact():
     view[:, 2] = 1.0
     view[0] = (0.0, 0.0, 1.0, 0.0, 0.0, 0.0)         # identity view: every coordinate lands on an integer
     view[1, 3:] = (0.7, -1.2, 0.4)
+    view[4, 2] = 2.0         # zoom in: each source voxel is hit by ~64 output voxels (the adjoint's hit lists overflow
+    view[5, 2] = 0.6         # and the launch falls back to the direct gather); zoom out: fewer hits than usual
     vox = rnd(n, c, 16, 16, 16, seed=91)
     minv = view_inverse_matrices(view)
     assert torch.equal(minv, H.view_matrices(view))                       # host matrices: bit-identical
