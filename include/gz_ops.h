@@ -122,6 +122,26 @@ size_t gz_rigid_resample_bwd_workspace_bytes(int N, int S);
 int gz_rigid_resample_bwd(const float* gout2d, const float* minv, float* gvox, float* workspace, size_t ws_bytes,
                           int N, int C, int S, hipStream_t stream);
 
+/* ---- loss heads and the scalar side of spectral normalisation (csrc/gz_loss.hip) -----------------------------
+ * Scalars (loss, sigma, the incoming loss gradient) are 1-element DEVICE arrays: nothing synchronises with the host.
+ * loss[0] = mean_i BCE-with-logits(x[i], target), target a constant 0 or 1: criterion(logits, ones_like(logits)) /
+ * zeros_like of core/lightning_module.py:114-119,126,221-235 */
+int gz_bce_logits_mean(const float* x, float* loss, int n, float target, hipStream_t stream);
+/* dx[i] = (sigmoid(x[i]) - target) * gloss[0] / n */
+int gz_bce_logits_mean_bwd(const float* x, const float* gloss, float* dx, int n, float target, hipStream_t stream);
+/* loss[0] = mean((a - b)^2): HoloGAN's q_loss (:226,234);  da[i] = 2 (a[i] - b[i]) gloss[0] / n */
+int gz_mse_mean(const float* a, const float* b, float* loss, int n, hipStream_t stream);
+int gz_mse_mean_bwd(const float* a, const float* b, const float* gloss, float* da, int n, hipStream_t stream);
+/* torch.nn.utils.spectral_norm (core/models/hologan_discriminator.py:15): out = x / max(||x||, eps) (in place
+ * allowed; the same values also to out2; out, out2, norm_out may be NULL), norm_out[0] = ||x||; out[0] = <a, b>; out = x / sigma[0]; and the gradient of
+ * w = W / sigma(W), sigma = u^T W v:  out[r][l] = (g[r][l] - (sum_r rowdots[r]) u[r] v[l]) / sigma[0] with
+ * rowdots[r] = <g[r], w[r]> (gz_rowdot). */
+int gz_vec_normalize(const float* x, float* out, float* out2, float* norm_out, int n, float eps, hipStream_t stream);
+int gz_vec_dot(const float* a, const float* b, float* out, int n, hipStream_t stream);
+int gz_div_scalar(const float* x, const float* sigma, float* out, long long count, hipStream_t stream);
+int gz_spectral_norm_bwd(const float* g, const float* rowdots, const float* u, const float* v, const float* sigma,
+                         float* out, int R, int L, hipStream_t stream);
+
 /* ---- normalisation + activation -------------------------------------------------------------
  * A tensor [N, C, inner] is N*C rows of `inner` contiguous floats (inner % 4 == 0).
  * coef layout: 4 arrays of `ncoef` floats (scale, shift, mean, rstd); ncoef = C for per-channel

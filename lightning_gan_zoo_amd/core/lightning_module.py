@@ -55,6 +55,16 @@ class BaseGAN(LightningModule):
     def training_step(self, batch, batch_idx, optimizer_idx):
         pass
 
+    def criterion_const(self, logits, value):
+        """``self.criterion(logits, ones_like(logits))`` / ``zeros_like`` (reference :114-119,126): the shipped
+        criterion (BCEWithLogitsLoss, mean reduction, conf/config.yaml:19-20) against a constant target is one fused
+        launch forward and one backward; any other criterion object is called as the reference calls it."""
+        c = self.criterion
+        if (isinstance(c, torch.nn.BCEWithLogitsLoss) and c.reduction == "mean" and c.weight is None
+                and c.pos_weight is None and logits.is_cuda):
+            return F.bce_logits_mean(logits, value)
+        return c(logits, torch.full_like(logits, value))
+
     def sample_noise(self, n):
         # drawn on the host generator, then copied to the device (reference :107-108); single host
         # thread + pinned staging, see harness.few_host_threads / HostStager
@@ -90,16 +100,16 @@ class DCGAN(BaseGAN):
 
         if optimizer_idx == 0:      # discriminator (reference :112-121)
             disc_real = self.discriminator(real).reshape(-1)
-            loss_disc_real = self.criterion(disc_real, torch.ones_like(disc_real))
+            loss_disc_real = self.criterion_const(disc_real, 1.0)
             disc_fake = self.discriminator(fake.detach()).reshape(-1)
-            loss_disc_fake = self.criterion(disc_fake, torch.zeros_like(disc_fake))
+            loss_disc_fake = self.criterion_const(disc_fake, 0.0)
             loss_disc = (loss_disc_real + loss_disc_fake) / 2
             self.log("train/d_loss", loss_disc)
             return loss_disc
 
         if optimizer_idx == 1:      # generator (reference :124-128)
             output = self.discriminator(fake).reshape(-1)
-            loss_gen = self.criterion(output, torch.ones_like(output))
+            loss_gen = self.criterion_const(output, 1.0)
             self.log("train/g_loss", loss_gen)
             return loss_gen
 
@@ -114,9 +124,9 @@ class GANStabilityR1(BaseGAN):
         if optimizer_idx == 0:
             real.requires_grad_()
             disc_real = self.discriminator(real).reshape(-1)
-            loss_disc_real = self.criterion(disc_real, torch.ones_like(disc_real))
+            loss_disc_real = self.criterion_const(disc_real, 1.0)
             disc_fake = self.discriminator(fake.detach()).reshape(-1)
-            loss_disc_fake = self.criterion(disc_fake, torch.zeros_like(disc_fake))
+            loss_disc_fake = self.criterion_const(disc_fake, 0.0)
             r1_reg = self.cfg.loss_weight.reg * compute_grad2(disc_real, real).mean()
             loss_disc = r1_reg + (loss_disc_real + loss_disc_fake)
             self.log("train/d_loss", loss_disc)
@@ -124,7 +134,7 @@ class GANStabilityR1(BaseGAN):
 
         if optimizer_idx == 1:
             output = self.discriminator(fake).reshape(-1)
-            loss_gen = self.criterion(output, torch.ones_like(output))
+            loss_gen = self.criterion_const(output, 1.0)
             self.log("train/g_loss", loss_gen)
             return loss_gen
 
@@ -187,19 +197,19 @@ class HOLOGAN(BaseGAN):
 
         if optimizer_idx == 0:
             disc_real, _ = self.discriminator(real)
-            loss_disc_real = self.criterion(disc_real, torch.ones_like(disc_real))
+            loss_disc_real = self.criterion_const(disc_real, 1.0)
             disc_fake, d_z_pred = self.discriminator(fake.detach())
-            loss_disc_fake = self.criterion(disc_fake, torch.zeros_like(disc_fake))
+            loss_disc_fake = self.criterion_const(disc_fake, 0.0)
             loss_disc = (loss_disc_real + loss_disc_fake) / 2
-            q_loss = torch.mean((d_z_pred - z) ** 2)
+            q_loss = F.mse_mean(d_z_pred, z)
             self.log("train/d_loss", loss_disc)
             self.log("train/q_loss", q_loss)
             return loss_disc + q_loss
 
         if optimizer_idx == 1:
             output, d_z_pred = self.discriminator(fake)
-            loss_gen = self.criterion(output, torch.ones_like(output))
-            q_loss = torch.mean((d_z_pred - z) ** 2)
+            loss_gen = self.criterion_const(output, 1.0)
+            q_loss = F.mse_mean(d_z_pred, z)
             self.log("train/g_loss", loss_gen)
             self.log("train/q_loss", q_loss)
             return loss_gen + q_loss

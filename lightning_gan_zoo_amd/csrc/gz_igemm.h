@@ -1681,7 +1681,7 @@ inline int launch_igemm(const typename AL::Params& pa, const typename BL::Params
         const int fm = (M + 31) / 32, fn = (N + 31) / 32;
         // many slabs over few output blocks (the K = 8192 / 32768 linear heads): 16 wavefronts share the slab walk
         if (nz > 16)
-            hipLaunchKernelGGL((splitk_finish_kernel<Epi, 16>), dim3(fm * fn * ny), dim3(1024), 0, stream, slab, nz, M, N,
+            hipLaunchKernelGGL((splitk_finish_kernel<Epi, 8>), dim3(fm * fn * ny), dim3(512), 0, stream, slab, nz, M, N,
                                pe, fn, ny);
         else
             hipLaunchKernelGGL((splitk_finish_kernel<Epi, 4>), dim3(fm * fn * ny), dim3(NT), 0, stream, slab, nz, M, N, pe,

@@ -1,0 +1,204 @@
+// Small fused tails of the training step that the reference spells as chains of tiny torch operators:
+//   * BCE-with-logits against a constant target, mean-reduced (core/lightning_module.py:114-119,126,221-235:
+//     criterion(logits, ones_like / zeros_like)) and its gradient;
+//   * mean squared error (HoloGAN's q_loss, :226,234) and its gradient;
+//   * the scalar side of torch.nn.utils.spectral_norm (core/models/hologan_discriminator.py:15): vector
+//     normalisation of the power iteration, sigma, weight / sigma, and the gradient of that quotient.
+// All are a handful of values to a few MB; one launch each instead of 4..14 framework launches (HoloGAN's optimizer
+// cycle spent 42 % of its launches in such operators).  Scalars stay on the device (no host synchronisation).
+#include "gz_common.h"
+#include "../../include/gz_ops.h"
+
+namespace gz {
+
+constexpr int LT = 256;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {      // red: >= 4 floats of LDS
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// loss = mean_i( max(x,0) - x*t + log1p(exp(-|x|)) )   (torch's binary_cross_entropy_with_logits formula)
+__global__ __launch_bounds__(LT) void bce_logits_mean_kernel(const float* __restrict__ x, float* __restrict__ loss,
+                                                            int n, float t) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += LT) {
+        const float v = x[i];
+        s += (fmaxf(v, 0.f) - v * t) + log1pf(expf(-fabsf(v)));
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) loss[0] = s / (float)n;
+}
+
+// dx = (sigmoid(x) - t) * g / n
+__global__ __launch_bounds__(LT) void bce_logits_mean_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                float* __restrict__ dx, int n, float t) {
+    const float scale = g[0] / (float)n;
+    for (int i = blockIdx.x * LT + threadIdx.x; i < n; i += gridDim.x * LT) {
+        const float v = x[i];
+        dx[i] = (1.f / (1.f + expf(-v)) - t) * scale;
+    }
+}
+
+__global__ __launch_bounds__(LT) void mse_mean_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     float* __restrict__ loss, int n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += LT) {
+        const float d = a[i] - b[i];
+        s += d * d;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) loss[0] = s / (float)n;
+}
+
+// da = 2 (a - b) g / n   (db = -da, taken by the caller when b needs a gradient)
+__global__ __launch_bounds__(LT) void mse_mean_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ g, float* __restrict__ da, int n) {
+    const float scale = 2.f * g[0] / (float)n;
+    for (int i = blockIdx.x * LT + threadIdx.x; i < n; i += gridDim.x * LT) da[i] = (a[i] - b[i]) * scale;
+}
+
+// out = out2 = x / max(||x||, eps);  norm_out[0] = ||x||.  One workgroup (n <= a few thousand).  `out` may be the
+// module's persistent buffer (updated in place like torch's spectral_norm does) and `out2` the private copy the
+// autograd node keeps; either may be NULL.
+__global__ __launch_bounds__(LT) void vec_normalize_kernel(const float* __restrict__ x, float* out, float* out2,
+                                                          float* __restrict__ norm_out, int n, float eps) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += LT) s += x[i] * x[i];
+    s = block_sum(s, red);
+    const float nrm = sqrtf(s);
+    const float inv = 1.f / fmaxf(nrm, eps);
+    for (int i = threadIdx.x; i < n; i += LT) {
+        const float q = x[i] * inv;
+        if (out) out[i] = q;
+        if (out2) out2[i] = q;
+    }
+    if (threadIdx.x == 0 && norm_out) norm_out[0] = nrm;
+}
+
+// sigma[0] = <a, b>   (one workgroup)
+__global__ __launch_bounds__(LT) void vec_dot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                    float* __restrict__ out, int n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += LT) s += a[i] * b[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+// out = x / sigma[0]
+__global__ __launch_bounds__(LT) void div_scalar_kernel(const float* __restrict__ x, const float* __restrict__ sigma,
+                                                       float* __restrict__ out, long long total4) {
+    const float inv = 1.f / sigma[0];
+    const long long stride = (long long)gridDim.x * LT;
+    for (long long i = (long long)blockIdx.x * LT + threadIdx.x; i < total4; i += stride) {
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+}
+
+// gradient of w = W / sigma(W), sigma = u^T W v with u, v held constant:
+//   dW[r][l] = (G[r][l] - c * u[r] * v[l]) / sigma,   c = sum_r rowdots[r],  rowdots[r] = <G[r], w[r]>
+__global__ __launch_bounds__(LT) void sn_bwd_kernel(const float* __restrict__ G, const float* __restrict__ rowdots,
+                                                   const float* __restrict__ u, const float* __restrict__ v,
+                                                   const float* __restrict__ sigma, float* __restrict__ out, int R,
+                                                   int L4, long long total4, FastDiv div_l4) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < R; i += LT) s += rowdots[i];
+    const float c = block_sum(s, red);
+    const float inv = 1.f / sigma[0];
+    const long long stride = (long long)gridDim.x * LT;
+    for (long long i = (long long)blockIdx.x * LT + threadIdx.x; i < total4; i += stride) {
+        const uint32_t r = fdiv((uint32_t)i, div_l4);
+        const uint32_t q = (uint32_t)i - r * (uint32_t)L4;
+        const float cu = c * u[r];
+        const f32x4 g = reinterpret_cast<const f32x4*>(G)[i];
+        const f32x4 vv = reinterpret_cast<const f32x4*>(v)[q];
+        f32x4 o;
+        o.x = (g.x - cu * vv.x) * inv; o.y = (g.y - cu * vv.y) * inv;
+        o.z = (g.z - cu * vv.z) * inv; o.w = (g.w - cu * vv.w) * inv;
+        reinterpret_cast<f32x4*>(out)[i] = o;
+    }
+}
+
+static int grid_for(long long items) {
+    long long b = (items + LT - 1) / LT;
+    if (b > 2048) b = 2048;
+    return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace gz
+
+using namespace gz;
+
+extern "C" {
+
+int gz_bce_logits_mean(const float* x, float* loss, int n, float target, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (n <= 0) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(bce_logits_mean_kernel, dim3(1), dim3(LT), 0, stream, x, loss, n, target);
+    return launch_status();
+}
+
+int gz_bce_logits_mean_bwd(const float* x, const float* gloss, float* dx, int n, float target, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (n <= 0) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(bce_logits_mean_bwd_kernel, dim3(grid_for(n)), dim3(LT), 0, stream, x, gloss, dx, n, target);
+    return launch_status();
+}
+
+int gz_mse_mean(const float* a, const float* b, float* loss, int n, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (n <= 0) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(mse_mean_kernel, dim3(1), dim3(LT), 0, stream, a, b, loss, n);
+    return launch_status();
+}
+
+int gz_mse_mean_bwd(const float* a, const float* b, const float* gloss, float* da, int n, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (n <= 0) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(mse_mean_bwd_kernel, dim3(grid_for(n)), dim3(LT), 0, stream, a, b, gloss, da, n);
+    return launch_status();
+}
+
+int gz_vec_normalize(const float* x, float* out, float* out2, float* norm_out, int n, float eps, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (n <= 0) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(vec_normalize_kernel, dim3(1), dim3(LT), 0, stream, x, out, out2, norm_out, n, eps);
+    return launch_status();
+}
+
+int gz_vec_dot(const float* a, const float* b, float* out, int n, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (n <= 0) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(vec_dot_kernel, dim3(1), dim3(LT), 0, stream, a, b, out, n);
+    return launch_status();
+}
+
+int gz_div_scalar(const float* x, const float* sigma, float* out, long long count, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (count <= 0 || (count & 3)) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(div_scalar_kernel, dim3(grid_for(count / 4)), dim3(LT), 0, stream, x, sigma, out, count / 4);
+    return launch_status();
+}
+
+int gz_spectral_norm_bwd(const float* g, const float* rowdots, const float* u, const float* v, const float* sigma,
+                         float* out, int R, int L, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (R <= 0 || L <= 0 || (L & 3)) return GZ_ERR_BAD_SHAPE;
+    const long long total4 = (long long)R * (L / 4);
+    hipLaunchKernelGGL(sn_bwd_kernel, dim3(grid_for(total4)), dim3(LT), 0, stream, g, rowdots, u, v, sigma, out, R, L / 4,
+                       total4, make_fastdiv(L / 4));
+    return launch_status();
+}
+
+}  // extern "C"

@@ -1051,11 +1051,59 @@ def rigid_resample_indices(vox, minv):
     return out, idx
 
 
+class _SpectralNormWeight(torch.autograd.Function):
+    """weight_orig / sigma with sigma = u^T W v after one power iteration (training: the module's u / v buffers are
+    updated in place, like torch.nn.utils.spectral_norm); u, v enter sigma as constants.  Six launches forward, two
+    backward (the framework spelling took ~16 + ~10)."""
+
+    @staticmethod
+    def forward(ctx, weight_orig, u, v, training, eps):
+        W = _req(weight_orig, "weight_orig")
+        R = W.shape[0]
+        L = W.numel() // R
+        st = _stream()
+        dev = W.device
+        us = torch.empty(R, device=dev, dtype=torch.float32)       # the copies this node keeps (the buffers move on)
+        vs = torch.empty(L, device=dev, dtype=torch.float32)
+        sigma = torch.empty(1, device=dev, dtype=torch.float32)
+        Wm = W.view(R, L)
+        if training:
+            v_raw = _coldot_raw(u, Wm)                              # W^T u
+            check(lib.gz_vec_normalize(_p(v_raw), _p(v), _p(vs), None, L, eps, st), "vec_normalize(v)")
+            wv = _rowdot_raw(Wm, vs, True)                          # W v
+            check(lib.gz_vec_normalize(_p(wv), _p(u), _p(us), None, R, eps, st), "vec_normalize(u)")
+        else:
+            us.copy_(u)
+            vs.copy_(v)
+            wv = _rowdot_raw(Wm, vs, True)
+        check(lib.gz_vec_dot(_p(us), _p(wv), _p(sigma), R, st), "vec_dot(sigma)")
+        w = torch.empty_like(W)
+        check(lib.gz_div_scalar(_p(W), _p(sigma), _p(w), W.numel(), st), "div_scalar")
+        ctx.save_for_backward(w, us, vs, sigma)
+        return w
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        w, us, vs, sigma = ctx.saved_tensors
+        g = _req(g)
+        R = w.shape[0]
+        L = w.numel() // R
+        rowdots = _rowdot_raw(g.view(R, L), w.view(R, L), False)
+        out = torch.empty_like(w)
+        check(lib.gz_spectral_norm_bwd(_p(g), _p(rowdots), _p(us), _p(vs), _p(sigma), _p(out), R, L, _stream()),
+              "spectral_norm_bwd")
+        return out, None, None, None, None
+
+
 def spectral_normalize(weight_orig, u, v, training, eps=1e-12):
     """torch.nn.utils.spectral_norm's weight: one power iteration (training: u, v updated in place),
     then weight_orig / sigma with sigma = u^T W v differentiable w.r.t. weight_orig.  The two
-    matrix-vector products per iteration run on gz_coldot / gz_rowdot."""
-    w_mat = weight_orig.reshape(weight_orig.shape[0], -1)
+    matrix-vector products per iteration run on gz_coldot / gz_rowdot, the rest on csrc/gz_loss.hip."""
+    L = weight_orig.numel() // weight_orig.shape[0]
+    if L % 4 == 0:
+        return _SpectralNormWeight.apply(weight_orig, u, v, bool(training), float(eps))
+    w_mat = weight_orig.reshape(weight_orig.shape[0], -1)           # odd row lengths: framework arithmetic
     if training:
         with torch.no_grad():
             wd = _req(w_mat.detach())
@@ -1068,6 +1116,60 @@ def spectral_normalize(weight_orig, u, v, training, eps=1e-12):
     uc, vc = u.clone(), v.clone()
     sigma = torch.dot(uc, _DotF.apply(w_mat, vc))
     return weight_orig / sigma
+
+
+# ---------------------------------------------------------------------------
+# loss heads (csrc/gz_loss.hip)
+# ---------------------------------------------------------------------------
+class _BCELogitsMean(torch.autograd.Function):
+    """mean BCE-with-logits against a constant target: criterion(x, ones_like(x)) / zeros_like(x)."""
+
+    @staticmethod
+    def forward(ctx, x, target):
+        x = _req(x, "logits").reshape(-1)
+        loss = torch.empty(1, device=x.device, dtype=torch.float32)
+        check(lib.gz_bce_logits_mean(_p(x), _p(loss), x.numel(), float(target), _stream()), "bce_logits_mean")
+        ctx.save_for_backward(x)
+        ctx.target = float(target)
+        return loss.reshape(())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _req(g).reshape(1)
+        dx = torch.empty_like(x)
+        check(lib.gz_bce_logits_mean_bwd(_p(x), _p(g), _p(dx), x.numel(), ctx.target, _stream()), "bce_logits_mean_bwd")
+        return dx, None
+
+
+def bce_logits_mean(logits, target):
+    return _BCELogitsMean.apply(logits.reshape(-1), target)
+
+
+class _MSEMean(torch.autograd.Function):
+    """mean((a - b)^2) with b a constant (HoloGAN's q_loss: b is the latent the generator was fed)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _req(a, "a"), _req(b, "b")
+        loss = torch.empty(1, device=a.device, dtype=torch.float32)
+        check(lib.gz_mse_mean(_p(a), _p(b), _p(loss), a.numel(), _stream()), "mse_mean")
+        ctx.save_for_backward(a, b)
+        return loss.reshape(())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _req(g).reshape(1)
+        da = torch.empty_like(a)
+        check(lib.gz_mse_mean_bwd(_p(a), _p(b), _p(g), _p(da), a.numel(), _stream()), "mse_mean_bwd")
+        return da, (-da if ctx.needs_input_grad[1] else None)
+
+
+def mse_mean(a, b):
+    return _MSEMean.apply(a, b)
 
 
 # ---------------------------------------------------------------------------

@@ -328,6 +328,57 @@ def test_spectral_normalize_matches_torch():
     assert rel(w_orig.grad, conv.weight_orig.grad) < TOL
 
 
+@pytest.mark.parametrize("n", [1, 7, 64, 513])
+def test_fused_loss_heads(n):
+    """BCE-with-logits against a constant target (mean) and the mean squared error of HoloGAN's q_loss: value and
+    gradient against torch, with a non-trivial upstream factor (the steps combine them as (a + b) / 2 + q)."""
+    F = _F()
+    x = rnd(n, seed=201) * 3
+    for target in (0.0, 1.0):
+        xr = x.clone().requires_grad_()
+        ref = TF.binary_cross_entropy_with_logits(xr, torch.full_like(xr, target))
+        (ref * 0.37).backward()
+        xd = x.cuda().requires_grad_()
+        out = F.bce_logits_mean(xd.reshape(n, 1), target)
+        (out * 0.37).backward()
+        assert out.dim() == 0 and rel(out, ref) < 1e-5 and rel(xd.grad, xr.grad) < 1e-5
+    a, b = rnd(n, 12, seed=202), rnd(n, 12, seed=203)
+    ar = a.clone().requires_grad_()
+    ref = torch.mean((ar - b) ** 2)
+    (ref * 1.7).backward()
+    ad = a.cuda().requires_grad_()
+    out = F.mse_mean(ad, b.cuda())
+    (out * 1.7).backward()
+    assert rel(out, ref) < 1e-5 and rel(ad.grad, ar.grad) < 1e-5
+
+
+def test_spectral_normalize_eval_mode_and_two_uses():
+    """Eval mode leaves u / v alone; two forward uses before one backward (the D step runs D(real), D(fake)) keep the
+    vectors each use saw."""
+    F = _F()
+    torch.manual_seed(5)
+    conv = torch.nn.utils.spectral_norm(torch.nn.Conv2d(8, 12, 5, 2, 2))
+    x1, x2 = rnd(2, 8, 16, 16, seed=211), rnd(2, 8, 16, 16, seed=212)
+    u0, v0 = conv.weight_u.clone(), conv.weight_v.clone()
+    conv.train()
+    ref = conv(x1).sum() + 2 * conv(x2).pow(2).sum()
+    ref.backward()
+    w_orig = conv.weight_orig.detach().clone().cuda().requires_grad_()
+    u, v = u0.cuda(), v0.cuda()
+    g = F.Geom(5, 5, 2, 2)
+    b = conv.bias.detach().cuda()
+    out = F.conv2d(x1.cuda(), F.spectral_normalize(w_orig, u, v, True), b, g).sum() + \
+        2 * F.conv2d(x2.cuda(), F.spectral_normalize(w_orig, u, v, True), b, g).pow(2).sum()
+    out.backward()
+    assert rel(out, ref) < TOL and rel(u, conv.weight_u) < TOL and rel(v, conv.weight_v) < TOL
+    assert rel(w_orig.grad, conv.weight_orig.grad) < TOL
+    conv.eval()
+    ue, ve = u.clone(), v.clone()
+    w_eval = F.spectral_normalize(w_orig.detach(), u, v, False)
+    assert torch.equal(u, ue) and torch.equal(v, ve)
+    assert rel(F.conv2d(x1.cuda(), w_eval, b, g), conv(x1)) < TOL
+
+
 def test_linear_act_fwd_bwd():
     F = _F()
     x, w, b = rnd(6, 40, seed=96), rnd(24, 40, seed=97, scale=0.2), rnd(24, seed=98)
