@@ -122,6 +122,26 @@ size_t gz_rigid_resample_bwd_workspace_bytes(int N, int S);
 int gz_rigid_resample_bwd(const float* gout2d, const float* minv, float* gvox, float* workspace, size_t ws_bytes,
                           int N, int C, int S, hipStream_t stream);
 
+/* ---- evaluation path: InceptionV3 feature extractor of FID / KID (core/callback_inception_metrics.py:183-246,
+ * core/submodules/gan_stability/metrics/inception.py) -- forward only --------------------------------------------
+ * y = act(conv2d(x, w) + bias) for ANY rectangular kernel, per-axis stride and padding (3x3 s2 p0, 5x5 s1 p2,
+ * 1x7 / 7x1, 1x3 / 3x1 ...).  Eval-mode BatchNorm is folded into w and bias by the caller.  wpack from
+ * gz_conv2d_pack_fwd_any (tap-major, channels padded to 16). */
+long long gz_conv2d_pack_fwd_any_elems(int K, int C, int KH, int KW);
+int gz_conv2d_pack_fwd_any(const float* w, float* wpack, int K, int C, int KH, int KW, hipStream_t stream);
+size_t gz_conv2d_fwd_any_workspace_bytes(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int SH,
+                                         int SW, int PH, int PW);
+int gz_conv2d_fwd_any(const float* x, const float* wpack, const float* bias, float* y, float* workspace,
+                      size_t ws_bytes, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int SH, int SW,
+                      int PH, int PW, int act, float slope, hipStream_t stream);
+/* square-window pooling over `planes` = N*C images; mode 0 max, 1 average with count_include_pad=False (the FID
+ * network's patched pools), 2 average over KS*KS.  nn.AdaptiveAvgPool2d(1) = KS = H, S = 1, P = 0, mode 2. */
+int gz_pool2d(const float* x, float* y, long long planes, int H, int W, int OH, int OW, int KS, int S, int P, int mode,
+              hipStream_t stream);
+/* y = F.interpolate(x, (OH, OW), mode='bilinear', align_corners=False) * mul + add */
+int gz_resize_bilinear(const float* x, float* y, long long planes, int H, int W, int OH, int OW, float mul, float add,
+                       hipStream_t stream);
+
 /* ---- loss heads and the scalar side of spectral normalisation (csrc/gz_loss.hip) -----------------------------
  * Scalars (loss, sigma, the incoming loss gradient) are 1-element DEVICE arrays: nothing synchronises with the host.
  * loss[0] = mean_i BCE-with-logits(x[i], target), target a constant 0 or 1: criterion(logits, ones_like(logits)) /

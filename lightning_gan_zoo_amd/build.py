@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libgz_hip.so")
 ARCH = "gfx950"
-SOURCES = ["gz_conv.hip", "gz_conv3d.hip", "gz_norm.hip", "gz_misc.hip", "gz_resample.hip", "gz_optim.hip", "gz_resnet.hip", "gz_loss.hip"]
+SOURCES = ["gz_conv.hip", "gz_conv3d.hip", "gz_norm.hip", "gz_misc.hip", "gz_resample.hip", "gz_optim.hip", "gz_resnet.hip", "gz_loss.hip", "gz_infer.hip"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE]
 
 

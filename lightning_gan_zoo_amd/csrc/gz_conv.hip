@@ -321,6 +321,31 @@ static int dispatch_fwd(const float* x, const float* wp, const float* bias, floa
 }
 
 // ---------------------------------------------------------------------------
+// F with run-time geometry (evaluation path: InceptionV3).  Always tap-major, channels padded to a chunk.
+// ---------------------------------------------------------------------------
+struct AnyGeom {
+    int KH, KW, SH, SW, PH, PW;
+};
+
+template <class Cfg>
+static int run_fwd_any(const float* x, const float* wp, const float* bias, float* y, const ConvShape& s,
+                       const AnyGeom& g, int act, float slope, hipStream_t st, int splits, float* slab) {
+    using AL = ConvFwdALoaderTapAny<Cfg::BM>;
+    using BL = MContigLoader4<Cfg::BN>;
+    typename AL::Params pa{x, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW), g.KH, g.KW, g.SH, g.SW, g.PH, g.PW};
+    int M = s.N * s.OH * s.OW;
+    EpiNCHW::Params pe{y, M, s.K, s.OH * s.OW, make_fastdiv(s.OH * s.OW), bias, act, slope};
+    int Kt = g.KH * g.KW * round_bk(s.C);
+    typename BL::Params pb{wp, Kt, round4(s.K), round4(s.K), 0};
+    return launch_igemm<Cfg, AL, BL, EpiNCHW>(pa, pb, pe, M, s.K, Kt, 1, splits, st, slab);
+}
+
+static SplitPlan fwd_any_plan(const ConvShape& s, const AnyGeom& g) {
+    long long M = (long long)s.N * s.OH * s.OW;
+    return plan_split(M, s.K, g.KH * g.KW * round_bk(s.C), 1, pick_tile(M, s.K, 1));
+}
+
+// ---------------------------------------------------------------------------
 // Dg with <= 4 image channels (the generator's output layer, 128 -> 3 @ 32 -> 64, and the
 // discriminator's input gradient in the gradient penalty): an MFMA tile would waste 29 of 32
 // columns, and the layer is HBM-bound anyway (reads 268 MB, 6.4 GFLOP at bs 512).  Direct VALU
@@ -1178,6 +1203,57 @@ int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* dbias, flo
 #define CALL(G) dispatch_wgrad<G>(x, y, dw, workspace, ws_bytes, s, stream)
     GZ_GEOM_DISPATCH(CALL)
 #undef CALL
+}
+
+long long gz_conv2d_pack_fwd_any_elems(int K, int C, int KH, int KW) {
+    return (long long)round_bk(C) * KH * KW * round4(K);
+}
+
+int gz_conv2d_pack_fwd_any(const float* w, float* wp, int K, int C, int KH, int KW, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (K <= 0 || C <= 0 || KH <= 0 || KW <= 0) return GZ_ERR_BAD_SHAPE;
+    const int ld = round4(K);
+    long long total = (long long)KH * KW * round_bk(C) * ld;
+    hipLaunchKernelGGL(pack_fwd_tap_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)),
+                       dim3(256), 0, stream, w, wp, K, C, KH * KW, round_bk(C), ld);
+    return launch_status();
+}
+
+static bool any_shape_ok(const ConvShape& s, const AnyGeom& g) {
+    if (s.N <= 0 || s.C <= 0 || s.K <= 0 || s.H <= 0 || s.W <= 0 || g.KH <= 0 || g.KW <= 0 || g.SH <= 0 || g.SW <= 0 ||
+        g.PH < 0 || g.PW < 0)
+        return false;
+    return s.OH == (s.H + 2 * g.PH - g.KH) / g.SH + 1 && s.OW == (s.W + 2 * g.PW - g.KW) / g.SW + 1 && s.OH > 0 &&
+           s.OW > 0;
+}
+
+size_t gz_conv2d_fwd_any_workspace_bytes(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int SH,
+                                         int SW, int PH, int PW) {
+    ConvShape s{N, C, H, W, K, OH, OW};
+    AnyGeom g{KH, KW, SH, SW, PH, PW};
+    if (!any_shape_ok(s, g)) return 0;
+    return split_bytes(fwd_any_plan(s, g), (long long)N * OH * OW, K, KH * KW * round_bk(C), 1);
+}
+
+int gz_conv2d_fwd_any(const float* x, const float* wpack, const float* bias, float* y, float* workspace,
+                      size_t ws_bytes, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int SH, int SW,
+                      int PH, int PW, int act, float slope, hipStream_t stream) {
+    gz::clear_stale_error();
+    ConvShape s{N, C, H, W, K, OH, OW};
+    AnyGeom g{KH, KW, SH, SW, PH, PW};
+    if (!any_shape_ok(s, g)) return GZ_ERR_BAD_SHAPE;
+    if ((long long)N * C * H * W * 4 >= (1ll << 31) || (long long)N * K * OH * OW * 4 >= (1ll << 31)) return GZ_ERR_TOO_LARGE;
+    long long M = (long long)N * OH * OW;
+    SplitPlan sp = fwd_any_plan(s, g);
+    if (sp.splits > 1 && (!workspace || ws_bytes < split_bytes(sp, M, K, KH * KW * round_bk(C), 1)))
+        sp = SplitPlan{pick_tile(M, K, 1), 1};
+    float* slab = sp.splits > 1 ? workspace : nullptr;
+    switch (sp.tile) {
+        case T128x128: return run_fwd_any<Cfg128x128>(x, wpack, bias, y, s, g, act, slope, stream, sp.splits, slab);
+        case T128x64: return run_fwd_any<Cfg128x64>(x, wpack, bias, y, s, g, act, slope, stream, sp.splits, slab);
+        case T128x32: return run_fwd_any<Cfg128x32>(x, wpack, bias, y, s, g, act, slope, stream, sp.splits, slab);
+        default: return run_fwd_any<Cfg64x64>(x, wpack, bias, y, s, g, act, slope, stream, sp.splits, slab);
+    }
 }
 
 /* which tile configuration a launch of op (0 F, 1 Dg, 2 Wg) would use: 0 128x128, 1 128x64, 2 128x32, 3 64x64 */

@@ -422,6 +422,79 @@ struct ConvFwdALoaderTap {
     }
 };
 
+// The same tap-major forward loader with the geometry as run-time values (rectangular kernels, per-axis stride and
+// padding): the evaluation path's InceptionV3 has 3x3 s2 p0, 5x5 s1 p2, 1x7 / 7x1, 1x3 / 3x1 ... layers, none of
+// which is worth a template instantiation of its own (forward only, no training step runs through them).
+template <int BM>
+struct ConvFwdALoaderTapAny {
+    struct Params {
+        const float* x;
+        ConvShape s;
+        FastDiv div_ohw, div_ow;
+        int KH, KW, SH, SW, PH, PW;
+    };
+    static constexpr int LD = BM;
+    static constexpr int EPT = BM * BK / NT;
+    static constexpr int STEP = NT / BM;
+    static constexpr bool DMA = GZ_IGEMM_DMA;
+    static constexpr int NPARTS = 0;
+    __device__ __forceinline__ void issue_lds_part(int, float*, int) {}
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[EPT];
+    int kb, m_l, iy0, ix0, C, H, W, cblocks, KW;
+    bool m_ok;
+    float r[DMA ? 1 : EPT];
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        const ConvShape& s = p.s;
+        const uint32_t shift = (uint32_t)(p.PH * s.W + p.PW) * 4u;
+        rsrc = make_rsrc(reinterpret_cast<const char*>(p.x) - shift, (uint32_t)s.N * s.C * s.H * s.W * 4u + shift);
+        m_l = tid % BM;
+        kb = tid / BM;
+        uint32_t m = (uint32_t)tile * BM + m_l;
+        m_ok = m < (uint32_t)s.N * s.OH * s.OW;
+        uint32_t n = fdiv(m, p.div_ohw);
+        uint32_t pix = m - n * (uint32_t)(s.OH * s.OW);
+        uint32_t oy = fdiv(pix, p.div_ow);
+        uint32_t ox = pix - oy * (uint32_t)s.OW;
+        iy0 = (int)oy * p.SH - p.PH;
+        ix0 = (int)ox * p.SW - p.PW;
+        C = s.C; H = s.H; W = s.W; KW = p.KW;
+        cblocks = round_bk(s.C) / BK;
+        const int pos = (int)(n * (uint32_t)(s.C * s.H * s.W)) + (iy0 + p.PH) * W + (ix0 + p.PW);   // >= 0 (shifted base)
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) voff[j] = (uint32_t)(pos + (kb + STEP * j) * H * W) * 4u;
+    }
+    __device__ __forceinline__ void chunk(int kc, uint32_t& soff, bool& ok, int& cb) const {
+        const int tap = kc / cblocks;
+        cb = (kc - tap * cblocks) * BK;
+        const int dy = tap / KW, dx = tap - dy * KW;
+        soff = (uint32_t)(cb * H * W + dy * W + dx) * 4u;
+        ok = m_ok && (unsigned)(iy0 + dy) < (unsigned)H && (unsigned)(ix0 + dx) < (unsigned)W;
+    }
+    __device__ __forceinline__ void issue_lds(int kc, float* dst) {
+        float* wbase = dst + (m_l - (int)(threadIdx.x & 63));
+        uint32_t soff; bool ok; int cb;
+        chunk(kc, soff, ok, cb);
+#pragma unroll
+        for (int j = 0; j < EPT; ++j)
+            bload_lds4(rsrc, wbase + (kb + STEP * j) * LD, (ok && cb + kb + STEP * j < C) ? voff[j] : OOB, soff);
+    }
+    __device__ __forceinline__ void issue(int kc) {
+        if constexpr (!DMA) {
+            uint32_t soff; bool ok; int cb;
+            chunk(kc, soff, ok, cb);
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) r[j] = bload(rsrc, (ok && cb + kb + STEP * j < C) ? voff[j] : OOB, soff);
+        }
+    }
+    __device__ __forceinline__ void commit(float* dst) const {
+        if constexpr (!DMA) {
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) dst[(kb + STEP * j) * LD + m_l] = r[j];
+        }
+    }
+};
+
 // transposed conv, phase (py, px), tap-major: A[m = (n, a, b)][k = (tap, ko)] = y[n][ko][oy0 - ty][ox0 - tx] with
 // tap = ty * nx + tx over the phase's own ny x nx taps (dg_taps); the weight rows of a phase are packed in the
 // same order (pack_dgrad_tap_kernel), so phases with fewer taps simply have fewer chunks.

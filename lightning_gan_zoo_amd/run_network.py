@@ -34,7 +34,8 @@ import torch
 from .config import ConfigError, compose_tree, locate, make_cfg, parse_value
 
 # keys of this runner, not of the reference's config (accepted with or without Hydra's "+")
-RUNNER_KEYS = {"max_steps": None, "log_every": 10, "dataset_path": None, "seed": 42, "steps_per_epoch": 100}
+RUNNER_KEYS = {"max_steps": None, "log_every": 10, "dataset_path": None, "seed": 42, "steps_per_epoch": 100,
+               "inception_weights": None}
 BUILTIN_DATASETS = ("synthetic", "image_folder", "tensor_file", "celeb_a")
 LIGHTNING_VERSION_TAG = "1.2.0"       # envelope layout written below (Lightning 1.1 / 1.2 generation)
 
@@ -444,6 +445,49 @@ def fit(module, cfg, data, run, sync=None, rank=0, world=1, evaluate=None):
     return module, trainer, step
 
 
+def make_fid_evaluator(cfg, run, module, device):
+    """The reference's InceptionMetrics callback (run_network.py:51-56, core/callback_inception_metrics.py:136-246) as
+    the ``evaluate`` hook of fit(): FID / KID of ``val.fid_n_samples`` generated images against the validation images,
+    both through the InceptionV3 pool features on the HIP kernels (inception.py).  Needs the FID weight file the
+    reference downloads (``inception_weights=<path to pt_inception-2015-12-05-6726825d.pth>``; no network here) and an
+    ImageFolder-shaped validation set; returns None otherwise, and the run keeps its latest checkpoint instead of
+    the best-FID one."""
+    node = cfg.get("dataset") or {}
+    if not (cfg.get("calc_fid", True) and run.get("inception_weights")):
+        return None
+    val_root = (node.get("val") or {}).get("root")
+    if not val_root or not str(node.get("_target_", "")).endswith("ImageFolder"):
+        return None
+    from . import eval as E
+    from .inception import InceptionFeatures, load_fid_weights
+    features = InceptionFeatures(load_fid_weights(run["inception_weights"], device))
+    n = int((cfg.get("val") or {}).get("fid_n_samples", 5000))
+    dump = E.SampleDump(module, n_samples=n, batch_size=16)          # host RNG draw, right after the module is built
+    t = cfg.train
+    cache = {}
+
+    def real_activations():
+        if "act" not in cache:          # the callback caches them too (real_inception_cache)
+            folder = ImageFolderImages(val_root, 16, t.img_size, t.channels_img, t.data_mean, t.data_std, "cpu")
+            acts, seen = [], 0
+            for imgs, _ in folder.host_batches():
+                if imgs.shape[-1] == 1:
+                    imgs = np.repeat(imgs, 3, axis=-1)
+                acts.append(features(imgs))
+                seen += len(imgs)
+                if seen >= len(folder):
+                    break
+            cache["act"] = np.concatenate(acts, axis=0)
+        return cache["act"]
+
+    def evaluate(mod, epoch):
+        m = E.evaluate(mod, dump, features, real_activations())
+        print("epoch %d FID: %.4f KID mean: %.6f KID stddev: %.6f" % (epoch, m["fid"], m["kid"], m["kid_std"]))
+        return m
+
+    return evaluate
+
+
 def main(argv=None):
     conf_dir, expt, overrides, run = parse_overrides(sys.argv[1:] if argv is None else argv)
     cfg = compose(conf_dir, expt, overrides, run)
@@ -465,8 +509,9 @@ def main(argv=None):
     if world > 1:
         from .ddp import GradSync
         sync = GradSync(module)
+    evaluate = make_fid_evaluator(cfg, run, module, device) if rank == 0 else None
     data = build_data(cfg, run, device, rank, world)
-    out = fit(module, cfg, data, run, sync=sync, rank=rank, world=world)
+    out = fit(module, cfg, data, run, sync=sync, rank=rank, world=world, evaluate=evaluate)
     if world > 1:
         torch.distributed.destroy_process_group()
     return out

@@ -1,0 +1,135 @@
+"""the FID / KID feature extractor (InceptionV3 with the FID patches) on the HIP convolution family
+against the CPU oracle (oracle/inception_cpu.py) with seeded weights, plus its three new operators against torch.
+The real weight file comes from a URL (no network here): what is pinned is the ARCHITECTURE and the arithmetic."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+TOL = 1e-3
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def seeded_state(net, seed=0):
+    """He-scaled convolution weights, BatchNorm affine / running statistics away from their defaults."""
+    g = torch.Generator().manual_seed(seed)
+    sd = net.state_dict()
+    for k, v in sd.items():
+        if k.endswith("conv.weight"):
+            fan_in = v[0].numel()
+            sd[k] = torch.randn(v.shape, generator=g) * (2.0 / fan_in) ** 0.5
+        elif k.endswith("bn.weight"):
+            sd[k] = 1 + 0.2 * (torch.rand(v.shape, generator=g) - 0.5)
+        elif k.endswith("bn.bias"):
+            sd[k] = 0.2 * (torch.rand(v.shape, generator=g) - 0.5)
+        elif k.endswith("running_mean"):
+            sd[k] = 0.2 * torch.randn(v.shape, generator=g)
+        elif k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(v.shape, generator=g)
+    return sd
+
+
+def test_state_dict_layout_is_torchvisions():
+    """The keys of the weight file the reference downloads (pytorch-fid's pt_inception-2015-12-05): torchvision's
+    inception_v3(num_classes=1008, aux_logits=False)."""
+    from lightning_gan_zoo_amd.inception import FIDInceptionV3
+    from oracle.inception_cpu import FIDInceptionV3 as Oracle
+    sd = FIDInceptionV3().state_dict()
+    assert list(sd) == list(Oracle().state_dict())
+    assert sd["Conv2d_1a_3x3.conv.weight"].shape == (32, 3, 3, 3)
+    assert sd["Mixed_5b.branch5x5_2.conv.weight"].shape == (64, 48, 5, 5)
+    assert sd["Mixed_6b.branch7x7_2.conv.weight"].shape == (128, 128, 1, 7)
+    assert sd["Mixed_6e.branch7x7dbl_4.conv.weight"].shape == (192, 192, 7, 1)
+    assert sd["Mixed_7a.branch3x3_2.conv.weight"].shape == (320, 192, 3, 3)
+    assert sd["Mixed_7c.branch3x3dbl_3b.conv.weight"].shape == (384, 384, 3, 1)
+    assert sd["Mixed_7c.branch_pool.bn.running_var"].shape == (192,)
+    assert sd["fc.weight"].shape == (1008, 2048)
+    assert sum(v.numel() for k, v in sd.items() if not k.endswith("num_batches_tracked")) == 23_885_392
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # N, C, H, W, K, KH, KW, SH, SW, PH, PW  (the layer types of InceptionV3 + ragged ones)
+    (2, 3, 75, 75, 32, 3, 3, 2, 2, 0, 0), (2, 32, 37, 37, 32, 3, 3, 1, 1, 0, 0), (2, 48, 35, 35, 64, 5, 5, 1, 1, 2, 2),
+    (2, 128, 17, 17, 128, 1, 7, 1, 1, 0, 3), (2, 160, 17, 17, 192, 7, 1, 1, 1, 3, 0),
+    (3, 384, 8, 8, 384, 1, 3, 1, 1, 0, 1), (3, 384, 8, 8, 384, 3, 1, 1, 1, 1, 0), (2, 288, 35, 35, 384, 3, 3, 2, 2, 0, 0),
+    (1, 2048, 8, 8, 320, 1, 1, 1, 1, 0, 0), (2, 20, 13, 9, 7, 2, 4, 2, 1, 1, 2), (16, 192, 17, 17, 192, 3, 3, 2, 2, 0, 0)])
+def test_conv2d_fwd_any(case):
+    from lightning_gan_zoo_amd import functional as F
+    from lightning_gan_zoo_amd._lib import check, lib
+    N, C, H, W, K, KH, KW, SH, SW, PH, PW = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, KH, KW, generator=g) * (2.0 / (C * KH * KW)) ** 0.5
+    b = torch.randn(K, generator=g)
+    ref = TF.relu(TF.conv2d(x, w, b, (SH, SW), (PH, PW)))
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    wp = torch.empty(lib.gz_conv2d_pack_fwd_any_elems(K, C, KH, KW), device="cuda")
+    check(lib.gz_conv2d_pack_fwd_any(F._p(wd), F._p(wp), K, C, KH, KW, F._stream()), "pack")
+    OH, OW = ref.shape[2:]
+    y = torch.empty(N, K, OH, OW, device="cuda")
+    nb = lib.gz_conv2d_fwd_any_workspace_bytes(N, C, H, W, K, OH, OW, KH, KW, SH, SW, PH, PW)
+    ws = torch.empty(max(nb // 4, 1), device="cuda")
+    check(lib.gz_conv2d_fwd_any(F._p(xd), F._p(wp), F._p(bd), F._p(y), F._p(ws), nb, N, C, H, W, K, OH, OW, KH, KW, SH, SW,
+                                PH, PW, F.ACT_RELU, 0.0, F._stream()), "fwd_any")
+    assert rel(y, ref) < TOL
+
+
+@pytest.mark.gpu
+def test_pool_and_resize():
+    from lightning_gan_zoo_amd import inception as I
+    x = torch.randn(3, 5, 17, 13, generator=torch.Generator().manual_seed(1))
+    xd = x.cuda()
+    assert rel(I._pool(xd, 3, 2, 0, I.MAX), TF.max_pool2d(x, 3, 2)) < 1e-6
+    assert rel(I._pool(xd, 3, 1, 1, I.MAX), TF.max_pool2d(x, 3, 1, 1)) < 1e-6
+    assert rel(I._pool(xd, 3, 1, 1, I.AVG_NOPAD), TF.avg_pool2d(x, 3, 1, 1, count_include_pad=False)) < 1e-6
+    assert rel(I._pool(xd, 3, 1, 1, I.AVG), TF.avg_pool2d(x, 3, 1, 1)) < 1e-6
+    sq = torch.randn(2, 7, 8, 8, generator=torch.Generator().manual_seed(2))
+    assert rel(I._pool(sq.cuda(), 8, 1, 0, I.AVG), TF.adaptive_avg_pool2d(sq, 1)) < 1e-6
+    from lightning_gan_zoo_amd._lib import check, lib
+    from lightning_gan_zoo_amd import functional as F
+    for (H, W, OH, OW) in ((64, 64, 299, 299), (128, 96, 299, 299), (300, 400, 299, 299), (17, 13, 17, 13)):
+        img = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(H))
+        ref = 2 * TF.interpolate(img, size=(OH, OW), mode="bilinear", align_corners=False) - 1
+        out = torch.empty(2, 3, OH, OW, device="cuda")
+        check(lib.gz_resize_bilinear(F._p(img.cuda()), F._p(out), 6, H, W, OH, OW, 2.0, -1.0, F._stream()), "resize")
+        assert rel(out, ref) < 1e-5
+
+
+@pytest.mark.gpu
+def test_inception_pool_features_match_oracle():
+    """2048-d pool features of two 64x64 and two 299x299 images, seeded weights, HIP vs CPU oracle at 1e-3."""
+    from lightning_gan_zoo_amd.inception import FIDInceptionV3, InceptionFeatures
+    from oracle.inception_cpu import FIDInceptionV3 as Oracle
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    oracle = Oracle().eval()
+    sd = seeded_state(oracle, 3)
+    oracle.load_state_dict(sd)
+    net = FIDInceptionV3()
+    net.load_state_dict(sd)                       # the same keys: how the reference's weight file would load
+    net.cuda()
+    for size in (64, 299):
+        x = torch.rand(2, 3, size, size, generator=torch.Generator().manual_seed(size))
+        with torch.no_grad():
+            ref = oracle(x)
+        out = net(x.cuda())
+        assert out.shape == (2, 2048)
+        err = rel(out, ref)
+        print(f"inception features at {size}x{size}: rel err {err:.1e}, |ref| max {float(ref.abs().max()):.2f}, "
+              f"mean {float(ref.mean()):.3f}")
+        assert err < TOL and float(ref.abs().max()) > 1e-3
+    # the evaluate() plumbing: uint8 NHWC images -> float64 activations, batches of 16
+    u8 = np.random.RandomState(0).randint(0, 256, size=(5, 32, 32, 3)).astype(np.uint8)
+    act = InceptionFeatures(net, batch_size=2)(u8)
+    with torch.no_grad():
+        ref = oracle(torch.from_numpy(u8).permute(0, 3, 1, 2).float() / 255)
+    assert act.shape == (5, 2048) and act.dtype == np.float64 and rel(torch.from_numpy(act), ref) < TOL
+    # a parameter change invalidates the folded weights
+    with torch.no_grad():
+        net.Conv2d_1a_3x3.bn.weight.mul_(1.5)
+        oracle.Conv2d_1a_3x3.bn.weight.mul_(1.5)
+        assert rel(net(x.cuda()), oracle(x)) < TOL
