@@ -74,6 +74,23 @@ class BaseGAN(LightningModule):
         real, _ = batch
         return {"real": real}
 
+    def validation_epoch_end(self, outputs):
+        """reference :64-73: the first validation batch's reals and the generator's images for the 8 ``fixed_noise``
+        latents drawn at construction, each as a normalised grid, logged as 'Real' / 'Fake' when a TensorBoard-style
+        logger is attached (``self.logger.experiment.add_image``); the two grids are also returned."""
+        from ..eval import make_grid
+        real = outputs[0]["real"][:len(self.fixed_noise)]
+        noise = self.fixed_noise.to(self.device)
+        with torch.no_grad():
+            fake = self.generator(noise)
+        img_grid_real = make_grid(real, normalize=True)
+        img_grid_fake = make_grid(fake, normalize=True)
+        experiment = getattr(getattr(self, "logger", None), "experiment", None)
+        if experiment is not None:
+            experiment.add_image("Real", img_grid_real, self.current_epoch)
+            experiment.add_image("Fake", img_grid_fake, self.current_epoch)
+        return img_grid_real, img_grid_fake
+
     def configure_optimizers(self):
         # the reference's nodes target torch.optim.Adam / RMSprop (conf/expt/*.yaml); on the GPU they are
         # served by the fused HIP implementations with the same arguments and state layout

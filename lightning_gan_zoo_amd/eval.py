@@ -40,6 +40,38 @@ class SampleDump:
             module.train(was_training)
 
 
+def make_grid(images, nrow=8, padding=2, normalize=False, pad_value=0.0):
+    """torchvision.utils.make_grid for a [N, C, H, W] tensor (the subset the reference uses,
+    core/lightning_module.py:68-69: ``normalize=True``, defaults otherwise): with ``normalize`` the WHOLE tensor is
+    shifted / scaled to [0, 1] by its own min / max (``scale_each=False``, the 1e-5 guard of torchvision's
+    ``norm_ip``); images are laid out ``nrow`` per row with ``padding`` pixels of ``pad_value`` around each;
+    single-channel input is repeated to three channels."""
+    t = images.detach()
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    if t.shape[1] == 1:
+        t = torch.cat((t, t, t), 1)
+    if normalize:
+        t = t.clone()
+        lo, hi = float(t.min()), float(t.max())
+        t = t.clamp(min=lo, max=hi).sub(lo).div(max(hi - lo, 1e-5))
+    n = t.shape[0]
+    if n == 1:
+        return t.squeeze(0)
+    xmaps = min(nrow, n)
+    ymaps = int(np.ceil(float(n) / xmaps))
+    height, width = int(t.shape[2] + padding), int(t.shape[3] + padding)
+    grid = t.new_full((t.shape[1], height * ymaps + padding, width * xmaps + padding), pad_value)
+    k = 0
+    for y in range(ymaps):
+        for x in range(xmaps):
+            if k >= n:
+                break
+            grid[:, y * height + padding:(y + 1) * height, x * width + padding:(x + 1) * width] = t[k]
+            k += 1
+    return grid
+
+
 def activation_statistics(act):
     act = np.asarray(act)
     return np.mean(act, axis=0), np.cov(act, rowvar=False)
