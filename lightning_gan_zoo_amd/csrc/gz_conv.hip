@@ -609,6 +609,13 @@ static int run_dgrad(const float* y, const float* wp, const float* bias, float* 
             pc[ph] = (s.K * dg_taps(G::kh, G::s, G::p, ph / G::s) * dg_taps(G::kw, G::s, G::p, ph % G::s) + BK - 1) / BK;
         return launch_igemm<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kg, G::s * G::s, splits, st, slab, pc);
     }
+    if constexpr (G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1) {
+        static const bool no_row4 = getenv("GZ_NO_ROW4") != nullptr;          // experiment: the per-element loader
+        if (!no_row4 && AW % 4 == 0 && (((uintptr_t)y) & 15) == 0) {
+            using AR = ConvDgALoaderRow4<Cfg::BM, 4, 4, 2, 1>;
+            return launch_igemm<Cfg, AR, BL, Epi>(pa, pb, pe, M, s.C, Kg, G::s * G::s, splits, st, slab);
+        }
+    }
     return launch_igemm<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kg, G::s * G::s, splits, st, slab);
 }
 

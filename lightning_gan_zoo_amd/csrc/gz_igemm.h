@@ -28,6 +28,7 @@
 //   void store(const Params&, acc, m_base, n_base, lane, y, z);
 #pragma once
 #include "gz_common.h"
+#include <type_traits>
 
 namespace gz {
 
@@ -758,6 +759,64 @@ struct ConvDgALoader {
             for (int j = 0; j < EPT; ++j) dst[(kb + STEP * j) * LD + m_l] = r[j];
         }
     }
+};
+
+// Row-shared A loader for the k4 s2 p1 transposed convolution (round 2).  In ConvDgALoader the two horizontal taps of
+// a (feature channel, vertical tap) pair are two LDS rows holding the same feature row, one of them shifted by a
+// column, and every element arrives by its own 4-byte LDS-DMA (8 per lane and chunk: executing them cost ~8 % of
+// the kernel).  Here a chunk's A image is 8 rows = 4 feature channels x 2 vertical taps of UNSHIFTED feature rows,
+// landed by ONE 16-byte LDS-DMA per lane (1 KiB per wavefront, 4 aligned pixels per lane), and the horizontal tap is
+// applied when the MFMA fragment is read: k-step s reads row s, its first half-wave (tx = 0) and second half-wave
+// (tx = 1) at column offsets (px + P) / S - tx, i.e. {0, -1} or {+1, 0}.  The one column that a shifted read takes
+// from the neighbouring image row (b = 0 for -1, b = AW - 1 for +1) is zeroed in the register (a lane's b is fixed).
+// Half the LDS-DMA bytes, an eighth of the instructions.  Needs AW % 4 == 0 and a 16-byte aligned tensor.
+template <int BM, int KH, int KW, int S, int P>
+struct ConvDgALoaderRow4 {
+    static_assert(KH == 4 && KW == 4 && S == 2 && P == 1, "k4 s2 p1 only");
+    static constexpr int TAPS = 4;
+    static constexpr bool UNIFORM = true, FIXED = true;
+    using Params = typename ConvDgALoader<BM, KH, KW, S, P>::Params;
+    static constexpr int LD = BM;
+    static constexpr bool DMA = true;
+    static constexpr bool ROWSHARE = true;
+    static constexpr int NPARTS = 0;
+    static constexpr int ROWS = BK / 2;                    // LDS rows per chunk
+    static constexpr int LANES = ROWS * BM / 4;            // lanes that load (256 for BM = 128, 128 for BM = 64)
+    __device__ __forceinline__ void issue_lds_part(int, float*, int) {}
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff;
+    int kol, K, OHW, tid_, shift_half1;
+    __device__ __forceinline__ void init(const Params& p, int tile, int phase, int tid) {
+        const ConvShape& s = p.s;
+        rsrc = make_rsrc(p.y, (uint32_t)s.N * s.K * s.OH * s.OW * 4u);
+        tid_ = tid;
+        K = s.K; OHW = s.OH * s.OW;
+        const int py = phase / S, px = phase % S;
+        shift_half1 = (px + P) / S - 1;                    // tx = 1; tx = 0 reads at (px + P) / S
+        const int r = tid / (BM / 4), c4 = tid % (BM / 4);
+        kol = r >> 1;
+        const int ty = r & 1;
+        uint32_t m = (uint32_t)tile * BM + c4 * 4;
+        const bool m_ok = tid < LANES && m < (uint32_t)s.N * p.AH * p.AW;
+        uint32_t n = fdiv(m, p.div_ahw);
+        uint32_t pix = m - n * (uint32_t)(p.AH * p.AW);
+        uint32_t a = fdiv(pix, p.div_aw);
+        uint32_t b = pix - a * (uint32_t)p.AW;
+        const int oy = (int)a + (py + P) / S - ty;
+        const bool ok = m_ok && (unsigned)oy < (unsigned)s.OH;
+        voff = ok ? (n * (uint32_t)(s.K * OHW) + (uint32_t)((kol * s.OH + oy) * s.OW) + b) * 4u : OOB;
+    }
+    // column offset the fragment reads of half-wave `half` apply, and whether lane-column b must be zeroed
+    __device__ __forceinline__ int frag_shift(int half) const { return half ? shift_half1 : shift_half1 + 1; }
+    __device__ __forceinline__ void issue_lds(int kc, float* dst) {
+        if (tid_ < LANES) {        // wave-uniform: LANES is a multiple of 64
+            const uint32_t soff = (uint32_t)kc * (uint32_t)((BK / TAPS) * OHW) * 4u;
+            const uint32_t v = kc * (BK / TAPS) + kol < K ? voff : OOB;
+            bload_lds16(rsrc, dst + (tid_ & ~63) * 4, v, soff);
+        }
+    }
+    __device__ __forceinline__ void issue(int) {}
+    __device__ __forceinline__ void commit(float*) const {}
 };
 
 // Weight gradient: dW[ko][(c, ky, kx)] = sum_{p = (n, oy, ox)} y[n][ko][oy][ox] * x[n][c][oy*S-P+ky][ox*S-P+kx]
@@ -1500,14 +1559,22 @@ __device__ __forceinline__ void store_slab(const GridMap& gm, f32x16 (&acc)[TM][
 #define GZ_IGEMM_WAVES_PER_SIMD 4
 #endif
 
+template <class T, class = void>
+struct is_rowshare : std::false_type {};
+template <class T>
+struct is_rowshare<T, std::void_t<decltype(T::ROWSHARE)>> : std::true_type {};
+
 template <class Cfg, class AL, class BL, class Epi>
 __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(typename AL::Params pa, typename BL::Params pb,
                                                    typename Epi::Params pe, GridMap gm) {
     constexpr int LDA = AL::LD, LDB = BL::LD;
     constexpr int TM = Cfg::TM, TN = Cfg::TN;
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
-    float* As = smem;
-    float* Bs = smem + 2 * BK * LDA;
+    // row-shared A images are read one column to the left / right of the tile: keep them behind the B images so that
+    // such a (masked) read stays inside this workgroup's allocation
+    constexpr bool RS0 = is_rowshare<AL>::value;
+    float* As = RS0 ? smem + 2 * BK * LDB : smem;
+    float* Bs = RS0 ? smem : smem + 2 * BK * LDA;
 
     const int tid = threadIdx.x;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
@@ -1555,7 +1622,19 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
     const int half = lane >> 5, l32 = lane & 31;
-    const int a_rd = half * LDA + wm * TM * 32 + l32;
+    constexpr bool RS = is_rowshare<AL>::value;       // ConvDgALoaderRow4: one LDS row per k-step, taps applied on read
+    int a_rd = half * LDA + wm * TM * 32 + l32;
+    constexpr int A_STEP = RS ? LDA : 2 * LDA;
+    bool a_zero[TM];
+    if constexpr (RS) {
+        const int sh = al.frag_shift(half);
+        a_rd = wm * TM * 32 + l32 + sh;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int b = (tile_m * Cfg::BM + wm * TM * 32 + i * 32 + l32) % pa.AW;      // m = (n * AH + a) * AW + b
+            a_zero[i] = (sh < 0 && b == 0) || (sh > 0 && b == pa.AW - 1);
+        }
+    }
     const int b_rd = half * LDB + wn * TN * 32 + l32;
 
     if (kc0 < kc1) {
@@ -1589,7 +1668,10 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
         // the LDS latency
         float af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][i] = Ar[i * 32];
+        for (int i = 0; i < TM; ++i) {
+            af[0][i] = Ar[i * 32];
+            if constexpr (RS) af[0][i] = a_zero[i] ? 0.f : af[0][i];
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[0][j] = Br[j * 32];
 #pragma unroll
@@ -1597,7 +1679,10 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
             const int c = s & 1, n = c ^ 1;
             if (s + 1 < BK / 2) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[n][i] = Ar[2 * (s + 1) * LDA + i * 32];
+                for (int i = 0; i < TM; ++i) {
+                    af[n][i] = Ar[(s + 1) * A_STEP + i * 32];
+                    if constexpr (RS) af[n][i] = a_zero[i] ? 0.f : af[n][i];
+                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[n][j] = Br[2 * (s + 1) * LDB + j * 32];
             }
