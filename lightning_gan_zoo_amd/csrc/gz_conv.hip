@@ -286,6 +286,17 @@ static int run_fwd(const float* x, const float* wp, const float* bias, float* y,
     }
     int Kg = s.C * G::kh * G::kw;
     typename BL::Params pb{wp, Kg, round4(s.K), round4(s.K), 0};
+    if constexpr (G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1) {
+        static const bool no_row4 = getenv("GZ_NO_ROW4") != nullptr;          // experiment: the K4V loader
+        // OW >= 16 only: with shorter rows the stride-2 fragment reads of the lanes of a half-wave fall on 2*OW / 2
+        // banks (OW = 4: an 8-way conflict; measured 113 -> 108 TFLOP/s on D.block3, 122 -> 117 on G.block2's
+        // backward), where K4V's im2col image stays conflict-free; at OW = 16 / 32 it is +5 % (D.block1) or neutral
+        if (!no_row4 && s.W == 2 * s.OW && s.H == 2 * s.OH && s.OW >= 16 && s.OW <= Cfg::BM && Cfg::BM % s.OW == 0 &&
+            (((uintptr_t)x) & 15) == 0) {
+            using AR = ConvFwdALoaderRow4<Cfg::BM>;
+            return launch_igemm<Cfg, AR, BL, EpiNCHW>(pa, pb, pe, M, s.K, Kg, 1, splits, st, slab);
+        }
+    }
     return launch_igemm<Cfg, AL, BL, EpiNCHW>(pa, pb, pe, M, s.K, Kg, 1, splits, st, slab);
 }
 

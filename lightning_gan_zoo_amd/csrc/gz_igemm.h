@@ -644,6 +644,59 @@ struct ConvFwdALoaderK4V {
     }
 };
 
+// Row-shared A loader for the k4 s2 p1 FORWARD convolution (round 2; the transposed one is ConvDgALoaderRow4).  The
+// im2col image of one input channel is 16 taps x BM pixels = 16*BM floats, of which each input value appears four
+// times; K4V gathers it with two 16-byte loads per lane and commits it with EIGHT ds_write_b32.  Here a chunk's LDS
+// image is the raw input rows the tile touches -- per output-row segment of OW pixels its four input rows of 2*OW
+// columns: 8*BM floats, one 16-byte LDS-DMA per lane, no VGPR staging, no ds_write -- and the taps are applied when
+// the MFMA fragment is read: lane (segment, ox), k = (ky, kx) reads  image[(seg*4 + ky) * 2*OW + 2*ox + kx - 1]
+// (stride-2 across lanes: a 2-way bank conflict on 2 of the 4 fragment reads per 4 MFMAs -- free).  The column left
+// of the image (ox = 0, kx = 0) and right of it (ox = OW-1, kx = 3) are zeroed in the register; rows above / below
+// are dropped by the descriptor's range check.  Needs W = 2*OW, H = 2*OH, OW <= BM, BM % OW == 0, 16-byte alignment.
+template <int BM>
+struct ConvFwdALoaderRow4 {
+    using Params = typename ConvFwdALoader<BM, 4, 4, 2, 1>::Params;
+    static constexpr int LD = BM;
+    static constexpr bool DMA = true;
+    static constexpr bool FWDROWS = true;
+    static constexpr int NPARTS = 0;
+    static constexpr int LANES = 2 * BM;                   // 8*BM floats / 4 per lane
+    __device__ __forceinline__ void issue_lds_part(int, float*, int) {}
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff;
+    int tid_, HW, OW, twoOW;
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        const ConvShape& s = p.s;
+        rsrc = make_rsrc(p.x, (uint32_t)(s.N * s.C * s.H * s.W) * 4u);
+        tid_ = tid;
+        HW = s.H * s.W; OW = s.OW; twoOW = 2 * s.OW;
+        const int f = tid * 4;
+        const int seg = f / (8 * OW), rem = f - seg * 8 * OW;
+        const int ky = rem / twoOW, col = rem - ky * twoOW;
+        const uint32_t m = (uint32_t)tile * BM + seg * OW;           // first pixel of the segment
+        const bool m_ok = tid < LANES && m < (uint32_t)s.N * s.OH * s.OW;
+        const uint32_t n = fdiv(m, p.div_ohw);
+        const uint32_t oy = fdiv(m - n * (uint32_t)(s.OH * s.OW), p.div_ow);
+        const int iy = (int)oy * 2 - 1 + ky;
+        const bool ok = m_ok && (unsigned)iy < (unsigned)s.H;
+        voff = ok ? (n * (uint32_t)(s.C * HW) + (uint32_t)(iy * s.W + col)) * 4u : OOB;
+    }
+    // fragment addressing of the lane that owns tile pixel m_local, half-wave `half` (k = 2s + half):
+    //   address(s) = base + (s >> 1) * 2*OW + 2 * (s & 1);  zero the value on even s if z_even, on odd s if z_odd
+    __device__ __forceinline__ void frag(int m_local, int half, int& base, bool& z_even, bool& z_odd) const {
+        const int seg = m_local / OW, ox = m_local - seg * OW;
+        base = seg * 8 * OW + 2 * ox - 1 + half;
+        z_even = half == 0 && ox == 0;              // kx = 0
+        z_odd = half == 1 && ox == OW - 1;          // kx = 3
+    }
+    __device__ __forceinline__ void issue_lds(int kc, float* dst) {
+        if (tid_ < LANES)          // wave-uniform
+            bload_lds16(rsrc, dst + (tid_ & ~63) * 4, voff, (uint32_t)kc * (uint32_t)HW * 4u);
+    }
+    __device__ __forceinline__ void issue(int) {}
+    __device__ __forceinline__ void commit(float*) const {}
+};
+
 // Transposed convolution / data gradient, decomposed into S*S output phases.
 // Phase (py, px) produces x[n][c][S*a+py][S*b+px]; along each axis it uses the taps
 //   t = 0..T-1 :  ky = ((py + P) % S) + S*t ,  oy = a + (py + P)/S - t
@@ -1560,6 +1613,10 @@ __device__ __forceinline__ void store_slab(const GridMap& gm, f32x16 (&acc)[TM][
 #endif
 
 template <class T, class = void>
+struct is_fwdrows : std::false_type {};
+template <class T>
+struct is_fwdrows<T, std::void_t<decltype(T::FWDROWS)>> : std::true_type {};
+template <class T, class = void>
 struct is_rowshare : std::false_type {};
 template <class T>
 struct is_rowshare<T, std::void_t<decltype(T::ROWSHARE)>> : std::true_type {};
@@ -1572,7 +1629,7 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
     // row-shared A images are read one column to the left / right of the tile: keep them behind the B images so that
     // such a (masked) read stays inside this workgroup's allocation
-    constexpr bool RS0 = is_rowshare<AL>::value;
+    constexpr bool RS0 = is_rowshare<AL>::value || is_fwdrows<AL>::value;
     float* As = RS0 ? smem + 2 * BK * LDB : smem;
     float* Bs = RS0 ? smem : smem + 2 * BK * LDA;
 
@@ -1635,6 +1692,15 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
             a_zero[i] = (sh < 0 && b == 0) || (sh > 0 && b == pa.AW - 1);
         }
     }
+    constexpr bool FR = is_fwdrows<AL>::value;        // ConvFwdALoaderRow4: raw input rows, taps applied on read
+    int fr_base[TM];
+    bool fr_ze[TM], fr_zo[TM];
+    int fr_2ow = 0;
+    if constexpr (FR) {
+        fr_2ow = al.twoOW;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) al.frag(wm * TM * 32 + i * 32 + l32, half, fr_base[i], fr_ze[i], fr_zo[i]);
+    }
     const int b_rd = half * LDB + wn * TN * 32 + l32;
 
     if (kc0 < kc1) {
@@ -1669,8 +1735,13 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
         float af[2][TM], bf[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            af[0][i] = Ar[i * 32];
-            if constexpr (RS) af[0][i] = a_zero[i] ? 0.f : af[0][i];
+            if constexpr (FR) {
+                const float v = (As + cur * BK * LDA)[fr_base[i]];
+                af[0][i] = fr_ze[i] ? 0.f : v;
+            } else {
+                af[0][i] = Ar[i * 32];
+                if constexpr (RS) af[0][i] = a_zero[i] ? 0.f : af[0][i];
+            }
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[0][j] = Br[j * 32];
@@ -1680,8 +1751,13 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
             if (s + 1 < BK / 2) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    af[n][i] = Ar[(s + 1) * A_STEP + i * 32];
-                    if constexpr (RS) af[n][i] = a_zero[i] ? 0.f : af[n][i];
+                    if constexpr (FR) {
+                        const float v = (As + cur * BK * LDA)[fr_base[i] + ((s + 1) >> 1) * fr_2ow + 2 * ((s + 1) & 1)];
+                        af[n][i] = (((s + 1) & 1) ? fr_zo[i] : fr_ze[i]) ? 0.f : v;
+                    } else {
+                        af[n][i] = Ar[(s + 1) * A_STEP + i * 32];
+                        if constexpr (RS) af[n][i] = a_zero[i] ? 0.f : af[n][i];
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[n][j] = Br[2 * (s + 1) * LDB + j * 32];
