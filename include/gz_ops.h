@@ -78,6 +78,19 @@ int gz_conv2d_wgrad_fuses_bias(int N, int C, int H, int W, int K, int OH, int OW
 int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* dbias, float* workspace, size_t ws_bytes, int N,
                     int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream);
 
+/* Convolution + BatchNorm statistics in one launch (standard_networks.py:34-44,80-88: conv / transpose_conv ->
+ * batch_norm): the epilogue also writes, per output channel and per group of pixels, (sum, sum of squares) of the
+ * raw convolution output to stats[rows][channels][2]; gz_batchnorm_finalize turns them into the coefficients and
+ * the running buffers -- the separate read of the whole feature map goes away.  *_stats_rows = number of partial
+ * rows the launch produces, 0 when it cannot fuse (split-K launch, 3-channel direct kernel): use the plain entry
+ * point + gz_batchnorm_stats then.  No bias, no activation (the activation follows the normalisation). */
+int gz_conv2d_fwd_stats_rows(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P);
+int gz_conv2d_fwd_stats(const float* x, const float* wpack, float* y, float* stats, int N, int C, int H, int W, int K,
+                        int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream);
+int gz_conv2d_dgrad_stats_rows(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P);
+int gz_conv2d_dgrad_stats(const float* y, const float* wpack, float* x, float* stats, int N, int C, int H, int W, int K,
+                          int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream);
+
 /* diagnostic: tile configuration a launch would use (op 0 F, 1 Dg, 2 Wg) -> 0 128x128, 1 128x64, 2 128x32, 3 64x64 */
 int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S);
 
@@ -174,6 +187,10 @@ int gz_norm_coef_elems(int N, int C, int per_channel);
 /* training-mode BatchNorm2d statistics (biased var for normalisation; running stats updated with the
  * unbiased var and `momentum`; *num_batches_tracked += 1).  Replaces the statistics half of
  * aten::native_batch_norm for nn.BatchNorm2d (standard_networks.py:44,87). */
+/* the same from per-tile partials [rows][C][2] written by gz_conv2d_*_stats; count = elements per channel (N*H*W) */
+int gz_batchnorm_finalize(const float* partials, int rows, long long count, const float* gamma, const float* beta,
+                          float* coef, float* running_mean, float* running_var, long long* num_batches_tracked, int C,
+                          float eps, float momentum, hipStream_t stream);
 int gz_batchnorm_stats(const float* x, const float* gamma, const float* beta, float* coef, float* running_mean,
                        float* running_var, long long* num_batches_tracked, void* workspace, int N, int C,
                        int inner, float eps, float momentum, hipStream_t stream);

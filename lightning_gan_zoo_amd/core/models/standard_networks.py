@@ -33,16 +33,21 @@ class _GBlock(nn.Module):
 
     def forward(self, x):
         w = self.transpose_conv.weight
+        bn = self.batch_norm
+        training = bn.training or bn.running_mean is None
+        stats = None
         if self.stride == 1 and self.padding == 0 and x.shape[2] == 1 and x.shape[3] == 1:
             n = x.shape[0]
             y = F.matmul(x.reshape(n, -1), w.view(w.shape[0], -1)).view(n, w.shape[1], 4, 4)
         elif self.stride == 2 and self.padding == 1:
-            y = F.conv_transpose2d(x, w, None, F.K4S2P1)
+            if training:        # the transposed convolution's epilogue also emits the BatchNorm partial sums
+                y, stats = F.conv_transpose2d_with_stats(x, w, F.K4S2P1)
+            else:
+                y = F.conv_transpose2d(x, w, None, F.K4S2P1)
         else:
             raise RuntimeError("unsupported transposed-convolution geometry on the HIP path")
-        bn = self.batch_norm
         return F.batch_norm_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                bn.training or bn.running_mean is None, bn.momentum, bn.eps, F.ACT_RELU, 0.0)
+                                training, bn.momentum, bn.eps, F.ACT_RELU, 0.0, stats)
 
 
 class _DBlock(nn.Module):
@@ -63,10 +68,14 @@ class _DBlock(nn.Module):
     def forward(self, x):
         slope = self.leaky_relu.negative_slope
         if self.norm == "batch_norm":
-            y = F.conv2d(x, self.conv.weight, None, F.K4S2P1)
             bn = self.batch_norm
+            stats = None
+            if bn.training:     # statistics from the convolution's own epilogue
+                y, stats = F.conv2d_with_stats(x, self.conv.weight, F.K4S2P1)
+            else:
+                y = F.conv2d(x, self.conv.weight, None, F.K4S2P1)
             return F.batch_norm_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                    bn.num_batches_tracked, bn.training, bn.momentum, bn.eps, F.ACT_LRELU, slope)
+                                    bn.num_batches_tracked, bn.training, bn.momentum, bn.eps, F.ACT_LRELU, slope, stats)
         if self.norm == "instance_norm2d":
             y = F.conv2d(x, self.conv.weight, None, F.K4S2P1)
             inn = self.instance_norm2d

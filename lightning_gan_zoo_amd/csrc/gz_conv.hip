@@ -265,7 +265,7 @@ static bool too_large(long long elems) { return elems * 4 >= (1ll << 31); }
 // ---------------------------------------------------------------------------
 template <class G, class Cfg>
 static int run_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvShape& s, int act,
-                   float slope, hipStream_t st, int splits = 1, float* slab = nullptr) {
+                   float slope, hipStream_t st, int splits = 1, float* slab = nullptr, float* stats = nullptr) {
 #ifndef GZ_NO_K4V
     using AL = std::conditional_t<G::kh == 4 && G::kw == 4, ConvFwdALoaderK4V<Cfg::BM, G::s, G::p>,
                                   ConvFwdALoader<Cfg::BM, G::kh, G::kw, G::s, G::p>>;
@@ -275,7 +275,8 @@ static int run_fwd(const float* x, const float* wp, const float* bias, float* y,
     using BL = MContigLoader4<Cfg::BN>;
     typename AL::Params pa{x, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW)};
     int M = s.N * s.OH * s.OW;
-    EpiNCHW::Params pe{y, M, s.K, s.OH * s.OW, make_fastdiv(s.OH * s.OW), bias, act, slope};
+    EpiNCHW::Params pe{y, M, s.K, s.OH * s.OW, make_fastdiv(s.OH * s.OW), bias, act, slope,
+                       reinterpret_cast<f32x2*>(stats)};
     if constexpr (BK % (G::kh * G::kw) != 0) {
         if (fwd_tap_major(s.C, G::kh, G::kw)) {
             using ALT = ConvFwdALoaderTap<Cfg::BM, G::kh, G::kw, G::s, G::p>;
@@ -589,7 +590,7 @@ static int run_dgrad_smallc(const float* y, const float* wp, const float* bias, 
 // ---------------------------------------------------------------------------
 template <class G, class Cfg>
 static int run_dgrad(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s, int act,
-                     float slope, hipStream_t st, int splits = 1, float* slab = nullptr) {
+                     float slope, hipStream_t st, int splits = 1, float* slab = nullptr, float* stats = nullptr) {
     using AL = ConvDgALoader<Cfg::BM, G::kh, G::kw, G::s, G::p>;
     using BL = MContigLoader4<Cfg::BN>;
     using Epi = EpiPhase<G::s>;
@@ -599,7 +600,8 @@ static int run_dgrad(const float* y, const float* wp, const float* bias, float* 
     int ldc = round4(s.C);
     typename BL::Params pb{wp, Kg, ldc, ldc, (long long)Kg * ldc};
     int M = s.N * AH * AW;
-    typename Epi::Params pe{x, M, s.C, s.H, s.W, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW), bias, act, slope};
+    typename Epi::Params pe{x, M, s.C, s.H, s.W, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW), bias, act, slope,
+                            reinterpret_cast<f32x2*>(stats), ((M + Cfg::BM - 1) / Cfg::BM) * Cfg::WM};
     if constexpr (!AL::FIXED) {
         if (dgrad_tap_major(s.K, G::kh, G::kw, G::s)) {
             using ALT = ConvDgALoaderTap<Cfg::BM, G::kh, G::kw, G::s, G::p>;
@@ -1219,6 +1221,73 @@ int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* dbias, flo
     if (wgrad_smallch_ok(s, KH, KW, S, P)) return run_wgrad_smallch(x, y, dw, dbias, workspace, ws_bytes, s, stream);
     if (dbias) return GZ_ERR_UNSUPPORTED;       // ask gz_conv2d_wgrad_fuses_bias first
 #define CALL(G) dispatch_wgrad<G>(x, y, dw, workspace, ws_bytes, s, stream)
+    GZ_GEOM_DISPATCH(CALL)
+#undef CALL
+}
+
+// ---- convolution + BatchNorm statistics in one launch --------------------------------------------------------
+static int stats_wm(TileId t) { return t == T128x32 ? 4 : 2; }
+static int stats_tm_rows(TileId t, long long M) {       // partial rows per phase: tiles_m * WM
+    const int bm = t == T64x64 ? 64 : 128;
+    return (int)((M + bm - 1) / bm) * stats_wm(t);
+}
+
+int gz_conv2d_fwd_stats_rows(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P) {
+    ConvShape s{N, C, H, W, K, OH, OW};
+    if (!shape_ok(s, KH, KW, S, P)) return 0;
+#define CALL(G) fwd_plan<G>(s)
+    SplitPlan sp = [&]() -> SplitPlan { GZ_GEOM_DISPATCH_OR(CALL, (SplitPlan{T64x64, 2})) }();
+#undef CALL
+    if (sp.splits > 1) return 0;              // split-K launches finish in another kernel: not fused
+    return stats_tm_rows(sp.tile, (long long)N * OH * OW);
+}
+
+int gz_conv2d_fwd_stats(const float* x, const float* wpack, float* y, float* stats, int N, int C, int H, int W, int K,
+                        int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream) {
+    gz::clear_stale_error();
+    ConvShape s{N, C, H, W, K, OH, OW};
+    if (!shape_ok(s, KH, KW, S, P) || !stats) return GZ_ERR_BAD_SHAPE;
+    if (gz_conv2d_fwd_stats_rows(N, C, H, W, K, OH, OW, KH, KW, S, P) <= 0) return GZ_ERR_UNSUPPORTED;
+    if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
+#define CALL(G)                                                                                                      \
+    [&]() -> int {                                                                                                   \
+        switch (fwd_plan<G>(s).tile) {                                                                               \
+            case T128x128: return run_fwd<G, Cfg128x128>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats); \
+            case T128x64: return run_fwd<G, Cfg128x64>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats);   \
+            case T128x32: return run_fwd<G, Cfg128x32>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats);   \
+            default: return run_fwd<G, Cfg64x64>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats);         \
+        }                                                                                                            \
+    }()
+    GZ_GEOM_DISPATCH(CALL)
+#undef CALL
+}
+
+int gz_conv2d_dgrad_stats_rows(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P) {
+    ConvShape s{N, C, H, W, K, OH, OW};
+    if (!shape_ok(s, KH, KW, S, P) || H % S || W % S) return 0;
+#define CALL(G) (dgrad_direct<G>(nullptr, s) ? SplitPlan{T64x64, 2} : dgrad_plan<G>(s))
+    SplitPlan sp = [&]() -> SplitPlan { GZ_GEOM_DISPATCH_OR(CALL, (SplitPlan{T64x64, 2})) }();
+#undef CALL
+    if (sp.splits > 1) return 0;
+    return S * S * stats_tm_rows(sp.tile, (long long)N * (H / S) * (W / S));
+}
+
+int gz_conv2d_dgrad_stats(const float* y, const float* wpack, float* x, float* stats, int N, int C, int H, int W, int K,
+                          int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream) {
+    gz::clear_stale_error();
+    ConvShape s{N, C, H, W, K, OH, OW};
+    if (!shape_ok(s, KH, KW, S, P) || !stats) return GZ_ERR_BAD_SHAPE;
+    if (gz_conv2d_dgrad_stats_rows(N, C, H, W, K, OH, OW, KH, KW, S, P) <= 0) return GZ_ERR_UNSUPPORTED;
+    if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
+#define CALL(G)                                                                                                        \
+    [&]() -> int {                                                                                                     \
+        switch (dgrad_plan<G>(s).tile) {                                                                               \
+            case T128x128: return run_dgrad<G, Cfg128x128>(y, wpack, nullptr, x, s, 0, 0.f, stream, 1, nullptr, stats); \
+            case T128x64: return run_dgrad<G, Cfg128x64>(y, wpack, nullptr, x, s, 0, 0.f, stream, 1, nullptr, stats);   \
+            case T128x32: return run_dgrad<G, Cfg128x32>(y, wpack, nullptr, x, s, 0, 0.f, stream, 1, nullptr, stats);   \
+            default: return run_dgrad<G, Cfg64x64>(y, wpack, nullptr, x, s, 0, 0.f, stream, 1, nullptr, stats);         \
+        }                                                                                                              \
+    }()
     GZ_GEOM_DISPATCH(CALL)
 #undef CALL
 }

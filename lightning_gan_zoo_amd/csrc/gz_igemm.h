@@ -1393,6 +1393,56 @@ struct Wg3DBLoader {
 //   C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
 // ---------------------------------------------------------------------------
 
+// ---------------------------------------------------------------------------
+// BatchNorm statistics from the accumulators (round 2; SURVEY 7.4 / VERDICT r1 item 6): per output channel the sum
+// and the sum of squares over the tile's pixels, so that the separate read of the whole feature map (row_sums_kernel)
+// disappears.  In the transposed-accumulator layout a lane owns a pixel and its 16 registers are 16 channels; the 32
+// lanes of a half-wave are reduced with a halving butterfly: at step k the lanes whose bit k is clear keep the lower
+// half of the surviving registers, the others the upper half, each adding what its partner sends -- 8 + 4 + 2 + 1 + 1
+// shuffles for 16 registers instead of 16 x 5.  Afterwards lane l of the half holds register
+// r = (b0 << 3) | (b1 << 2) | (b2 << 1) | b3 (b_k = bit k of l).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float half_wave_reduce16(const float (&v)[16], int lane) {
+    float t[8], u[4], w[2];
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = (b0 ? v[k + 8] : v[k]) + __shfl_xor(b0 ? v[k] : v[k + 8], 1, 64);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = (b1 ? t[k + 4] : t[k]) + __shfl_xor(b1 ? t[k] : t[k + 4], 2, 64);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) w[k] = (b2 ? u[k + 2] : u[k]) + __shfl_xor(b2 ? u[k] : u[k + 2], 4, 64);
+    float x = (b3 ? w[1] : w[0]) + __shfl_xor(b3 ? w[0] : w[1], 8, 64);
+    return x + __shfl_xor(x, 16, 64);
+}
+
+// stats[row][ch] = (sum, sum of squares) over the pixels this wavefront owns (TM x 32 per half-wave), for its TN x 32
+// channels.  Pixels past the end of the tensor hold exact zeros (their A rows were out of range) and add nothing.
+template <int TM, int TN>
+__device__ __forceinline__ void tile_channel_stats(f32x16 (&acc)[TM][TN], f32x2* __restrict__ stats, long long row,
+                                                   int CH, int n_base, int lane) {
+    const int half = lane >> 5;
+    const int r = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        float s1[16], s2[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float v = acc[i][j][q];
+                a += v;
+                b = fmaf(v, v, b);
+            }
+            s1[q] = a;
+            s2[q] = b;
+        }
+        const float t1 = half_wave_reduce16(s1, lane), t2 = half_wave_reduce16(s2, lane);
+        const int ch = n_base + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if ((lane & 16) == 0 && ch < CH) stats[row * CH + ch] = f32x2{t1, t2};
+    }
+}
+
 // C[z][m][n] row-major (n contiguous): wgrad slabs, plain GEMM.  Optional bias[n] + activation.
 struct EpiRowMajor {
     static constexpr bool SWAP = false;   // lanes run along n, the contiguous dimension of the row-major output
@@ -1439,11 +1489,13 @@ struct EpiNCHW {
         const float* bias;
         int act;
         float slope;
+        f32x2* stats;            // optional [rows][CH] partial BatchNorm statistics (bias null, act none); row = m_base / (TM*32)
     };
     template <int TM, int TN>
     __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
                                                  int n_base, int lane, int y, int z) {
         const int col_l = lane & 31, half = lane >> 5;
+        if (p.stats) tile_channel_stats<TM, TN>(acc, p.stats, m_base / (TM * 32), p.CH, n_base, lane);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m_base + i * 32 + col_l;
@@ -1479,11 +1531,15 @@ struct EpiPhase {
         const float* bias;
         int act;
         float slope;
+        f32x2* stats;            // optional [S*S phases x rows_per_phase][C] partial BatchNorm statistics
+        int stats_rows;          // rows per phase = tiles_m * BM / (TM*32)
     };
     template <int TM, int TN>
     __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
                                                  int n_base, int lane, int y, int z) {
         const int col_l = lane & 31, half = lane >> 5;
+        if (p.stats)
+            tile_channel_stats<TM, TN>(acc, p.stats, (long long)y * p.stats_rows + m_base / (TM * 32), p.C, n_base, lane);
         const int py = y / S, px = y % S;
         const long long chs = (long long)p.H * p.W;
 #pragma unroll

@@ -85,23 +85,39 @@ __global__ __launch_bounds__(64) void channel_sum_finalize_kernel(const f32x2* _
 
 // BatchNorm finalize: one wavefront per channel; lanes stride over n, fp64 shuffle-combine.
 // coef[0*C..] = scale, coef[1*C..] = shift, coef[2*C..] = mean, coef[3*C..] = rstd
-__global__ __launch_bounds__(64) void bn_finalize_kernel(const f32x2* __restrict__ sums,
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void bn_finalize_kernel(const f32x2* __restrict__ sums,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ coef,
                                                          float* running_mean, float* running_var, long long* nbt,
-                                                         int N, int C, int inner, float eps, float momentum) {
+                                                         int N, int C, int inner, float eps, float momentum,
+                                                         double count) {
     const int c = blockIdx.x, lane = threadIdx.x;
     if (c == 0 && lane == 0 && nbt) *nbt += 1;
     double s1 = 0.0, s2 = 0.0;
-    for (int n = lane; n < N; n += 64) {
+    for (int n = lane; n < N; n += 64 * WAVES) {
         f32x2 v = sums[(long long)n * C + c];
         s1 += (double)v.x;
         s2 += (double)v.y;
     }
     s1 = wave_sum_d(s1);
     s2 = wave_sum_d(s2);
+    if constexpr (WAVES > 1) {       // many partial rows (per-tile statistics of a large layer): 4 wavefronts share the walk
+        __shared__ double part[WAVES][2];
+        if ((lane & 63) == 0) {
+            part[lane >> 6][0] = s1;
+            part[lane >> 6][1] = s2;
+        }
+        __syncthreads();
+        s1 = s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            s1 += part[w][0];
+            s2 += part[w][1];
+        }
+    }
     if (lane != 0) return;
-    double cnt = (double)N * inner;
+    double cnt = count > 0.0 ? count : (double)N * inner;      // count > 0: `sums` are per-tile partials, not rows
     double mean = s1 / cnt;
     double var = s2 / cnt - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -473,8 +489,22 @@ int gz_batchnorm_stats(const float* x, const float* gamma, const float* beta, fl
     if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
     RowGeom g = row_geom((long long)N * C, inner);
     hipLaunchKernelGGL(row_sums_kernel, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, (f32x2*)workspace, g);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, stream, (const f32x2*)workspace, gamma, beta, coef,
-                       running_mean, running_var, num_batches_tracked, N, C, inner, eps, momentum);
+    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(C), dim3(64), 0, stream, (const f32x2*)workspace, gamma, beta, coef,
+                       running_mean, running_var, num_batches_tracked, N, C, inner, eps, momentum, 0.0);
+    return launch_status();
+}
+
+int gz_batchnorm_finalize(const float* partials, int rows, long long count, const float* gamma, const float* beta,
+                          float* coef, float* running_mean, float* running_var, long long* num_batches_tracked, int C,
+                          float eps, float momentum, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (rows <= 0 || C <= 0 || count <= 0) return GZ_ERR_BAD_SHAPE;
+    if (rows > 512)
+        hipLaunchKernelGGL(bn_finalize_kernel<8>, dim3(C), dim3(512), 0, stream, (const f32x2*)partials, gamma, beta, coef,
+                           running_mean, running_var, num_batches_tracked, rows, C, 0, eps, momentum, (double)count);
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(C), dim3(64), 0, stream, (const f32x2*)partials, gamma, beta, coef,
+                           running_mean, running_var, num_batches_tracked, rows, C, 0, eps, momentum, (double)count);
     return launch_status();
 }
 

@@ -182,6 +182,45 @@ def _conv_fwd_raw(x, w, bias, geom, act, slope):
     return y
 
 
+_NO_BN_FUSE = bool(os.environ.get("GZ_NO_BN_FUSE"))      # experiment: statistics by a separate pass, as in round 1
+
+
+def _conv_fwd_stats_raw(x, w, geom):
+    """(y, stats) -- the convolution and, from the same launch, the per-tile BatchNorm partial sums of y
+    (gz_conv2d_fwd_stats); stats is None when the launch cannot carry them (split-K)."""
+    N, C, H, W = x.shape
+    K = w.shape[0]
+    OH, OW = out_size(H, geom), out_size(W, geom)
+    rows = 0 if _NO_BN_FUSE else lib.gz_conv2d_fwd_stats_rows(N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
+                                                              geom.pad)
+    if rows <= 0:
+        return _conv_fwd_raw(x, w, None, geom, ACT_NONE, 0.0), None
+    y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
+    stats = torch.empty((rows, K, 2), device=x.device, dtype=torch.float32)
+    wp = _packed(w, "f", geom)
+    _timed(0, (N, C, H, W, K, OH, OW), geom, 2.0 * N * OH * OW * K * C * geom.kh * geom.kw, lambda: check(
+        lib.gz_conv2d_fwd_stats(_p(x), _p(wp), _p(y), _p(stats), N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
+                                geom.pad, _stream()), "conv2d_fwd_stats"))
+    return y, stats
+
+
+def _conv_dgrad_stats_raw(g, w, geom, hw):
+    N, K, OH, OW = g.shape
+    C = w.shape[1]
+    H, W = hw
+    rows = 0 if _NO_BN_FUSE else lib.gz_conv2d_dgrad_stats_rows(N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
+                                                                geom.pad)
+    if rows <= 0:
+        return _conv_dgrad_raw(g, w, None, geom, hw, ACT_NONE, 0.0), None
+    x = torch.empty((N, C, H, W), device=g.device, dtype=torch.float32)
+    stats = torch.empty((rows, C, 2), device=g.device, dtype=torch.float32)
+    wp = _packed(w, "d", geom)
+    _timed(1, (N, C, H, W, K, OH, OW), geom, 2.0 * N * OH * OW * K * C * geom.kh * geom.kw, lambda: check(
+        lib.gz_conv2d_dgrad_stats(_p(g), _p(wp), _p(x), _p(stats), N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
+                                  geom.pad, _stream()), "conv2d_dgrad_stats"))
+    return x, stats
+
+
 def _conv_dgrad_raw(g, w, bias, geom, hw, act, slope):
     N, K, OH, OW = g.shape
     C = w.shape[1]
@@ -305,16 +344,23 @@ def _pair_wgrad_dgrad(wgrad, dgrad, flops):
 
 class _ConvF(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, geom, act, slope):
+    def forward(ctx, x, w, bias, geom, act, slope, want_stats=False):
         x, w = _req(x, "x"), _req(w, "w")
-        y = _conv_fwd_raw(x, w, bias, geom, act, slope)
         ctx.geom, ctx.act, ctx.slope = geom, act, slope
         ctx.has_bias = bias is not None
+        if want_stats:          # BatchNorm follows: no bias, no activation; second output = partial statistics
+            y, stats = _conv_fwd_stats_raw(x, w, geom)
+            ctx.save_for_backward(x, w, None)
+            if stats is None:
+                stats = torch.empty(0, device=x.device)
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        y = _conv_fwd_raw(x, w, bias, geom, act, slope)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, *_stats_grad):
         x, w, y = ctx.saved_tensors
         geom = ctx.geom
         if ctx.act != ACT_NONE:
@@ -332,7 +378,7 @@ class _ConvF(torch.autograd.Function):
             dw = _ConvWg.apply(x, gy, geom)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = gy.sum((0, 2, 3))
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
     @staticmethod
     def _first_order(ctx, gy, x, w, geom):
@@ -349,23 +395,30 @@ class _ConvF(torch.autograd.Function):
                 dw = _conv_wgrad_raw(x, gy, geom)
         elif want_b:
             db = _channel_sum_raw(gy)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class _ConvDg(torch.autograd.Function):
     """x = act(conv_transpose2d(g, w) + bias): ConvTranspose2d forward and Conv2d input gradient."""
 
     @staticmethod
-    def forward(ctx, g, w, bias, geom, hw, act, slope):
+    def forward(ctx, g, w, bias, geom, hw, act, slope, want_stats=False):
         g, w = _req(g, "g"), _req(w, "w")
-        x = _conv_dgrad_raw(g, w, bias, geom, hw, act, slope)
         ctx.geom, ctx.act, ctx.slope = geom, act, slope
         ctx.has_bias = bias is not None
+        if want_stats:
+            x, stats = _conv_dgrad_stats_raw(g, w, geom, hw)
+            ctx.save_for_backward(g, w, None)
+            if stats is None:
+                stats = torch.empty(0, device=g.device)
+            ctx.mark_non_differentiable(stats)
+            return x, stats
+        x = _conv_dgrad_raw(g, w, bias, geom, hw, act, slope)
         ctx.save_for_backward(g, w, x if act != ACT_NONE else None)
         return x
 
     @staticmethod
-    def backward(ctx, v):
+    def backward(ctx, v, *_stats_grad):
         g, w, x = ctx.saved_tensors
         geom = ctx.geom
         if ctx.act != ACT_NONE:
@@ -375,7 +428,7 @@ class _ConvDg(torch.autograd.Function):
             dg = _conv_fwd_raw(v, w, None, geom, ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
             dw = _conv_wgrad_raw(v, g, geom) if ctx.needs_input_grad[1] else None
             db = _channel_sum_raw(v) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-            return dg, dw, db, None, None, None, None
+            return dg, dw, db, None, None, None, None, None
         dg = dw = db = None
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
             dg, dw = _pair_wgrad_dgrad(lambda: _ConvWg.apply(v, g, geom),
@@ -386,7 +439,7 @@ class _ConvDg(torch.autograd.Function):
             dw = _ConvWg.apply(v, g, geom)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = v.sum((0, 2, 3))
-        return dg, dw, db, None, None, None, None
+        return dg, dw, db, None, None, None, None, None
 
 
 class _ConvWg(torch.autograd.Function):
@@ -420,6 +473,20 @@ def conv_transpose2d(x, w, bias=None, geom=K4S2P1, act=ACT_NONE, slope=0.0):
     oh = (H - 1) * geom.stride - 2 * geom.pad + geom.kh
     ow = (W - 1) * geom.stride - 2 * geom.pad + geom.kw
     return _ConvDg.apply(x, w, bias, geom, (oh, ow), act, slope)
+
+
+def conv2d_with_stats(x, w, geom=K4S2P1):
+    """(conv2d(x, w), stats) for a convolution that feeds a training-mode BatchNorm: the launch also produces the
+    per-tile (sum, sum of squares) of its output; pass ``stats`` to batch_norm_act.  stats is an empty tensor when
+    the launch could not carry them (batch_norm_act then reads the feature map itself)."""
+    return _ConvF.apply(x, w, None, geom, ACT_NONE, 0.0, True)
+
+
+def conv_transpose2d_with_stats(x, w, geom=K4S2P1):
+    H, W = x.shape[2:]
+    oh = (H - 1) * geom.stride - 2 * geom.pad + geom.kh
+    ow = (W - 1) * geom.stride - 2 * geom.pad + geom.kw
+    return _ConvDg.apply(x, w, None, geom, (oh, ow), ACT_NONE, 0.0, True)
 
 
 # ---------------------------------------------------------------------------
@@ -591,13 +658,18 @@ class _BatchNormAct(torch.autograd.Function):
     nn.BatchNorm2d (momentum, unbiased running var, num_batches_tracked += 1)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act, slope):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act, slope, stats=None):
         x = _req(x, "x")
         N, C = x.shape[:2]
         inner = x.numel() // (N * C)
         coef = torch.empty(4 * C, device=x.device, dtype=torch.float32)
         st = _stream()
-        if training:
+        if training and stats is not None and stats.numel():
+            # partial sums written by the producing convolution's epilogue (conv2d_with_stats)
+            check(lib.gz_batchnorm_finalize(_p(stats), stats.shape[0], N * inner, _p(gamma), _p(beta), _p(coef),
+                                            _p(running_mean), _p(running_var), _p(nbt), C, eps, momentum, st),
+                  "batchnorm_finalize")
+        elif training:
             ws = _norm_ws(x, N, C)
             check(lib.gz_batchnorm_stats(_p(x), _p(gamma), _p(beta), _p(coef), _p(running_mean), _p(running_var),
                                          _p(nbt), _p(ws), N, C, inner, eps, momentum, st), "batchnorm_stats")
@@ -633,7 +705,7 @@ class _BatchNormAct(torch.autograd.Function):
             sgx = _rowdot_raw(gp.view(N * C, inner), x.view(N * C, inner), False).view(N, C).sum(0)
             dgamma = rstd * (sgx - mean * dbeta)
             return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                    None, None, None, None, None, None, None, None)
+                    None, None, None, None, None, None, None, None, None)
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
         dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
@@ -643,12 +715,13 @@ class _BatchNormAct(torch.autograd.Function):
         check(lib.gz_norm_act_bwd(_p(gout), _p(x), _p(coef), _p(dx), _p(dgamma), _p(dbeta), _p(ws), _p(kbuf), N, C,
                                   inner, 1, 0, 0, act, slope, _stream()), "norm_act_bwd")
         return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, nbt, training, momentum=0.1, eps=1e-5,
-                   act=ACT_NONE, slope=0.0):
-    return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act, slope)
+                   act=ACT_NONE, slope=0.0, stats=None):
+    return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act, slope,
+                               stats)
 
 
 class _RowNormAct(torch.autograd.Function):

@@ -86,6 +86,49 @@ def test_small_channel_transposed_conv(case):
                TF.conv_transpose2d(gy, w, None, 2, 1)) < TOL
 
 
+@pytest.mark.parametrize("case", [(2, 3, 16, 5), (4, 8, 16, 16), (3, 20, 8, 40), (8, 64, 16, 128), (16, 32, 32, 96),
+                                  (64, 16, 32, 256), (512, 64, 32, 128), (37, 24, 16, 72)])
+def test_conv_with_fused_batchnorm_statistics(case):
+    """conv / transposed conv whose epilogue also emits the BatchNorm partial sums (gz_conv2d_*_stats): the output is
+    bit-identical to the plain launch, the partial sums add up to the per-channel sum / sum of squares of the output
+    (every tile shape, ragged pixel and channel tails), and batch_norm_act fed with them gives the same result,
+    gradients and running buffers as when it reads the feature map itself."""
+    F = _F()
+    N, C, H, K = case
+    g = F.K4S2P1
+    x, w = rnd(N, C, H, H, seed=301).cuda(), rnd(K, C, 4, 4, seed=302, scale=0.1).cuda()
+    for name in ("conv", "conv_transpose"):
+        if name == "conv":
+            y_plain = F.conv2d(x, w, None, g)
+            y, stats = F.conv2d_with_stats(x, w, g)
+            ch = K
+        else:
+            xt = rnd(N, K, H // 2, H // 2, seed=303).cuda()
+            y_plain = F.conv_transpose2d(xt, w, None, g)          # w [Cin = K, Cout = C, 4, 4]
+            y, stats = F.conv_transpose2d_with_stats(xt, w, g)
+            ch = C
+        assert torch.equal(y, y_plain)
+        if stats.numel() == 0:
+            continue            # a split-K launch (few output tiles): not fused, by design
+        assert stats.shape[1:] == (ch, 2)
+        tot = stats.double().sum(0).cpu()
+        yd = y.double().cpu()
+        assert rel(tot[:, 0], yd.sum((0, 2, 3))) < 1e-5 and rel(tot[:, 1], (yd * yd).sum((0, 2, 3))) < 1e-5
+        gamma, beta = (rnd(ch, seed=304) * 0.1 + 1).cuda(), (rnd(ch, seed=305) * 0.1).cuda()
+        go = rnd(*y.shape, seed=306).cuda()
+        res = []
+        for st in (stats, None):
+            ya = y.detach().clone().requires_grad_()
+            ga, ba = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+            rm, rv, nbt = torch.zeros(ch).cuda(), torch.ones(ch).cuda(), torch.zeros((), dtype=torch.int64).cuda()
+            out = F.batch_norm_act(ya, ga, ba, rm, rv, nbt, True, 0.1, 1e-5, F.ACT_LRELU, 0.2, st)
+            out.backward(go)
+            res.append((out.detach(), ya.grad, ga.grad, ba.grad, rm, rv, nbt))
+        for a, b in zip(res[0][:6], res[1][:6]):
+            assert rel(a, b) < 1e-5
+        assert int(res[0][6]) == int(res[1][6]) == 1
+
+
 def test_conv_bias_act_epilogues():
     F = _F()
     g = F.K4S2P1
