@@ -33,9 +33,9 @@ class ZMapping(nn.Module):
         self.relu = nn.ReLU()
 
     def forward(self, x):
-        out = F.linear_act(x, self.linear1.weight, self.linear1.bias, F.ACT_RELU)
-        c = self.output_channel
-        return out[:, :c].contiguous(), out[:, c:].contiguous()
+        """[N, 2C]: the AdaIN scale (first half) and shift (second half), consumed packed by adain_act_packed
+        (the reference slices them, hologan_generator.py:17-18)."""
+        return F.linear_act(x, self.linear1.weight, self.linear1.bias, F.ACT_RELU)
 
 
 class BasicBlock(nn.Module):
@@ -58,8 +58,7 @@ class BasicBlock(nn.Module):
             h = F.conv_transpose2d(h, ct.weight, ct.bias, F.K4S2P1)
         else:
             h = F.conv_transpose3d(h, ct.weight, ct.bias)
-        s, b = self.zMapping(z)
-        return F.adain_act(h, s, b, 1e-8, F.ACT_RELU)
+        return F.adain_act_packed(h, self.zMapping(z), 1e-8, F.ACT_RELU)
 
 
 def _mat(rows):
@@ -150,8 +149,7 @@ class Generator(nn.Module):
                 view_in = self.sample_view(n)
             minv = draw_on_host(lambda: view_inverse_matrices(view_in).reshape(n, 16).contiguous(), dev)
 
-        s0, b0 = self.zMapping(z)
-        h = F.adain_act(self.x.repeat(n, 1, 1, 1, 1), s0, b0, 1e-8, F.ACT_RELU)
+        h = F.adain_act_packed(self.x.repeat(n, 1, 1, 1, 1), self.zMapping(z), 1e-8, F.ACT_RELU)
         h = self.block1(h, z)
         h = self.block2(h, z)
         h = F.rigid_resample(h, minv)                                 # [N, 16*C, 16, 16]

@@ -163,7 +163,9 @@ __global__ void row_finalize_kernel(const f32x2* __restrict__ sums, const float*
     if (var < 0.0) var = 0.0;
     if (unbiased && inner > 1) var = var * cnt / (cnt - 1.0);
     float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    int gi = affine_per_row ? r : r % C;
+    // affine_per_row == 2: scale and shift are the two halves of one packed [N][2C] array (HoloGAN's ZMapping
+    // output): gamma points at it, beta at gamma + C, row (n, c) reads element n * 2C + c of each
+    int gi = affine_per_row == 2 ? (r / C) * 2 * C + r % C : (affine_per_row ? r : r % C);
     float ga = gamma ? gamma[gi] : 1.f, be = beta ? beta[gi] : 0.f;
     float scale = ga * rstd;
     coef[r] = scale;
@@ -284,8 +286,9 @@ __global__ void row_bwd_finalize_kernel(const f32x2* __restrict__ sums, float* _
         k[i] = v.x / (float)inner;
         k[rows + i] = v.y / (float)((unbiased && inner > 1) ? inner - 1 : inner);
         if (affine_per_row) {
-            if (dgamma) dgamma[i] = v.y;
-            if (dbeta) dbeta[i] = v.x;
+            const int gi = affine_per_row == 2 ? (i / C) * 2 * C + i % C : i;     // 2: packed [N][2C] gradient
+            if (dgamma) dgamma[gi] = v.y;
+            if (dbeta) dbeta[gi] = v.x;
         }
     }
 }

@@ -1052,6 +1052,52 @@ def adain_act(x, scale, bias, eps=1e-8, act=ACT_RELU, slope=0.0):
     return _AdaINAct.apply(x, scale, bias, eps, act, slope)
 
 
+class _AdaINActPacked(torch.autograd.Function):
+    """adain_act with scale and shift given as the two halves of ONE [N, 2C] tensor (the ZMapping output,
+    hologan_generator.py:15-18): no slicing / copying on the way in, and the gradient comes back as one [N, 2C]
+    tensor written by the kernel (the framework spelling cost 2 copies forward and a zeros + 2 slice copies + add
+    backward per block)."""
+
+    @staticmethod
+    def forward(ctx, x, sb, eps, act, slope):
+        x, sb = _req(x, "x"), _req(sb, "scale|shift")
+        N, C = x.shape[:2]
+        if sb.shape != (N, 2 * C):
+            raise RuntimeError("adain_act_packed: expected scale|shift of shape [N, 2C]")
+        inner = x.numel() // (N * C)
+        coef = torch.empty(4 * N * C, device=x.device, dtype=torch.float32)
+        ws = _norm_ws(x, N, C)
+        st = _stream()
+        sbp = sb.data_ptr()
+        check(lib.gz_rownorm_stats(_p(x), ctypes.c_void_p(sbp), ctypes.c_void_p(sbp + 4 * C), _p(coef), _p(ws), N, C,
+                                   inner, eps, 2, 1, st), "rownorm_stats(adain, packed)")
+        out = torch.empty_like(x)
+        check(lib.gz_norm_act_fwd(_p(x), _p(coef), _p(out), N, C, inner, 0, act, slope, st), "norm_act_fwd")
+        ctx.save_for_backward(x, coef)
+        ctx.cfg = (N, C, inner, act, slope)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        x, coef = ctx.saved_tensors
+        N, C, inner, act, slope = ctx.cfg
+        gout = _req(gout)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dsb = torch.empty((N, 2 * C), device=x.device, dtype=torch.float32)
+        kbuf = torch.empty(2 * N * C, device=x.device, dtype=torch.float32)
+        ws = _norm_ws(x, N, C)
+        p0 = dsb.data_ptr()
+        check(lib.gz_norm_act_bwd(_p(gout), _p(x), _p(coef), _p(dx), ctypes.c_void_p(p0), ctypes.c_void_p(p0 + 4 * C),
+                                  _p(ws), _p(kbuf), N, C, inner, 0, 2, 1, act, slope, _stream()),
+              "norm_act_bwd(adain, packed)")
+        return dx, dsb, None, None, None
+
+
+def adain_act_packed(x, sb, eps=1e-8, act=ACT_RELU, slope=0.0):
+    return _AdaINActPacked.apply(x, sb, eps, act, slope)
+
+
 class _LinearAct(torch.autograd.Function):
     """act(x @ W^T + b) with bias and activation fused in the GEMM epilogue."""
 

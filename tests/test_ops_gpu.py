@@ -313,6 +313,13 @@ def test_adain_relu_fwd_bwd(shape):
     out.backward(go.cuda())
     for got, want in ((out, ref), (xd.grad, xr.grad), (sd.grad, sr.grad), (bd.grad, br.grad)):
         assert rel(got, want) < TOL
+    # scale | shift packed in one [N, 2C] tensor (the ZMapping output as it is)
+    xp = x.cuda().requires_grad_()
+    sbp = torch.cat([s, b], 1).cuda().requires_grad_()
+    outp = F.adain_act_packed(xp, sbp, 1e-8, F.ACT_RELU)
+    outp.backward(go.cuda())
+    assert torch.equal(outp, out) and rel(xp.grad, xr.grad) < TOL
+    assert rel(sbp.grad[:, :C], sr.grad) < TOL and rel(sbp.grad[:, C:], br.grad) < TOL
 
 
 def test_rigid_resample_matches_oracle_and_indices_are_bit_exact():
