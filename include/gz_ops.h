@@ -204,6 +204,13 @@ int gz_batchnorm_eval_coef(const float* gamma, const float* beta, const float* r
  * or AdaIN (hologan_generator.py:333-345; gamma/beta per row, unbiased var). */
 int gz_rownorm_stats(const float* x, const float* gamma, const float* beta, float* coef, void* workspace, int N,
                      int C, int inner, float eps, int affine_per_row, int unbiased, hipStream_t stream);
+/* gz_rownorm_stats + gz_norm_act_fwd(per_channel = 0) in one launch (the row is re-read from cache): coef as above,
+ * out = act(x * scale + shift).  affine_per_row: 0 = gamma/beta per channel, 1 = per row ([N][C] arrays, AdaIN),
+ * 2 = per row from one packed [N][2C] array (gamma = its base, beta = base + C: HoloGAN's ZMapping output,
+ * hologan_generator.py:15-18). */
+int gz_rownorm_act_fwd(const float* x, const float* gamma, const float* beta, float* coef, float* out, int N, int C,
+                       int inner, float eps, int affine_per_row, int unbiased, int act, float slope,
+                       hipStream_t stream);
 /* out = act(x * scale + shift) */
 int gz_norm_act_fwd(const float* x, const float* coef, float* out, int N, int C, int inner, int per_channel,
                     int act, float slope, hipStream_t stream);

@@ -30,6 +30,44 @@ static size_t bytes3(int splits, long long M, long long N, int Kdim, int ny) {
     return splits > 1 ? (size_t)split_nz(Kdim, splits) * ny * M * N * 4 : 0;
 }
 
+// Split-K of the transposed convolution's 8 phases (1, 2, 2, 2, 4, 4, 4, 8 taps for k3 s2 p1): the chunk count per
+// workgroup is chosen from the TOTAL work so that ~1024 workgroups of equal length come out; a phase gets as many
+// slabs as its own reduction needs (GridMap::phase_nz), not the longest phase's count.
+struct DgPlan3 {
+    int splits;         // of the longest phase
+    long long slabs;    // sum over the phases
+};
+
+static DgPlan3 plan3_dg(int tile, long long Mp, long long C, int K, int KS, int S, int P) {
+    DgPlan3 none{1, 0};
+    static int off = getenv("GZ_NO_SPLITK") ? 1 : 0;
+    static int even = getenv("GZ_DG3_EVEN_SPLIT") ? 1 : 0;      // experiment: the round-1 plan (same slab count per phase)
+    const int bm = tile == 3 ? 64 : 128, bn = tile == 0 ? 128 : (tile == 2 ? 32 : 64);
+    const long long tp = ((Mp + bm - 1) / bm) * ((C + bn - 1) / bn);
+    int pc[8], maxpc = 0;
+    long long total = 0;
+    for (int ph = 0; ph < S * S * S; ++ph) {
+        pc[ph] = (K * dg_taps(KS, S, P, ph / (S * S)) * dg_taps(KS, S, P, (ph / S) % S) * dg_taps(KS, S, P, ph % S) +
+                  BK - 1) / BK;
+        total += pc[ph];
+        maxpc = pc[ph] > maxpc ? pc[ph] : maxpc;
+    }
+    if (off || maxpc < 16 || tp * S * S * S >= 512) return none;
+    int splits;
+    if (even) {
+        splits = plan3(tile, Mp, C, K * 8, 8);
+    } else {
+        long long cps = (total * tp + 1023) / 1024;
+        if (cps < 8) cps = 8;
+        splits = (int)((maxpc + cps - 1) / cps);
+    }
+    if (splits < 2) return none;
+    const int cps = (maxpc + splits - 1) / splits;
+    long long slabs = 0;
+    for (int ph = 0; ph < S * S * S; ++ph) slabs += (pc[ph] + cps - 1) / cps;
+    return DgPlan3{splits, slabs};
+}
+
 static int pick3(long long M, long long N, int ny) {
     if (N <= 32) return 2;
     auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * ny; };
@@ -155,8 +193,9 @@ static int run_dgrad3(const float* y, const float* wp, const float* bias, float*
 }
 
 static int splits3(long long tiles, int chunks) {
+    static int target = getenv("GZ_WG3_TARGET") ? atoi(getenv("GZ_WG3_TARGET")) : 1024;
     if (tiles >= 256) return 1;
-    long long want = (512 + tiles - 1) / tiles;
+    long long want = (target + tiles - 1) / tiles;
     long long cap = chunks / 8 > 0 ? chunks / 8 : 1;
     long long s = want < cap ? want : cap;
     return (int)(s < 1 ? 1 : s);
@@ -250,8 +289,8 @@ size_t gz_conv3d_fwd_workspace_bytes(int N, int C, int K, int OD, int OH, int OW
 
 size_t gz_conv3d_dgrad_workspace_bytes(int N, int C, int K, int OD, int OH, int OW, int KS) {
     long long M = (long long)N * OD * OH * OW;      // per phase: the S = 2 output grid has OD*OH*OW cells per phase
-    int Kg = K * 8;
-    return bytes3(plan3(pick3(M, C, 8), M, C, Kg, 8), M, C, Kg, 8);
+    DgPlan3 pl = plan3_dg(pick3(M, C, 8), M, C, K, KS, 2, 1);
+    return pl.splits > 1 ? (size_t)pl.slabs * M * C * 4 : 0;
 }
 
 int gz_conv3d_fwd(const float* x, const float* wpack, const float* bias, float* y, float* workspace, size_t ws_bytes,
@@ -284,8 +323,9 @@ int gz_conv3d_dgrad(const float* y, const float* wpack, const float* bias, float
     if ((uintptr_t)wpack & 15) return GZ_ERR_BAD_SHAPE;
     const long long Mp = (long long)N * (D / S) * (H / S) * (W / S);
     int t = pick3(Mp, C, S * S * S);
-    int splits = plan3(t, Mp, C, K * 8, 8);
-    if (splits > 1 && (!workspace || ws_bytes < bytes3(splits, Mp, C, K * 8, 8))) splits = 1;
+    DgPlan3 pl = plan3_dg(t, Mp, C, K, KS, S, P);
+    int splits = pl.splits;
+    if (splits > 1 && (!workspace || ws_bytes < (size_t)pl.slabs * Mp * C * 4)) splits = 1;
     float* slab = splits > 1 ? workspace : nullptr;
 #define CALL(CFG) run_dgrad3<CFG, 3, 2, 1>(y, wpack, bias, x, s, act, slope, stream, splits, slab)
     GZ3_TILE_SWITCH(t, CALL)
@@ -309,6 +349,8 @@ int gz_conv3d_wgrad(const float* x, const float* y, float* dw, float* workspace,
     if (big3((long long)N * C * D * H * W) || big3((long long)N * K * OD * OH * OW)) return GZ_ERR_TOO_LARGE;
     long long NTOT = (long long)C * KS * KS * KS;
     int t = NTOT <= 32 ? 2 : ((NTOT <= 64 || K <= 64) ? (K <= 64 ? 3 : 1) : 0);
+    static int force = getenv("GZ_WG3_TILE") ? atoi(getenv("GZ_WG3_TILE")) : -1;      // experiment
+    if (force >= 0 && t == 0) t = force;
 #define CALL(CFG) run_wgrad3<CFG, 3, 2, 1>(x, y, dw, workspace, ws_bytes, s, stream)
     GZ3_TILE_SWITCH(t, CALL)
 #undef CALL

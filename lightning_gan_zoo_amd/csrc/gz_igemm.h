@@ -1340,7 +1340,12 @@ struct Wg3DBLoader {
     static constexpr int EPT = BN / 16;
     static constexpr int T3 = KS * KS * KS;
     __amdgpu_buffer_rsrc_t rsrc;
-    int toff[EPT], kd_[EPT], ky_[EPT], kx_[EPT];
+    // Validity of a tap is kept as 3 + 3 bits per element (tap index 0 / KS-1 along d, y, x: the only taps that can
+    // leave the volume below / above), eight elements to a register -- the per-element kd/ky/kx arrays of round 1
+    // cost 24 more registers and the 128x128 kernel spilled 22 of them inside the reduction loop.
+    static_assert(EPT <= 8 && KS == 3 && S == 2 && P == 1, "only tap 0 / tap KS-1 may leave the volume");
+    int toff[EPT];
+    uint32_t lo_bits, hi_bits;       // 3 bits per element j at 3*j: (kd == 0, ky == 0, kx == 0) / (== KS-1)
     int kl, n_l, ODHW, OHW, OW, D, H, W, CDHW, KTOT;
     FastDiv div_odhw, div_ohw, div_ow;
     float r[EPT];
@@ -1353,15 +1358,17 @@ struct Wg3DBLoader {
         D = s.D; H = s.H; W = s.W; CDHW = s.C * s.D * s.H * s.W;
         KTOT = p.KTOT;
         div_odhw = p.div_odhw; div_ohw = p.div_ohw; div_ow = p.div_ow;
+        lo_bits = hi_bits = 0;
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
             int col = tile * BN + n_l + 16 * j;
             int c = col / T3;
             int tap = col - c * T3;
-            kd_[j] = tap / (KS * KS) - P;
-            ky_[j] = (tap / KS) % KS - P;
-            kx_[j] = tap % KS - P;
-            toff[j] = col < p.NTOT ? ((c * D + kd_[j]) * H + ky_[j]) * W + kx_[j] : INT32_MIN;
+            const int kd = tap / (KS * KS), ky = (tap / KS) % KS, kx = tap % KS;
+            const bool in = col < p.NTOT;
+            toff[j] = in ? ((c * D + kd - P) * H + ky - P) * W + kx - P : INT32_MIN;     // INT32_MIN: column past the end
+            lo_bits |= (uint32_t)((kd == 0) | (ky == 0) << 1 | (kx == 0) << 2) << (3 * j);
+            hi_bits |= (uint32_t)((kd == KS - 1) | (ky == KS - 1) << 1 | (kx == KS - 1) << 2) << (3 * j);
         }
     }
     __device__ __forceinline__ void issue(int kc) {
@@ -1375,10 +1382,15 @@ struct Wg3DBLoader {
         int bd = (int)od * S, by = (int)oy * S, bx = (int)ox * S;
         int base = (int)n * CDHW + (bd * H + by) * W + bx;
         bool ok = p < (uint32_t)KTOT;
+        // this output position's taps 0 reach below the volume when base coordinate - P < 0, taps KS-1 above it when
+        // base + KS-1-P >= extent
+        const uint32_t pos_lo = (uint32_t)(bd < P) | (uint32_t)(by < P) << 1 | (uint32_t)(bx < P) << 2;
+        const uint32_t pos_hi = (uint32_t)(bd + KS - 1 - P >= D) | (uint32_t)(by + KS - 1 - P >= H) << 1 |
+                                (uint32_t)(bx + KS - 1 - P >= W) << 2;
+        const uint32_t bad = (lo_bits & (pos_lo * 0x249249u)) | (hi_bits & (pos_hi * 0x249249u));
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            bool v2 = ok && toff[j] != INT32_MIN && (unsigned)(bd + kd_[j]) < (unsigned)D &&
-                      (unsigned)(by + ky_[j]) < (unsigned)H && (unsigned)(bx + kx_[j]) < (unsigned)W;
+            bool v2 = ok && toff[j] != INT32_MIN && ((bad >> (3 * j)) & 7u) == 0;
             r[j] = bload(rsrc, v2 ? (uint32_t)(base + toff[j]) * 4u : OOB, 0);
         }
     }
@@ -1628,6 +1640,12 @@ struct GridMap {
     int var_chunks;
     int phase_chunks[8];
     int phase_order[8];        // phases by decreasing chunk count
+    // split-K of such a launch: phase y owns phase_nz[y] = ceil(phase_chunks[y] / chunks_per_split) slabs starting at
+    // slab phase_slab0[y]; the (y, z) workgroups past a short phase's last slab exit at once, so that every
+    // remaining workgroup carries about the same number of chunks (with one slab count for all phases the 8-tap
+    // phase of the 4^3 -> 8^3 transposed convolution ran 8x longer than the 1-tap phase beside it)
+    int phase_nz[8];
+    int phase_slab0[8];
     int no_swizzle;            // experiment (GZ_NO_XCD_SWIZZLE): plain blockIdx order
 };
 
@@ -1718,6 +1736,8 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
     const int z = blockIdx.z;
     const int kc0 = z * gm.chunks_per_split;
     const int kc1 = min(gm.var_chunks ? gm.phase_chunks[y] : gm.chunks, kc0 + gm.chunks_per_split);
+
+    if (gm.slab && gm.var_chunks && kc0 >= kc1) return;      // past this phase's last slab (uniform per workgroup)
 
     AL al;
     BL bl;
@@ -1867,18 +1887,25 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
 #endif
     if (gm.slab)
         store_slab<Epi::SWAP, TM, TN>(gm, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32, lane,
-                           y * (int)gridDim.z + z);
+                           gm.var_chunks ? gm.phase_slab0[y] + z : y * (int)gridDim.z + z);
     else
         Epi::template store<TM, TN>(pe, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32,
                                     lane, y, z);
 }
+
+struct SlabMap {      // per-phase slab ranges of a split launch with phases of unequal length (GridMap::phase_nz)
+    int var;
+    int nz[8];
+    int slab0[8];
+};
 
 // Second pass of a split-K launch: a workgroup owns one 32x32 output block; its WAVES wavefronts each sum every
 // WAVES-th slab into the accumulator image Epi::store expects (the MFMA C/D layout), the partial images meet in
 // LDS in a fixed order, and wavefront 0 runs the op's own epilogue (bias, activation, NCHW / phase scatter).
 template <class Epi, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void splitk_finish_kernel(const float* __restrict__ slab, int nz, int M, int N,
-                                                                   typename Epi::Params pe, int tiles_n, int ny) {
+                                                                   typename Epi::Params pe, int tiles_n, int ny,
+                                                                   SlabMap sm) {
     __shared__ float part[WAVES - 1][16][64];
     int bid = blockIdx.x;
     const int y = bid % ny;
@@ -1890,8 +1917,10 @@ __global__ __launch_bounds__(64 * WAVES) void splitk_finish_kernel(const float* 
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    const int slab0 = sm.var ? sm.slab0[y] : y * nz;
+    if (sm.var) nz = sm.nz[y];
     for (int z = wave; z < nz; z += WAVES) {
-        const float* c = slab + (long long)(y * nz + z) * M * N;
+        const float* c = slab + (long long)(slab0 + z) * M * N;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -1965,6 +1994,14 @@ inline int launch_igemm(const typename AL::Params& pa, const typename BL::Params
     gm.ny = ny;
     dim3 grid(gm.tiles_m * gm.tiles_n * ny, 1, nz);
     if (slab && nz > 1) gm.slab = slab;
+    SlabMap sm;
+    sm.var = gm.slab && gm.var_chunks;
+    for (int i = 0, at = 0; i < 8; ++i) {
+        int n = (sm.var && i < ny) ? (gm.phase_chunks[i] + gm.chunks_per_split - 1) / gm.chunks_per_split : 0;
+        gm.phase_nz[i] = sm.nz[i] = n;
+        gm.phase_slab0[i] = sm.slab0[i] = at;
+        at += n;
+    }
     static int dyn_lds = getenv("GZ_DYN_LDS") ? atoi(getenv("GZ_DYN_LDS")) : 0;   // experiment: throttle workgroups per CU
     hipLaunchKernelGGL((igemm_kernel<Cfg, AL, BL, Epi>), grid, dim3(NT), dyn_lds, stream, pa, pb, pe, gm);
     if (gm.slab) {
@@ -1972,10 +2009,10 @@ inline int launch_igemm(const typename AL::Params& pa, const typename BL::Params
         // many slabs over few output blocks (the K = 8192 / 32768 linear heads): 16 wavefronts share the slab walk
         if (nz > 16)
             hipLaunchKernelGGL((splitk_finish_kernel<Epi, 8>), dim3(fm * fn * ny), dim3(512), 0, stream, slab, nz, M, N,
-                               pe, fn, ny);
+                               pe, fn, ny, sm);
         else
             hipLaunchKernelGGL((splitk_finish_kernel<Epi, 4>), dim3(fm * fn * ny), dim3(NT), 0, stream, slab, nz, M, N, pe,
-                               fn, ny);
+                               fn, ny, sm);
     }
     return launch_status();
 }

@@ -149,31 +149,6 @@ __global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float
     coef[3 * C + c] = rstd;
 }
 
-// per-row finalize (InstanceNorm / AdaIN): rows = N*C, gamma/beta indexed by channel (stride_n = 0)
-// or by row (AdaIN: per-sample scale/bias, stride_n = C).  unbiased = 1 uses var * n/(n-1).
-__global__ void row_finalize_kernel(const f32x2* __restrict__ sums, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, float* __restrict__ coef, int rows, int C,
-                                    int inner, float eps, int affine_per_row, int unbiased) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    f32x2 v = sums[r];
-    double cnt = (double)inner;
-    double mean = (double)v.x / cnt;
-    double var = (double)v.y / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    if (unbiased && inner > 1) var = var * cnt / (cnt - 1.0);
-    float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    // affine_per_row == 2: scale and shift are the two halves of one packed [N][2C] array (HoloGAN's ZMapping
-    // output): gamma points at it, beta at gamma + C, row (n, c) reads element n * 2C + c of each
-    int gi = affine_per_row == 2 ? (r / C) * 2 * C + r % C : (affine_per_row ? r : r % C);
-    float ga = gamma ? gamma[gi] : 1.f, be = beta ? beta[gi] : 0.f;
-    float scale = ga * rstd;
-    coef[r] = scale;
-    coef[rows + r] = be - (float)mean * scale;
-    coef[2 * rows + r] = (float)mean;
-    coef[3 * rows + r] = rstd;
-}
-
 // ---------------------------------------------------------------------------
 // forward apply: out = act(x * scale[i] + shift[i])
 // ---------------------------------------------------------------------------
@@ -203,6 +178,82 @@ __global__ __launch_bounds__(PW_THREADS) void norm_act_apply_kernel(const float*
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = act_fwd(v[k] * sc + sh, act, slope);
         reinterpret_cast<f32x4*>(out)[i] = o;
+    }
+}
+
+// Per-row statistics, their finalize and the apply in ONE launch (InstanceNorm / AdaIN; round 2): the sub-wave that
+// summed a row turns the sums into (scale, shift, mean, rstd) itself (gamma / beta per channel, per row, or per row
+// from a packed [N][2C] array: affine_per_row 0 / 1 / 2; unbiased = 1 uses var * n/(n-1)) and streams the row again while it is still in this CU's cache.  Replaces row_sums + row_finalize +
+// norm_act_apply: HoloGAN ran 25 such triples per optimizer-step pair, each launch costing its ~2.5 us dispatch gap
+// on top of ~5 us of work.
+__global__ __launch_bounds__(PW_THREADS) void rownorm_act_fused_kernel(const float* __restrict__ x,
+                                                                       const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta,
+                                                                       float* __restrict__ coef,
+                                                                       float* __restrict__ out, RowGeom g, int C,
+                                                                       int inner, float eps, int affine_per_row,
+                                                                       int unbiased, int act, float slope) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * PW_THREADS + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * PW_THREADS) >> 6;
+    const int sub = lane / g.lpr, l = lane % g.lpr;
+    for (long long row0 = (long long)wave * g.rpw; row0 < g.rows; row0 += (long long)nwaves * g.rpw) {
+        const long long row = row0 + sub;
+        const bool live = row < g.rows;
+        const f32x4* p = reinterpret_cast<const f32x4*>(x) + row * g.q4;
+        // Two passes over the (cache-resident) row: the mean first, then the centred second moment with the
+        // correction term of the "corrected two-pass" formula.  The one-pass E[x^2] - mean^2 of row_sums_kernel loses
+        // mean^2 / var digits, and AdaIN rows do have |mean| >> sigma (a convolution of an all-positive, nearly
+        // constant AdaIN+ReLU output): two summation orders of the SAME convolution then moved HoloGAN's
+        // second-pair gradients by 3 %, which the reference's torch.var (two passes) does not do.
+        float s[1] = {0.f};
+        if (live) {
+            for (int q = l; q < g.q4; q += g.lpr) {
+                f32x4 v = p[q];
+                s[0] += (v.x + v.y) + (v.z + v.w);
+            }
+        }
+        sub_reduce<1>(s, g.lpr);        // xor butterfly: every lane of the sub-wave holds the row's sum
+        const double cnt = (double)inner;
+        const float mean_f = (float)((double)s[0] / cnt);
+        float d[2] = {0.f, 0.f};
+        if (live) {
+            for (int q = l; q < g.q4; q += g.lpr) {
+                f32x4 v = p[q];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float e = v[k] - mean_f;
+                    d[0] += e;
+                    d[1] += e * e;
+                }
+            }
+        }
+        sub_reduce<2>(d, g.lpr);
+        if (!live) continue;
+        const int r = (int)row;
+        const double mean = (double)mean_f + (double)d[0] / cnt;
+        double var = ((double)d[1] - (double)d[0] * (double)d[0] / cnt) / cnt;
+        if (var < 0.0) var = 0.0;
+        if (unbiased && inner > 1) var = var * cnt / (cnt - 1.0);
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const int gi = affine_per_row == 2 ? (r / C) * 2 * C + r % C : (affine_per_row ? r : r % C);
+        const float ga = gamma ? gamma[gi] : 1.f, be = beta ? beta[gi] : 0.f;
+        const float sc = ga * rstd;
+        const float sh = be - (float)mean * sc;
+        if (l == 0) {
+            coef[r] = sc;
+            coef[g.rows + r] = sh;
+            coef[2 * g.rows + r] = (float)mean;
+            coef[3 * g.rows + r] = rstd;
+        }
+        if (!out) continue;       // statistics only (gz_rownorm_stats)
+        f32x4* po = reinterpret_cast<f32x4*>(out) + row * g.q4;
+        for (int q = l; q < g.q4; q += g.lpr) {
+            f32x4 v = p[q], o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = act_fwd(v[k] * sc + sh, act, slope);
+            po[q] = o;
+        }
     }
 }
 
@@ -332,6 +383,69 @@ __global__ __launch_bounds__(PW_THREADS) void norm_bwd_apply_kernel(const float*
             o[q] = sc * (dz - k1 - xh * k2);
         }
         reinterpret_cast<f32x4*>(dx)[i] = o;
+    }
+}
+
+// First backward of a per-row normalisation in ONE launch: row sums of (dz, dz*xh), the two coefficients, the per-row
+// affine gradients (AdaIN) and dx = scale * (dz - k1 - xh*k2) from a second, cache-resident read of the row.
+// `sums` (optional) keeps the raw row sums for row_bwd_affine_kernel (per-channel gamma / beta).
+__global__ __launch_bounds__(PW_THREADS) void rownorm_bwd_fused_kernel(const float* __restrict__ gout,
+                                                                       const float* __restrict__ x,
+                                                                       const float* __restrict__ coef,
+                                                                       float* __restrict__ dx,
+                                                                       float* __restrict__ dgamma,
+                                                                       float* __restrict__ dbeta,
+                                                                       f32x2* __restrict__ sums, RowGeom g, int C,
+                                                                       int inner, int affine_per_row, int unbiased,
+                                                                       int act, float slope) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * PW_THREADS + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * PW_THREADS) >> 6;
+    const int sub = lane / g.lpr, l = lane % g.lpr;
+    for (long long row0 = (long long)wave * g.rpw; row0 < g.rows; row0 += (long long)nwaves * g.rpw) {
+        const long long row = row0 + sub;
+        const bool live = row < g.rows;
+        const int ci = live ? (int)row : 0;
+        const float sc = coef[ci], sh = coef[g.rows + ci], mean = coef[2 * g.rows + ci], rstd = coef[3 * g.rows + ci];
+        const f32x4* px = reinterpret_cast<const f32x4*>(x) + row * g.q4;
+        const f32x4* pg = reinterpret_cast<const f32x4*>(gout) + row * g.q4;
+        float s[2] = {0.f, 0.f};
+        if (live) {
+            for (int q = l; q < g.q4; q += g.lpr) {
+                f32x4 xv = px[q], gv = pg[q];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float dz = gv[k] * act_grad_z(xv[k] * sc + sh, act, slope);
+                    s[0] += dz;
+                    s[1] += dz * ((xv[k] - mean) * rstd);
+                }
+            }
+        }
+        sub_reduce<2>(s, g.lpr);
+        if (!live) continue;
+        const float k1 = s[0] / (float)inner;
+        const float k2 = s[1] / (float)((unbiased && inner > 1) ? inner - 1 : inner);
+        if (l == 0) {
+            if (sums) sums[row] = f32x2{s[0], s[1]};
+            if (affine_per_row) {
+                const int r = (int)row;
+                const int gi = affine_per_row == 2 ? (r / C) * 2 * C + r % C : r;
+                if (dgamma) dgamma[gi] = s[1];
+                if (dbeta) dbeta[gi] = s[0];
+            }
+        }
+        if (!dx) continue;
+        f32x4* po = reinterpret_cast<f32x4*>(dx) + row * g.q4;
+        for (int q = l; q < g.q4; q += g.lpr) {
+            f32x4 xv = px[q], gv = pg[q], o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float dz = gv[k] * act_grad_z(xv[k] * sc + sh, act, slope);
+                float xh = (xv[k] - mean) * rstd;
+                o[k] = sc * (dz - k1 - xh * k2);
+            }
+            po[q] = o;
+        }
     }
 }
 
@@ -533,11 +647,21 @@ int gz_rownorm_stats(const float* x, const float* gamma, const float* beta, floa
                      int C, int inner, float eps, int affine_per_row, int unbiased, hipStream_t stream) {
     gz::clear_stale_error();
     if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
+    (void)workspace;
     RowGeom g = row_geom((long long)N * C, inner);
-    hipLaunchKernelGGL(row_sums_kernel, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, (f32x2*)workspace, g);
-    int rows = N * C;
-    hipLaunchKernelGGL(row_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, (const f32x2*)workspace,
-                       gamma, beta, coef, rows, C, inner, eps, affine_per_row, unbiased);
+    hipLaunchKernelGGL(rownorm_act_fused_kernel, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, gamma, beta, coef,
+                       (float*)nullptr, g, C, inner, eps, affine_per_row, unbiased, ACT_NONE, 0.f);
+    return launch_status();
+}
+
+int gz_rownorm_act_fwd(const float* x, const float* gamma, const float* beta, float* coef, float* out, int N, int C,
+                       int inner, float eps, int affine_per_row, int unbiased, int act, float slope,
+                       hipStream_t stream) {
+    gz::clear_stale_error();
+    if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
+    RowGeom g = row_geom((long long)N * C, inner);
+    hipLaunchKernelGGL(rownorm_act_fused_kernel, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, gamma, beta, coef,
+                       out, g, C, inner, eps, affine_per_row, unbiased, act, slope);
     return launch_status();
 }
 
@@ -558,6 +682,17 @@ int gz_norm_act_bwd(const float* gout, const float* x, const float* coef, float*
     if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
     RowGeom rg = row_geom((long long)N * C, inner);
     ApplyGeom g = apply_geom(N, C, inner, per_channel);
+    static const bool unfused = getenv("GZ_NORM_UNFUSED") != nullptr;      // experiment: the three-launch path
+    if (!per_channel && !unfused) {
+        const bool channel_affine = !affine_per_row && (dgamma || dbeta);
+        hipLaunchKernelGGL(rownorm_bwd_fused_kernel, dim3(row_grid(rg)), dim3(PW_THREADS), 0, stream, gout, x, coef, dx,
+                           dgamma, dbeta, channel_affine ? (f32x2*)workspace : (f32x2*)nullptr, rg, C, inner,
+                           affine_per_row, unbiased, act, slope);
+        if (channel_affine)
+            hipLaunchKernelGGL(row_bwd_affine_kernel, dim3(C), dim3(64), 0, stream, (const f32x2*)workspace, dgamma,
+                               dbeta, N, C);
+        return launch_status();
+    }
     hipLaunchKernelGGL(norm_bwd_rowsums_kernel, dim3(row_grid(rg)), dim3(PW_THREADS), 0, stream, gout, x, coef,
                        (f32x2*)workspace, rg, C, per_channel, g.ncoef, act, slope);
     if (per_channel) {

@@ -161,11 +161,22 @@ def invalidate(w):
 # ---------------------------------------------------------------------------
 # raw (non-differentiable) launchers
 # ---------------------------------------------------------------------------
+# GZ_POISON_SCRATCH=1 (tests): every scratch / workspace buffer starts as NaN, so a kernel that reads a part of it that
+# this launch has not written shows up in the results instead of depending on what the allocator handed back
+_POISON = bool(os.environ.get("GZ_POISON_SCRATCH"))
+
+
+def _ws(nfloats, device):
+    if _POISON:
+        return torch.full((nfloats,), float("nan"), device=device, dtype=torch.float32)
+    return torch.empty(nfloats, device=device, dtype=torch.float32)
+
+
 def _scratch(nbytes, device):
     """Split-K scratch of one launch (include/gz_ops.h: gz_*_workspace_bytes); None when the op is not split."""
     if not nbytes:
         return None, 0
-    return torch.empty(nbytes // 4, device=device, dtype=torch.float32), nbytes
+    return _ws(nbytes // 4, device), nbytes
 
 
 def _conv_fwd_raw(x, w, bias, geom, act, slope):
@@ -242,7 +253,7 @@ def _channel_sum_raw(g):
     if inner % 4:
         return g.sum([d for d in range(g.dim()) if d != 1])
     out = torch.empty(C, device=g.device, dtype=torch.float32)
-    ws = torch.empty(max(lib.gz_norm_workspace_bytes(N, C) // 4, 1), device=g.device, dtype=torch.float32)
+    ws = _ws(max(lib.gz_norm_workspace_bytes(N, C) // 4, 1), g.device)
     check(lib.gz_channel_sum(_p(g), _p(out), _p(ws), N, C, inner, _stream()), "channel_sum")
     return out
 
@@ -254,7 +265,7 @@ def _conv_wgrad_raw(x, g, geom, with_bias=False):
     _, K, OH, OW = g.shape
     dw = torch.empty((K, C, geom.kh, geom.kw), device=x.device, dtype=torch.float32)
     nbytes = lib.gz_conv2d_wgrad_workspace_bytes(N, C, H, W, K, OH, OW, geom.kh, geom.kw)
-    ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+    ws = _ws(max(nbytes // 4, 1), x.device)
     db = None
     if with_bias and lib.gz_conv2d_wgrad_fuses_bias(N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride, geom.pad):
         db = torch.empty(K, device=x.device, dtype=torch.float32)
@@ -583,7 +594,7 @@ def _coldot_raw(g, x):
     R, L = x.shape
     out = torch.empty(L, device=x.device, dtype=torch.float32)
     nbytes = lib.gz_coldot_workspace_bytes(R, L)
-    ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+    ws = _ws(max(nbytes // 4, 1), x.device)
     check(lib.gz_coldot(_p(g), _p(x), _p(out), _p(ws), nbytes, R, L, _stream()), "coldot")
     return out
 
@@ -650,7 +661,7 @@ def full_dot_conv(x, w):
 # normalisation + activation
 # ---------------------------------------------------------------------------
 def _norm_ws(x, N, C):
-    return torch.empty(max(lib.gz_norm_workspace_bytes(N, C) // 4, 1), device=x.device, dtype=torch.float32)
+    return _ws(max(lib.gz_norm_workspace_bytes(N, C) // 4, 1), x.device)
 
 
 class _BatchNormAct(torch.autograd.Function):
@@ -734,12 +745,9 @@ class _RowNormAct(torch.autograd.Function):
         N, C = x.shape[:2]
         inner = x.numel() // (N * C)
         coef = torch.empty(4 * N * C, device=x.device, dtype=torch.float32)
-        ws = _norm_ws(x, N, C)
-        st = _stream()
-        check(lib.gz_rownorm_stats(_p(x), _p(gamma), _p(beta), _p(coef), _p(ws), N, C, inner, eps, 0, 0, st),
-              "rownorm_stats")
         out = torch.empty_like(x)
-        check(lib.gz_norm_act_fwd(_p(x), _p(coef), _p(out), N, C, inner, 0, act, slope, st), "norm_act_fwd")
+        check(lib.gz_rownorm_act_fwd(_p(x), _p(gamma), _p(beta), _p(coef), _p(out), N, C, inner, eps, 0, 0, act, slope,
+                                     _stream()), "rownorm_act_fwd")
         ctx.save_for_backward(x, gamma, coef)
         ctx.cfg = (N, C, inner, act, slope)
         return out
@@ -946,7 +954,7 @@ def _conv3d_wgrad_raw(x, g, ks):
     _, K, OD, OH, OW = g.shape
     dw = torch.empty((K, C, ks, ks, ks), device=x.device, dtype=torch.float32)
     nbytes = lib.gz_conv3d_wgrad_workspace_bytes(N, C, K, OD, OH, OW, ks)
-    ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+    ws = _ws(max(nbytes // 4, 1), x.device)
     _timed_detail(lambda: "igemm3d<Wg> N%d C%d D%d K%d" % (N, C, D, K), 2.0 * N * OD * OH * OW * K * C * ks ** 3,
                   lambda: check(lib.gz_conv3d_wgrad(_p(x), _p(g), _p(dw), _p(ws), nbytes, N, C, D, H, W, K, OD, OH, OW,
                                                     ks, 2, 1, _stream()), "conv3d_wgrad"))
@@ -1022,12 +1030,9 @@ class _AdaINAct(torch.autograd.Function):
         N, C = x.shape[:2]
         inner = x.numel() // (N * C)
         coef = torch.empty(4 * N * C, device=x.device, dtype=torch.float32)
-        ws = _norm_ws(x, N, C)
-        st = _stream()
-        check(lib.gz_rownorm_stats(_p(x), _p(scale), _p(bias), _p(coef), _p(ws), N, C, inner, eps, 1, 1, st),
-              "rownorm_stats(adain)")
         out = torch.empty_like(x)
-        check(lib.gz_norm_act_fwd(_p(x), _p(coef), _p(out), N, C, inner, 0, act, slope, st), "norm_act_fwd")
+        check(lib.gz_rownorm_act_fwd(_p(x), _p(scale), _p(bias), _p(coef), _p(out), N, C, inner, eps, 1, 1, act, slope,
+                                     _stream()), "rownorm_act_fwd(adain)")
         ctx.save_for_backward(x, coef)
         ctx.cfg = (N, C, inner, act, slope)
         return out
@@ -1066,13 +1071,10 @@ class _AdaINActPacked(torch.autograd.Function):
             raise RuntimeError("adain_act_packed: expected scale|shift of shape [N, 2C]")
         inner = x.numel() // (N * C)
         coef = torch.empty(4 * N * C, device=x.device, dtype=torch.float32)
-        ws = _norm_ws(x, N, C)
-        st = _stream()
         sbp = sb.data_ptr()
-        check(lib.gz_rownorm_stats(_p(x), ctypes.c_void_p(sbp), ctypes.c_void_p(sbp + 4 * C), _p(coef), _p(ws), N, C,
-                                   inner, eps, 2, 1, st), "rownorm_stats(adain, packed)")
         out = torch.empty_like(x)
-        check(lib.gz_norm_act_fwd(_p(x), _p(coef), _p(out), N, C, inner, 0, act, slope, st), "norm_act_fwd")
+        check(lib.gz_rownorm_act_fwd(_p(x), ctypes.c_void_p(sbp), ctypes.c_void_p(sbp + 4 * C), _p(coef), _p(out), N, C,
+                                     inner, eps, 2, 1, act, slope, _stream()), "rownorm_act_fwd(adain, packed)")
         ctx.save_for_backward(x, coef)
         ctx.cfg = (N, C, inner, act, slope)
         return out

@@ -322,6 +322,35 @@ def test_adain_relu_fwd_bwd(shape):
     assert rel(sbp.grad[:, :C], sr.grad) < TOL and rel(sbp.grad[:, C:], br.grad) < TOL
 
 
+@pytest.mark.parametrize("inner_shape", [(8, 8, 8), (32, 32)])
+def test_row_norms_keep_their_digits_when_the_mean_dwarfs_the_spread(inner_shape):
+    """AdaIN / InstanceNorm rows with |mean| = 300 sigma (the output of a convolution over an all-positive, nearly
+    constant AdaIN+ReLU map looks like this): the statistics are two-pass, so the result stays within 1e-3 of fp64
+    -- a one-pass E[x^2] - mean^2 in fp32 is off by 1e-7 * 300^2 = 1 % of the variance here."""
+    F = _F()
+    N, C = 4, 8
+    x = (rnd(N, C, *inner_shape, seed=91) * 0.1 + 30.0)
+    s, b = rnd(N, C, seed=92).abs() + 0.5, rnd(N, C, seed=93) * 0.3
+    go = rnd(N, C, *inner_shape, seed=94)
+    x64 = x.double().requires_grad_()
+    flat = x64.reshape(N, C, -1)
+    xh = (flat - flat.mean(2, keepdim=True)) * torch.rsqrt(flat.var(2, keepdim=True) + 1e-8)
+    ref = torch.relu(s.double()[..., None] * xh + b.double()[..., None]).reshape(x.shape)
+    ref.backward(go.double())
+    xd = x.cuda().requires_grad_()
+    out = F.adain_act(xd, s.cuda(), b.cuda(), 1e-8, F.ACT_RELU)
+    out.backward(go.cuda())
+    assert rel(out, ref.float()) < TOL and rel(xd.grad, x64.grad.float()) < TOL
+    if len(inner_shape) == 2:
+        x64 = x.double().requires_grad_()
+        ref = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(x64), 0.2)
+        ref.backward(go.double())
+        xd = x.cuda().requires_grad_()
+        out = F.instance_norm_act(xd, None, None, 1e-5, F.ACT_LRELU, 0.2)
+        out.backward(go.cuda())
+        assert rel(out, ref.float()) < TOL and rel(xd.grad, x64.grad.float()) < TOL
+
+
 def test_rigid_resample_matches_oracle_and_indices_are_bit_exact():
     """int64 voxel indices (reference idx_a..idx_h) bit-exact; resampled features and their adjoint
     within 1e-3 (observed 1e-6)."""

@@ -58,7 +58,7 @@ def update_agreement(out, golden, init, lr):
 
 
 def compare(out, golden, tol, label, atol_scale=None, cond=None, cond_factor=10.0, final_abs=0.0,
-            grad_floor=0.0, final_tol=2e-4, report=False):
+            grad_floor=0.0, final_tol=2e-4, report=False, pair1_grad_floor=0.0):
     """Every recorded quantity within ``tol`` of the fixture, relative to the largest reference
     magnitude of that quantity (scalars: relative to max(|ref|, atol_scale), where atol_scale is
     the logit scale -- WGAN losses are differences of logit means).  Integer tensors (BatchNorm

@@ -86,12 +86,22 @@ def test_product_matches_stable_mask_fixture(expt):
     pre-activations they see, the closest is 3e-7 from zero in the reference run (``margin/`` in the fixture), and
     ONE element landing on the other side moves that layer's weight gradient by ~0.8 / sqrt(positions * channels)
     = 1.6e-3 -- the reference's own fp32-vs-fp64 pair shows exactly that (cond 5e-4 .. 7e-3 on the discriminator's
-    second-pair gradients, <= 1e-4 elsewhere).  Hence max(1e-3, 10 cond) per quantity, as everywhere else."""
+    second-pair gradients, <= 1e-4 elsewhere).  Hence max(1e-3, 10 cond) per quantity, as everywhere else.
+
+    Second-pair gradients, hologan only: 5e-2.  The discriminator's input gradient is a sum of nearly cancelling
+    contributions (|d loss / d image| = 0.07 against 15 inside the blocks), so ONE LeakyReLU decision of the G step
+    taken the other way moves the generator's gradients by up to 3.8e-2 (final_layer) -- measured in round 2 by
+    running this product with two split-K plans of the same ConvTranspose3d, i.e. a 1e-9 relative perturbation of
+    the volume: one plan lands on the reference's side of that 3e-7 margin, the other does not, every forward
+    quantity and every first-pair gradient agreeing to 1e-6 in both.  Which side an fp32 implementation lands on is
+    not a property the reference defines; the 1e-3 statement about BOTH steps' gradients is
+    test_hologan_step_gradients_with_pinned_masks, where the oracle takes the product's decisions."""
     inputs, golden, cond = load_golden(expt, "full", stable=True)
     step = build_product_step(expt, "full", stable=True)
     out = scenario.run_scenario(step, inputs, "cuda", full=False, set_alpha=set_alpha, stable=True)
     scale = float(np.abs(golden["probe/logits"]).max())
-    worst = compare(out, golden, TOL, f"hip {expt}/full/stable", atol_scale=scale, cond=cond, report=True)
+    worst = compare(out, golden, TOL, f"hip {expt}/full/stable", atol_scale=scale, cond=cond, report=True,
+                    pair1_grad_floor=5e-2 if expt == "hologan" else 0.0)
     print(f"{expt}/full/stable: worst {worst[3]} err {worst[1]:.2e} (bar {worst[2]:.2e})")
 
 

@@ -1,17 +1,18 @@
-"""F / Dg / Wg timing of HoloGAN's two ConvTranspose3d layers (bs 64): python tools/conv3d_bench.py [batch]"""
+"""Per-launch times of HoloGAN's two ConvTranspose3d layers (k3 s2 p1 op1) at bs 64: forward (= Dg kernel), input
+gradient (= F kernel), weight gradient.  python tools/conv3d_bench.py [bs]"""
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from lightning_gan_zoo_amd import functional as F  # noqa: E402
+from lightning_gan_zoo_amd import functional as F      # noqa: E402
 
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 
 
-def timeit(fn, n=10):
-    for _ in range(2):
+def timeit(fn, n=20):
+    for _ in range(3):
         fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -20,17 +21,20 @@ def timeit(fn, n=10):
         fn()
     e.record()
     torch.cuda.synchronize()
-    return s.elapsed_time(e) / n * 1e3
+    return s.elapsed_time(e) / n
 
 
-# ConvTranspose3d(Cin -> Cout), input D^3 -> (2D)^3; in conv terms K = Cin (feature side), C = Cout (image side)
-for name, cin, cout, d in [("512->128 4^3->8^3", 512, 128, 4), ("128->64 8^3->16^3", 128, 64, 8)]:
-    g = torch.randn(bs, cin, d, d, d, device="cuda")
-    w = torch.randn(cin, cout, 3, 3, 3, device="cuda") * 0.05
-    x = torch.randn(bs, cout, 2 * d, 2 * d, 2 * d, device="cuda")
-    fl = 2.0 * bs * d ** 3 * cin * cout * 27
-    td = timeit(lambda: F._conv3d_dgrad_raw(g, w, None, 0, 0.))
-    tf = timeit(lambda: F._conv3d_fwd_raw(x, w, None, 0, 0.))
-    tw = timeit(lambda: F._conv3d_wgrad_raw(x, g, 3))
-    print("%-20s GF %5.1f | Dg %6.1f us %5.1f TF | F %6.1f us %5.1f TF | Wg %6.1f us %5.1f TF"
-          % (name, fl / 1e9, td, fl / td / 1e6, tf, fl / tf / 1e6, tw, fl / tw / 1e6))
+print("bs", bs, {k: v for k, v in os.environ.items() if k.startswith("GZ_")})
+for name, cin, cout, d in (("block1", 512, 128, 4), ("block2", 128, 64, 8)):
+    x = torch.randn(bs, cin, d, d, d, device="cuda", requires_grad=True)
+    w = (torch.randn(cin, cout, 3, 3, 3, device="cuda") * 0.05).requires_grad_()
+    b = torch.zeros(cout, device="cuda", requires_grad=True)
+    flop = 2.0 * bs * (2 * d) ** 3 * cin * cout * 27 / 8
+    tf = timeit(lambda: F.conv_transpose3d(x.detach(), w.detach(), b.detach()))
+    y = F.conv_transpose3d(x, w, b)
+    gy = torch.randn_like(y)
+    tall = timeit(lambda: torch.autograd.grad(y, (x, w), gy, retain_graph=True))
+    tx = timeit(lambda: torch.autograd.grad(y, (x,), gy, retain_graph=True))
+    tw = timeit(lambda: torch.autograd.grad(y, (w,), gy, retain_graph=True))
+    print("%s %d->%d %d^3  GF %.1f | fwd %.3f ms %.1f TF | dx %.3f ms %.1f TF | dw %.3f ms %.1f TF | dx+dw %.3f" % (
+        name, cin, cout, d, flop / 1e9, tf, flop / tf / 1e9, tx, flop / tx / 1e9, tw, flop / tw / 1e9, tall))
