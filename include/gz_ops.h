@@ -170,6 +170,10 @@ int gz_mse_mean_bwd(const float* a, const float* b, const float* gloss, float* d
  * w = W / sigma(W), sigma = u^T W v:  out[r][l] = (g[r][l] - (sum_r rowdots[r]) u[r] v[l]) / sigma[0] with
  * rowdots[r] = <g[r], w[r]> (gz_rowdot). */
 int gz_vec_normalize(const float* x, float* out, float* out2, float* norm_out, int n, float eps, hipStream_t stream);
+/* gz_vec_normalize that also returns dot_out[0] = <x / max(||x||, eps), x>: with x = W v this is the power iteration's
+ * u update and sigma = u^T W v in one launch */
+int gz_vec_normalize_dot(const float* x, float* out, float* out2, float* dot_out, int n, float eps,
+                         hipStream_t stream);
 int gz_vec_dot(const float* a, const float* b, float* out, int n, hipStream_t stream);
 int gz_div_scalar(const float* x, const float* sigma, float* out, long long count, hipStream_t stream);
 int gz_spectral_norm_bwd(const float* g, const float* rowdots, const float* u, const float* v, const float* sigma,

@@ -67,20 +67,30 @@ __global__ __launch_bounds__(LT) void mse_mean_bwd_kernel(const float* __restric
 // out = out2 = x / max(||x||, eps);  norm_out[0] = ||x||.  One workgroup (n <= a few thousand).  `out` may be the
 // module's persistent buffer (updated in place like torch's spectral_norm does) and `out2` the private copy the
 // autograd node keeps; either may be NULL.
+// `dot_out` (optional): <normalised x, x>, i.e. spectral_norm's sigma = u^T (W v) when x = W v -- the separate
+// vec_dot launch of the power iteration folded in.
 __global__ __launch_bounds__(LT) void vec_normalize_kernel(const float* __restrict__ x, float* out, float* out2,
-                                                          float* __restrict__ norm_out, int n, float eps) {
+                                                          float* __restrict__ norm_out, float* __restrict__ dot_out,
+                                                          int n, float eps) {
     __shared__ float red[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += LT) s += x[i] * x[i];
     s = block_sum(s, red);
     const float nrm = sqrtf(s);
     const float inv = 1.f / fmaxf(nrm, eps);
+    float d = 0.f;
     for (int i = threadIdx.x; i < n; i += LT) {
-        const float q = x[i] * inv;
+        const float xi = x[i];      // read first: `out` may be x itself
+        const float q = xi * inv;
         if (out) out[i] = q;
         if (out2) out2[i] = q;
+        d += q * xi;
     }
     if (threadIdx.x == 0 && norm_out) norm_out[0] = nrm;
+    if (dot_out) {
+        d = block_sum(d, red);
+        if (threadIdx.x == 0) dot_out[0] = d;
+    }
 }
 
 // sigma[0] = <a, b>   (one workgroup)
@@ -173,7 +183,17 @@ int gz_mse_mean_bwd(const float* a, const float* b, const float* gloss, float* d
 int gz_vec_normalize(const float* x, float* out, float* out2, float* norm_out, int n, float eps, hipStream_t stream) {
     gz::clear_stale_error();
     if (n <= 0) return GZ_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL(vec_normalize_kernel, dim3(1), dim3(LT), 0, stream, x, out, out2, norm_out, n, eps);
+    hipLaunchKernelGGL(vec_normalize_kernel, dim3(1), dim3(LT), 0, stream, x, out, out2, norm_out, (float*)nullptr, n,
+                       eps);
+    return launch_status();
+}
+
+int gz_vec_normalize_dot(const float* x, float* out, float* out2, float* dot_out, int n, float eps,
+                         hipStream_t stream) {
+    gz::clear_stale_error();
+    if (n <= 0 || !dot_out) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(vec_normalize_kernel, dim3(1), dim3(LT), 0, stream, x, out, out2, (float*)nullptr, dot_out, n,
+                       eps);
     return launch_status();
 }
 

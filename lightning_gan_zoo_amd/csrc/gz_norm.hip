@@ -186,6 +186,9 @@ __global__ __launch_bounds__(PW_THREADS) void norm_act_apply_kernel(const float*
 // from a packed [N][2C] array: affine_per_row 0 / 1 / 2; unbiased = 1 uses var * n/(n-1)) and streams the row again while it is still in this CU's cache.  Replaces row_sums + row_finalize +
 // norm_act_apply: HoloGAN ran 25 such triples per optimizer-step pair, each launch costing its ~2.5 us dispatch gap
 // on top of ~5 us of work.
+// CACHE > 0: a lane keeps its (at most CACHE) float4 of the row in registers, so the row is read from memory once;
+// CACHE = 0 streams it three times (rows longer than 64 lanes x 16 float4 = 4096 floats).
+template <int CACHE>
 __global__ __launch_bounds__(PW_THREADS) void rownorm_act_fused_kernel(const float* __restrict__ x,
                                                                        const float* __restrict__ gamma,
                                                                        const float* __restrict__ beta,
@@ -206,8 +209,16 @@ __global__ __launch_bounds__(PW_THREADS) void rownorm_act_fused_kernel(const flo
         // mean^2 / var digits, and AdaIN rows do have |mean| >> sigma (a convolution of an all-positive, nearly
         // constant AdaIN+ReLU output): two summation orders of the SAME convolution then moved HoloGAN's
         // second-pair gradients by 3 %, which the reference's torch.var (two passes) does not do.
+        f32x4 c[CACHE > 0 ? CACHE : 1];
         float s[1] = {0.f};
-        if (live) {
+        if constexpr (CACHE > 0) {
+#pragma unroll
+            for (int i = 0; i < CACHE; ++i) {
+                const int q = l + i * g.lpr;
+                c[i] = (live && q < g.q4) ? p[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+                s[0] += (c[i].x + c[i].y) + (c[i].z + c[i].w);
+            }
+        } else if (live) {
             for (int q = l; q < g.q4; q += g.lpr) {
                 f32x4 v = p[q];
                 s[0] += (v.x + v.y) + (v.z + v.w);
@@ -217,7 +228,19 @@ __global__ __launch_bounds__(PW_THREADS) void rownorm_act_fused_kernel(const flo
         const double cnt = (double)inner;
         const float mean_f = (float)((double)s[0] / cnt);
         float d[2] = {0.f, 0.f};
-        if (live) {
+        if constexpr (CACHE > 0) {
+#pragma unroll
+            for (int i = 0; i < CACHE; ++i) {
+                if (live && l + i * g.lpr < g.q4) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float e = c[i][k] - mean_f;
+                        d[0] += e;
+                        d[1] += e * e;
+                    }
+                }
+            }
+        } else if (live) {
             for (int q = l; q < g.q4; q += g.lpr) {
                 f32x4 v = p[q];
 #pragma unroll
@@ -248,11 +271,24 @@ __global__ __launch_bounds__(PW_THREADS) void rownorm_act_fused_kernel(const flo
         }
         if (!out) continue;       // statistics only (gz_rownorm_stats)
         f32x4* po = reinterpret_cast<f32x4*>(out) + row * g.q4;
-        for (int q = l; q < g.q4; q += g.lpr) {
-            f32x4 v = p[q], o;
+        if constexpr (CACHE > 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = act_fwd(v[k] * sc + sh, act, slope);
-            po[q] = o;
+            for (int i = 0; i < CACHE; ++i) {
+                const int q = l + i * g.lpr;
+                if (q < g.q4) {
+                    f32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = act_fwd(c[i][k] * sc + sh, act, slope);
+                    po[q] = o;
+                }
+            }
+        } else {
+            for (int q = l; q < g.q4; q += g.lpr) {
+                f32x4 v = p[q], o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = act_fwd(v[k] * sc + sh, act, slope);
+                po[q] = o;
+            }
         }
     }
 }
@@ -389,6 +425,7 @@ __global__ __launch_bounds__(PW_THREADS) void norm_bwd_apply_kernel(const float*
 // First backward of a per-row normalisation in ONE launch: row sums of (dz, dz*xh), the two coefficients, the per-row
 // affine gradients (AdaIN) and dx = scale * (dz - k1 - xh*k2) from a second, cache-resident read of the row.
 // `sums` (optional) keeps the raw row sums for row_bwd_affine_kernel (per-channel gamma / beta).
+template <int CACHE>      // as rownorm_act_fused_kernel: dz and xh of the lane's float4 stay in registers
 __global__ __launch_bounds__(PW_THREADS) void rownorm_bwd_fused_kernel(const float* __restrict__ gout,
                                                                        const float* __restrict__ x,
                                                                        const float* __restrict__ coef,
@@ -410,7 +447,25 @@ __global__ __launch_bounds__(PW_THREADS) void rownorm_bwd_fused_kernel(const flo
         const f32x4* px = reinterpret_cast<const f32x4*>(x) + row * g.q4;
         const f32x4* pg = reinterpret_cast<const f32x4*>(gout) + row * g.q4;
         float s[2] = {0.f, 0.f};
-        if (live) {
+        f32x4 cdz[CACHE > 0 ? CACHE : 1], cxh[CACHE > 0 ? CACHE : 1];
+        if constexpr (CACHE > 0) {
+#pragma unroll
+            for (int i = 0; i < CACHE; ++i) {
+                const int q = l + i * g.lpr;
+                const bool in = live && q < g.q4;
+                const f32x4 xv = in ? px[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 gv = in ? pg[q] : f32x4{0.f, 0.f, 0.f, 0.f};     // gv = 0: nothing added to the sums
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dz = gv[k] * act_grad_z(xv[k] * sc + sh, act, slope);
+                    const float xh = (xv[k] - mean) * rstd;
+                    cdz[i][k] = dz;
+                    cxh[i][k] = xh;
+                    s[0] += dz;
+                    s[1] += dz * xh;
+                }
+            }
+        } else if (live) {
             for (int q = l; q < g.q4; q += g.lpr) {
                 f32x4 xv = px[q], gv = pg[q];
 #pragma unroll
@@ -436,15 +491,28 @@ __global__ __launch_bounds__(PW_THREADS) void rownorm_bwd_fused_kernel(const flo
         }
         if (!dx) continue;
         f32x4* po = reinterpret_cast<f32x4*>(dx) + row * g.q4;
-        for (int q = l; q < g.q4; q += g.lpr) {
-            f32x4 xv = px[q], gv = pg[q], o;
+        if constexpr (CACHE > 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float dz = gv[k] * act_grad_z(xv[k] * sc + sh, act, slope);
-                float xh = (xv[k] - mean) * rstd;
-                o[k] = sc * (dz - k1 - xh * k2);
+            for (int i = 0; i < CACHE; ++i) {
+                const int q = l + i * g.lpr;
+                if (q < g.q4) {
+                    f32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = sc * (cdz[i][k] - k1 - cxh[i][k] * k2);
+                    po[q] = o;
+                }
             }
-            po[q] = o;
+        } else {
+            for (int q = l; q < g.q4; q += g.lpr) {
+                f32x4 xv = px[q], gv = pg[q], o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float dz = gv[k] * act_grad_z(xv[k] * sc + sh, act, slope);
+                    float xh = (xv[k] - mean) * rstd;
+                    o[k] = sc * (dz - k1 - xh * k2);
+                }
+                po[q] = o;
+            }
         }
     }
 }
@@ -589,6 +657,20 @@ static bool norm_shape_ok(int N, int C, int inner) {
            (long long)N * C * inner / 4 < (1ll << 31);
 }
 
+static void launch_rownorm_fused(const float* x, const float* gamma, const float* beta, float* coef, float* out,
+                                 const RowGeom& g, int C, int inner, float eps, int affine_per_row, int unbiased,
+                                 int act, float slope, hipStream_t stream) {
+    const int per_lane = (g.q4 + g.lpr - 1) / g.lpr;      // float4 per lane
+#define GZ_RN(CACHE)                                                                                               \
+    hipLaunchKernelGGL(rownorm_act_fused_kernel<CACHE>, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, gamma, \
+                       beta, coef, out, g, C, inner, eps, affine_per_row, unbiased, act, slope)
+    if (per_lane <= 1) GZ_RN(1);
+    else if (per_lane <= 4) GZ_RN(4);
+    else if (per_lane <= 16) GZ_RN(16);
+    else GZ_RN(0);
+#undef GZ_RN
+}
+
 }  // namespace gz
 
 using namespace gz;
@@ -649,8 +731,7 @@ int gz_rownorm_stats(const float* x, const float* gamma, const float* beta, floa
     if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
     (void)workspace;
     RowGeom g = row_geom((long long)N * C, inner);
-    hipLaunchKernelGGL(rownorm_act_fused_kernel, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, gamma, beta, coef,
-                       (float*)nullptr, g, C, inner, eps, affine_per_row, unbiased, ACT_NONE, 0.f);
+    launch_rownorm_fused(x, gamma, beta, coef, nullptr, g, C, inner, eps, affine_per_row, unbiased, ACT_NONE, 0.f, stream);
     return launch_status();
 }
 
@@ -660,8 +741,7 @@ int gz_rownorm_act_fwd(const float* x, const float* gamma, const float* beta, fl
     gz::clear_stale_error();
     if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
     RowGeom g = row_geom((long long)N * C, inner);
-    hipLaunchKernelGGL(rownorm_act_fused_kernel, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, gamma, beta, coef,
-                       out, g, C, inner, eps, affine_per_row, unbiased, act, slope);
+    launch_rownorm_fused(x, gamma, beta, coef, out, g, C, inner, eps, affine_per_row, unbiased, act, slope, stream);
     return launch_status();
 }
 
@@ -685,9 +765,17 @@ int gz_norm_act_bwd(const float* gout, const float* x, const float* coef, float*
     static const bool unfused = getenv("GZ_NORM_UNFUSED") != nullptr;      // experiment: the three-launch path
     if (!per_channel && !unfused) {
         const bool channel_affine = !affine_per_row && (dgamma || dbeta);
-        hipLaunchKernelGGL(rownorm_bwd_fused_kernel, dim3(row_grid(rg)), dim3(PW_THREADS), 0, stream, gout, x, coef, dx,
-                           dgamma, dbeta, channel_affine ? (f32x2*)workspace : (f32x2*)nullptr, rg, C, inner,
-                           affine_per_row, unbiased, act, slope);
+        static const int max_cache = getenv("GZ_NORM_BWD_CACHE") ? atoi(getenv("GZ_NORM_BWD_CACHE")) : 4;
+        const int per_lane = (rg.q4 + rg.lpr - 1) / rg.lpr;
+#define GZ_RB(CACHE)                                                                                                  \
+    hipLaunchKernelGGL(rownorm_bwd_fused_kernel<CACHE>, dim3(row_grid(rg)), dim3(PW_THREADS), 0, stream, gout, x, coef, \
+                       dx, dgamma, dbeta, channel_affine ? (f32x2*)workspace : (f32x2*)nullptr, rg, C, inner,          \
+                       affine_per_row, unbiased, act, slope)
+        if (per_lane <= 1) GZ_RB(1);
+        else if (per_lane <= 4 && max_cache >= 4) GZ_RB(4);
+        else if (per_lane <= 16 && max_cache >= 16) GZ_RB(16);
+        else GZ_RB(0);
+#undef GZ_RB
         if (channel_affine)
             hipLaunchKernelGGL(row_bwd_affine_kernel, dim3(C), dim3(64), 0, stream, (const f32x2*)workspace, dgamma,
                                dbeta, N, C);

@@ -771,8 +771,9 @@ class _RowNormActBwd(torch.autograd.Function):
         N, C, inner, act, slope = cfg
         gout = _req(gout)
         dx = torch.empty_like(x)
-        dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
-        dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
+        # affine=False (HoloGAN's discriminator): no per-channel reduction over the row sums at all
+        dgamma = torch.empty(C, device=x.device, dtype=torch.float32) if gamma is not None else None
+        dbeta = torch.empty(C, device=x.device, dtype=torch.float32) if gamma is not None else None
         kbuf = torch.empty(2 * N * C, device=x.device, dtype=torch.float32)
         ws = _norm_ws(x, N, C)
         check(lib.gz_norm_act_bwd(_p(gout), _p(x), _p(coef), _p(dx), _p(dgamma), _p(dbeta), _p(ws), _p(kbuf), N, C,
@@ -1192,12 +1193,12 @@ class _SpectralNormWeight(torch.autograd.Function):
             v_raw = _coldot_raw(u, Wm)                              # W^T u
             check(lib.gz_vec_normalize(_p(v_raw), _p(v), _p(vs), None, L, eps, st), "vec_normalize(v)")
             wv = _rowdot_raw(Wm, vs, True)                          # W v
-            check(lib.gz_vec_normalize(_p(wv), _p(u), _p(us), None, R, eps, st), "vec_normalize(u)")
+            check(lib.gz_vec_normalize_dot(_p(wv), _p(u), _p(us), _p(sigma), R, eps, st), "vec_normalize(u), sigma")
         else:
             us.copy_(u)
             vs.copy_(v)
             wv = _rowdot_raw(Wm, vs, True)
-        check(lib.gz_vec_dot(_p(us), _p(wv), _p(sigma), R, st), "vec_dot(sigma)")
+            check(lib.gz_vec_dot(_p(us), _p(wv), _p(sigma), R, st), "vec_dot(sigma)")
         w = torch.empty_like(W)
         check(lib.gz_div_scalar(_p(W), _p(sigma), _p(w), W.numel(), st), "div_scalar")
         ctx.save_for_backward(w, us, vs, sigma)
