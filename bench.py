@@ -251,11 +251,21 @@ def run_rank(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    # GZ_REHEARSE_ONE_GPU=1: every rank drives cuda:0 and the collectives run on gloo (RCCL refuses two ranks on one
+    # device).  It exists to run the whole N > 1 code path -- rank spawn, gradient hooks on HIP tensors, deferred
+    # optimizer steps, barrier / max-over-ranks timing, the JSON line -- on a 1-GPU box; its number is meaningless and
+    # the line says so ("rehearsal").
+    rehearsal = bool(os.environ.get("GZ_REHEARSE_ONE_GPU")) and world > 1
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from lightning_gan_zoo_amd import functional as F
 
@@ -309,6 +319,8 @@ def run_rank(args):
     }
     if world > 1:
         out["rccl_ranks"] = dist.get_world_size()
+        if rehearsal:
+            out["rehearsal"] = "all ranks on cuda:0, gloo transport: code-path check only, not a measurement"
         sync = trainer.grad_sync
         out["grad_exchange"] = {"buckets": [[(e - s) * 4 for s, e, _, _ in fg.buckets] for fg in sync.flats],
                                 **sync.stats}

@@ -54,3 +54,28 @@ def test_gradsync_on_rccl_single_rank_matches_plain_trainer():
     finally:
         dist.destroy_process_group()
         os.environ.pop("GZ_DDP_ALWAYS_REDUCE", None)
+
+
+def test_two_rank_bench_rehearsal_on_one_gpu():
+    """``bench.py --gpus 2`` end to end on this 1-GPU box: the parent spawns the ranks, both drive cuda:0 and the
+    collectives run on gloo (GZ_REHEARSE_ONE_GPU).  Everything of the N > 1 path except RCCL itself executes on HIP
+    tensors: gradient hooks, bucketed exchange, deferred optimizer steps, barrier + max-over-ranks timing, one JSON
+    line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GZ_REHEARSE_ONE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--reps", "1", "--batch", "32", "--no-cpu-baseline", "--no-kernel-timer"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and len(out["per_rank_ms_per_step"]) == 2
+    assert out["config"]["global_batch"] == 64 and out["scaling"] == "weak" and "rehearsal" in out
+    ex = out["grad_exchange"]
+    assert ex["buckets_from_hooks"] > 0 and ex["buckets_after_backward"] == 0
