@@ -498,13 +498,21 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # GZ_REHEARSE_ONE_GPU=1 (tests, 1-GPU boxes): all ranks on cuda:0, collectives on gloo -- RCCL refuses two ranks on
+    # one device; everything else of the multi-rank path runs as it would on N GPUs
+    rehearsal = bool(os.environ.get("GZ_REHEARSE_ONE_GPU")) and world > 1
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     sync = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     module = locate(cfg.model.lm["_target_"])(cfg, logging_dir="output").to(device)
     if world > 1:
         from .ddp import GradSync

@@ -79,3 +79,27 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     assert out["config"]["global_batch"] == 64 and out["scaling"] == "weak" and "rehearsal" in out
     ex = out["grad_exchange"]
     assert ex["buckets_from_hooks"] > 0 and ex["buckets_after_backward"] == 0
+
+
+def test_two_rank_training_run_rehearsal_on_one_gpu(tmp_path):
+    """``python -m torch.distributed.run --nproc-per-node 2 -m lightning_gan_zoo_amd.run_network +expt=dc_gan ...`` on
+    one GPU (GZ_REHEARSE_ONE_GPU): sharded synthetic data, gradient exchange from the backward hooks, rank 0 alone
+    writes the Lightning-format checkpoint, both ranks leave together."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ck = str(tmp_path / "ckpt")
+    env = dict(os.environ, GZ_REHEARSE_ONE_GPU="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), "-m", "lightning_gan_zoo_amd.run_network", "+expt=dc_gan",
+           "dataset=synthetic", "train.features_gen=8", "train.features_disc=8", "model.noise_dim=16",
+           "train.batch_size=8", "train.ckpt_dir=" + ck, "log_every=1000", "max_steps=4"]
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert os.listdir(ck) == ["step=4.ckpt"]
+    blob = torch.load(os.path.join(ck, "step=4.ckpt"), weights_only=False)
+    assert blob["global_step"] == 4
+    assert all(torch.isfinite(v).all() for v in blob["state_dict"].values() if v.is_floating_point())
