@@ -270,7 +270,7 @@ int gz_upsample2_bwd(const float* gy, float* gx, long long planes, int H, int W,
 int gz_u8hwc_to_nchw(const unsigned char* in, float* out, int N, int H, int W, int C, float mean, float std,
                      hipStream_t stream);
 
-/* ---- fused multi-tensor optimizer steps (the `optimiser` nodes of conf/expt/*.yaml) -------------------------
+/* ---- fused multi-tensor optimizer steps (the `optimiser` nodes of conf/expt/<name>.yaml) -------------------------
  * `count` <= GZ_OPT_MAX_TENSORS tensors per call (host arrays of device pointers and element counts);
  * grads are multiplied by grad_scale first (1/world for data-parallel means).  Formulas are torch.optim's
  * single-tensor ones (no weight decay, no amsgrad / momentum / centered). */

@@ -1790,8 +1790,8 @@ __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(type
     for (int kc = kc0; kc < kc1; ++kc) {
         const int cur = (kc - kc0) & 1;
         const bool more = kc + 1 < kc1;
-#if !defined(GZ_EXP_NOLOAD) && !defined(GZ_EXP_NOISSUE)   // timing experiments only (wrong results)
         constexpr bool INTERLEAVE = GZ_IGEMM_INTERLEAVE && AL::DMA && BL::DMA;
+#if !defined(GZ_EXP_NOLOAD) && !defined(GZ_EXP_NOISSUE)   // timing experiments only (wrong results)
         if (more && !INTERLEAVE) {
             // the other LDS buffer was last read in the previous iteration, behind its closing barrier
 #ifdef GZ_EXP_SAMECHUNK      // timing experiment: always re-load chunk kc0 (cache-resident)

@@ -365,6 +365,7 @@ class _ConvF(torch.autograd.Function):
             if stats is None:
                 stats = torch.empty(0, device=x.device)
             ctx.mark_non_differentiable(stats)
+            ctx.set_materialize_grads(False)      # else every backward launches a zero fill for the statistics' "gradient"
             return y, stats
         y = _conv_fwd_raw(x, w, bias, geom, act, slope)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
@@ -372,6 +373,8 @@ class _ConvF(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, *_stats_grad):
+        if gy is None:
+            return (None,) * 7
         x, w, y = ctx.saved_tensors
         geom = ctx.geom
         if ctx.act != ACT_NONE:
@@ -423,6 +426,7 @@ class _ConvDg(torch.autograd.Function):
             if stats is None:
                 stats = torch.empty(0, device=g.device)
             ctx.mark_non_differentiable(stats)
+            ctx.set_materialize_grads(False)
             return x, stats
         x = _conv_dgrad_raw(g, w, bias, geom, hw, act, slope)
         ctx.save_for_backward(g, w, x if act != ACT_NONE else None)
@@ -430,6 +434,8 @@ class _ConvDg(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v, *_stats_grad):
+        if v is None:
+            return (None,) * 8
         g, w, x = ctx.saved_tensors
         geom = ctx.geom
         if ctx.act != ACT_NONE:
