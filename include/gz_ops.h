@@ -239,6 +239,8 @@ int gz_rowdot(const float* a, const float* b, float* y, int R, int L, int b_broa
 /* out[r][:] = s[r] * x[r][:] (+ t[r] * x2[r][:], t = 1 - s when one_minus_s else s2); x_broadcast: x is [L] */
 int gz_rowscale(const float* x, const float* s, const float* x2, const float* s2, float* out, int R, int L,
                 int x_broadcast, int one_minus_s, hipStream_t stream);
+/* out[l] = sum_r x[r][l]  (nn.Linear's bias gradient: core/models/hologan_discriminator.py:41-50, hologan_generator.py:11) */
+int gz_colsum(const float* x, float* out, int R, int L, hipStream_t stream);
 /* out[l] = sum_r g[r] * x[r][l] */
 size_t gz_coldot_workspace_bytes(int R, int L);
 int gz_coldot(const float* g, const float* x, float* out, float* workspace, size_t ws_bytes, int R, int L,

@@ -97,11 +97,37 @@ static int grid_for(long long items) {
     return (int)b;
 }
 
+// out[l] = sum_r x[r][l]: the bias gradient of an nn.Linear (R = batch rows, at most a few hundred).  A lane owns a
+// column; the 16 lane-groups of a workgroup take every 16th row and meet in LDS in a fixed order.
+__global__ __launch_bounds__(MT) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int L) {
+    __shared__ float part[16][17];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float s = 0.f;
+    if (c < L)
+        for (int r = rg; r < R; r += MT / 16) s += x[(long long)r * L + c];
+    part[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && c < L) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[i][cl];
+        out[c] = t;
+    }
+}
+
 }  // namespace gz
 
 using namespace gz;
 
 extern "C" {
+
+int gz_colsum(const float* x, float* out, int R, int L, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (R <= 0 || L <= 0) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(colsum_kernel, dim3((L + 15) / 16), dim3(MT), 0, stream, x, out, R, L);
+    return launch_status();
+}
 
 int gz_rowdot(const float* a, const float* b, float* y, int R, int L, int b_broadcast, hipStream_t stream) {
     gz::clear_stale_error();

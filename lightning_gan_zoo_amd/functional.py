@@ -1131,7 +1131,10 @@ class _LinearAct(torch.autograd.Function):
                 g = g * (d if d is not None else torch.where(out > 0, 1.0, ctx.slope))
         dx = gemm(g, weight) if ctx.needs_input_grad[0] else None
         dw = gemm(g, x, trans_a=True) if ctx.needs_input_grad[1] else None
-        db = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(g.shape[1], device=g.device, dtype=torch.float32)
+            check(lib.gz_colsum(_p(g), _p(db), g.shape[0], g.shape[1], _stream()), "colsum")
         return dx, dw, db, None, None
 
 

@@ -471,6 +471,13 @@ def test_linear_act_fwd_bwd():
         out.pow(2).sum().backward()
         for got, want in ((out, ref), (xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
             assert rel(got, want) < TOL
+    # the logit head's shapes: one output column, and a batch longer than the 16 row groups of colsum_kernel
+    x, w, b = rnd(70, 64, seed=99), rnd(1, 64, seed=100, scale=0.2), rnd(1, seed=101)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    TF.linear(xr, wr, br).pow(2).sum().backward()
+    xd, wd, bd = x.cuda().requires_grad_(), w.cuda().requires_grad_(), b.cuda().requires_grad_()
+    F.linear_act(xd, wd, bd).pow(2).sum().backward()
+    assert rel(bd.grad, br.grad) < TOL and rel(wd.grad, wr.grad) < TOL
 
 
 def test_hologan_ext128_matches_oracle_extension():
