@@ -231,6 +231,9 @@ int gz_rownorm_act_bwd2(const float* gout, const float* v, const float* x, const
 /* dx = g * act'(.) with the derivative expressed through the activation OUTPUT (LeakyReLU, ReLU, tanh) */
 int gz_act_bwd(const float* g, const float* out, float* dx, long long count, int act, float slope,
                hipStream_t stream);
+/* res = v * g * (-2 out): the derivative of gz_act_bwd's tanh result g * (1 - out^2) with respect to `out`, contracted
+ * with v (second-order backward through a fused tanh epilogue) */
+int gz_tanh_bwd2(const float* v, const float* g, const float* out, float* res, long long count, hipStream_t stream);
 
 /* ---- row helpers (last discriminator layer, gradient-penalty tail, WGAN clip) -----------------
  * matrices are [R][L] row-major with L % 4 == 0. */

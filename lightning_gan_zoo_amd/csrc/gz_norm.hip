@@ -633,6 +633,21 @@ __global__ __launch_bounds__(PW_THREADS) void act_bwd_kernel(const float* __rest
     }
 }
 
+// d/d(out) of g * (1 - out^2) contracted with v: the tanh leg of a second-order backward
+__global__ __launch_bounds__(PW_THREADS) void tanh_bwd2_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                               const float* __restrict__ out, float* __restrict__ res,
+                                                               long long total4) {
+    const long long stride = (long long)gridDim.x * PW_THREADS;
+    for (long long i = (long long)blockIdx.x * PW_THREADS + threadIdx.x; i < total4; i += stride) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(v)[i], b = reinterpret_cast<const f32x4*>(g)[i];
+        const f32x4 o = reinterpret_cast<const f32x4*>(out)[i];
+        f32x4 r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = a[q] * b[q] * (-2.f * o[q]);
+        reinterpret_cast<f32x4*>(res)[i] = r;
+    }
+}
+
 static int ew_grid(long long total4) {
     long long b = (total4 + PW_THREADS - 1) / PW_THREADS;
     if (b > 256 * 8) b = 256 * 8;
@@ -824,6 +839,14 @@ int gz_act_bwd(const float* g, const float* out, float* dx, long long count, int
     if (count <= 0 || (count & 3)) return GZ_ERR_BAD_SHAPE;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(count / 4)), dim3(PW_THREADS), 0, stream, g, out, dx, count / 4,
                        act, slope);
+    return launch_status();
+}
+
+int gz_tanh_bwd2(const float* v, const float* g, const float* out, float* res, long long count, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (count <= 0 || (count & 3)) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(tanh_bwd2_kernel, dim3(ew_grid(count / 4)), dim3(PW_THREADS), 0, stream, v, g, out, res,
+                       count / 4);
     return launch_status();
 }
 

@@ -248,6 +248,7 @@ def _conv_dgrad_raw(g, w, bias, geom, hw, act, slope):
 
 def _channel_sum_raw(g):
     """g.sum over every dimension but the channel (the bias gradient of a convolution), no autograd."""
+    g = _req(g)
     N, C = g.shape[0], g.shape[1]
     inner = g.numel() // (N * C)
     if inner % 4:
@@ -256,6 +257,21 @@ def _channel_sum_raw(g):
     ws = _ws(max(lib.gz_norm_workspace_bytes(N, C) // 4, 1), g.device)
     check(lib.gz_channel_sum(_p(g), _p(out), _p(ws), N, C, inner, _stream()), "channel_sum")
     return out
+
+
+class _ChannelSum(torch.autograd.Function):
+    """Bias gradient while a graph is being recorded (double-backward branches): the same kernel, differentiable
+    (its adjoint broadcasts the incoming vector back over n and the map)."""
+
+    @staticmethod
+    def forward(ctx, g):
+        ctx.shape = tuple(g.shape)
+        return _channel_sum_raw(g)
+
+    @staticmethod
+    def backward(ctx, v):
+        view = (1, -1) + (1,) * (len(ctx.shape) - 2)
+        return v.reshape(view).expand(ctx.shape)
 
 
 def _conv_wgrad_raw(x, g, geom, with_bias=False):
@@ -313,7 +329,13 @@ class _ActBwd(torch.autograd.Function):
         gg = _ActBwd.apply(v, out, ctx.act, ctx.slope) if ctx.needs_input_grad[0] else None
         go = None
         if ctx.needs_input_grad[1] and ctx.act == ACT_TANH:
-            go = v * g * (-2.0 * out)   # d/d(out) of g*(1-out^2); only tanh has a non-constant mask
+            # d/d(out) of g*(1-out^2); only tanh has a non-constant mask
+            if out.numel() % 4 == 0:
+                v, g, o = _req(v), _req(g), _req(out)
+                go = torch.empty_like(o)
+                check(lib.gz_tanh_bwd2(_p(v), _p(g), _p(o), _p(go), o.numel(), _stream()), "tanh_bwd2")
+            else:
+                go = v * g * (-2.0 * out)
         return gg, go, None, None
 
 
@@ -391,7 +413,7 @@ class _ConvF(torch.autograd.Function):
         elif ctx.needs_input_grad[1]:
             dw = _ConvWg.apply(x, gy, geom)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = gy.sum((0, 2, 3))
+            db = _ChannelSum.apply(gy)
         return dx, dw, db, None, None, None, None
 
     @staticmethod
@@ -455,7 +477,7 @@ class _ConvDg(torch.autograd.Function):
         elif ctx.needs_input_grad[1]:
             dw = _ConvWg.apply(v, g, geom)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = v.sum((0, 2, 3))
+            db = _ChannelSum.apply(v)
         return dg, dw, db, None, None, None, None, None
 
 
@@ -986,7 +1008,7 @@ class _Conv3DDg(torch.autograd.Function):
         dw = _Conv3DWg.apply(v, g, w.shape[2]) if ctx.needs_input_grad[1] else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = v.sum((0, 2, 3, 4)) if torch.is_grad_enabled() else _channel_sum_raw(v)
+            db = _ChannelSum.apply(v) if torch.is_grad_enabled() else _channel_sum_raw(v)
         return dg, dw, db
 
 

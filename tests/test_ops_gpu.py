@@ -779,3 +779,22 @@ def test_batchnorm_eval_mode_backward(act):
     yd.backward(go.cuda())
     assert rel(yd, y) < TOL and rel(xd.grad, xr.grad) < TOL and rel(gd.grad, gr.grad) < TOL and rel(bd.grad, br.grad) < TOL
     assert int(nbt) == 0
+
+
+def test_second_order_through_fused_tanh_and_bias():
+    """create_graph=True through conv_transpose2d(+bias, tanh epilogue): the double backward of the activation
+    (gz_tanh_bwd2) and the differentiable bias gradient (_ChannelSum) against torch's own double backward."""
+    F = _F()
+    x, w, b = rnd(4, 8, 8, 8, seed=201), rnd(8, 4, 4, 4, seed=202, scale=0.2), rnd(4, seed=203)
+    outs = []
+    for dev in ("cpu", "cuda"):
+        xd, wd, bd = (t.detach().clone().to(dev).requires_grad_() for t in (x, w, b))
+        if dev == "cpu":
+            y = torch.tanh(TF.conv_transpose2d(xd, wd, bd, 2, 1))
+        else:
+            y = F.conv_transpose2d(xd, wd, bd, F.K4S2P1, F.ACT_TANH)
+        gx, gb = torch.autograd.grad(y.pow(2).sum(), (xd, bd), create_graph=True)
+        (gx.pow(2).sum() + gb.pow(2).sum()).backward()
+        outs.append([t.detach().cpu() for t in (y, gx, gb, xd.grad, wd.grad, bd.grad)])
+    for got, want in zip(outs[1], outs[0]):
+        assert rel(got, want) < TOL
