@@ -215,6 +215,13 @@ int gz_rownorm_stats(const float* x, const float* gamma, const float* beta, floa
 int gz_rownorm_act_fwd(const float* x, const float* gamma, const float* beta, float* coef, float* out, int N, int C,
                        int inner, float eps, int affine_per_row, int unbiased, int act, float slope,
                        hipStream_t stream);
+/* AdaIN + activation of a constant shared by all samples (HoloGAN's learned 4^3 volume, hologan_generator.py:141
+ * `self.x.repeat(batch, ...)`): x is [C][inner], sb the packed [N][2C] scale | shift, out / coef as for N*C rows.
+ * Backward: dx [C][inner] (summed over the samples), dsb [N][2C]; inner <= 1024. */
+int gz_adain_const_fwd(const float* x, const float* sb, float* coef, float* out, int N, int C, int inner, float eps,
+                       int act, float slope, hipStream_t stream);
+int gz_adain_const_bwd(const float* gout, const float* x, const float* coef, float* dx, float* dsb, int N, int C,
+                       int inner, int act, float slope, hipStream_t stream);
 /* out = act(x * scale + shift) */
 int gz_norm_act_fwd(const float* x, const float* coef, float* out, int N, int C, int inner, int per_channel,
                     int act, float slope, hipStream_t stream);

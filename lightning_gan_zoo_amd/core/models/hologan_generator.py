@@ -149,7 +149,7 @@ class Generator(nn.Module):
                 view_in = self.sample_view(n)
             minv = draw_on_host(lambda: view_inverse_matrices(view_in).reshape(n, 16).contiguous(), dev)
 
-        h = F.adain_act_packed(self.x.repeat(n, 1, 1, 1, 1), self.zMapping(z), 1e-8, F.ACT_RELU)
+        h = F.adain_const_act(self.x, self.zMapping(z), 1e-8, F.ACT_RELU)     # = AdaIN(self.x.repeat(n, ...)), reference :141
         h = self.block1(h, z)
         h = self.block2(h, z)
         h = F.rigid_resample(h, minv)                                 # [N, 16*C, 16, 16]

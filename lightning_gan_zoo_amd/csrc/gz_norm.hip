@@ -195,7 +195,8 @@ __global__ __launch_bounds__(PW_THREADS) void rownorm_act_fused_kernel(const flo
                                                                        float* __restrict__ coef,
                                                                        float* __restrict__ out, RowGeom g, int C,
                                                                        int inner, float eps, int affine_per_row,
-                                                                       int unbiased, int act, float slope) {
+                                                                       int unbiased, int act, float slope,
+                                                                       int x_rows) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * PW_THREADS + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * PW_THREADS) >> 6;
@@ -203,7 +204,9 @@ __global__ __launch_bounds__(PW_THREADS) void rownorm_act_fused_kernel(const flo
     for (long long row0 = (long long)wave * g.rpw; row0 < g.rows; row0 += (long long)nwaves * g.rpw) {
         const long long row = row0 + sub;
         const bool live = row < g.rows;
-        const f32x4* p = reinterpret_cast<const f32x4*>(x) + row * g.q4;
+        // x_rows > 0: x has only x_rows rows, shared by every sample (HoloGAN's learned constant, which the reference
+        // materialises with .repeat(batch, ...), hologan_generator.py:141)
+        const f32x4* p = reinterpret_cast<const f32x4*>(x) + (x_rows > 0 ? row % x_rows : row) * g.q4;
         // Two passes over the (cache-resident) row: the mean first, then the centred second moment with the
         // correction term of the "corrected two-pass" formula.  The one-pass E[x^2] - mean^2 of row_sums_kernel loses
         // mean^2 / var digits, and AdaIN rows do have |mean| >> sigma (a convolution of an all-positive, nearly
@@ -517,6 +520,68 @@ __global__ __launch_bounds__(PW_THREADS) void rownorm_bwd_fused_kernel(const flo
     }
 }
 
+// First backward of AdaIN over a constant shared by every sample (x: [C][inner], gout: [N][C][inner]): the sub-wave
+// that owns channel c walks the N samples, writes each sample's packed (d scale | d shift) and accumulates
+// d x[c] = sum_n scale (dz - k1 - xh k2) in registers -- the framework spelling was a [N, C, inner] dx plus a sum.
+__global__ __launch_bounds__(PW_THREADS) void adain_const_bwd_kernel(const float* __restrict__ gout,
+                                                                     const float* __restrict__ x,
+                                                                     const float* __restrict__ coef,
+                                                                     float* __restrict__ dx, float* __restrict__ dsb,
+                                                                     RowGeom g, int N, int C, int inner, int act,
+                                                                     float slope) {
+    constexpr int CACHE = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * PW_THREADS + threadIdx.x) >> 6;
+    const int sub = lane / g.lpr, l = lane % g.lpr;
+    const int c = wave * g.rpw + sub;          // g.rows = C here
+    const bool live = c < C;
+    const int rows = N * C;
+    const f32x4* px = reinterpret_cast<const f32x4*>(x) + (long long)(live ? c : 0) * g.q4;
+    f32x4 xv[CACHE], acc[CACHE];
+#pragma unroll
+    for (int i = 0; i < CACHE; ++i) {
+        const int q = l + i * g.lpr;
+        xv[i] = (live && q < g.q4) ? px[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int n = 0; n < N; ++n) {
+        const int r = n * C + (live ? c : 0);
+        const float sc = coef[r], sh = coef[rows + r], mean = coef[2 * rows + r], rstd = coef[3 * rows + r];
+        const f32x4* pg = reinterpret_cast<const f32x4*>(gout) + (long long)r * g.q4;
+        f32x4 dz[CACHE], xh[CACHE];
+        float s[2] = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < CACHE; ++i) {
+            const int q = l + i * g.lpr;
+            const f32x4 gv = (live && q < g.q4) ? pg[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                dz[i][k] = gv[k] * act_grad_z(xv[i][k] * sc + sh, act, slope);
+                xh[i][k] = (xv[i][k] - mean) * rstd;
+                s[0] += dz[i][k];
+                s[1] += dz[i][k] * xh[i][k];
+            }
+        }
+        sub_reduce<2>(s, g.lpr);
+        const float k1 = s[0] / (float)inner, k2 = s[1] / (float)(inner > 1 ? inner - 1 : inner);
+        if (live && l == 0) {
+            dsb[(long long)n * 2 * C + c] = s[1];
+            dsb[(long long)n * 2 * C + C + c] = s[0];
+        }
+#pragma unroll
+        for (int i = 0; i < CACHE; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[i][k] += sc * (dz[i][k] - k1 - xh[i][k] * k2);
+    }
+    if (!live) return;
+    f32x4* po = reinterpret_cast<f32x4*>(dx) + (long long)c * g.q4;
+#pragma unroll
+    for (int i = 0; i < CACHE; ++i) {
+        const int q = l + i * g.lpr;
+        if (q < g.q4) po[q] = acc[i];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // double backward (per-row statistics only: InstanceNorm).  With g = gout*act'(z) and
 // v = dL/d(dx):   sums5[row] = (sum v, sum g, sum g*xh, sum v*xh, sum v*g)
@@ -674,11 +739,11 @@ static bool norm_shape_ok(int N, int C, int inner) {
 
 static void launch_rownorm_fused(const float* x, const float* gamma, const float* beta, float* coef, float* out,
                                  const RowGeom& g, int C, int inner, float eps, int affine_per_row, int unbiased,
-                                 int act, float slope, hipStream_t stream) {
+                                 int act, float slope, hipStream_t stream, int x_rows = 0) {
     const int per_lane = (g.q4 + g.lpr - 1) / g.lpr;      // float4 per lane
 #define GZ_RN(CACHE)                                                                                               \
     hipLaunchKernelGGL(rownorm_act_fused_kernel<CACHE>, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, gamma, \
-                       beta, coef, out, g, C, inner, eps, affine_per_row, unbiased, act, slope)
+                       beta, coef, out, g, C, inner, eps, affine_per_row, unbiased, act, slope, x_rows)
     if (per_lane <= 1) GZ_RN(1);
     else if (per_lane <= 4) GZ_RN(4);
     else if (per_lane <= 16) GZ_RN(16);
@@ -757,6 +822,27 @@ int gz_rownorm_act_fwd(const float* x, const float* gamma, const float* beta, fl
     if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
     RowGeom g = row_geom((long long)N * C, inner);
     launch_rownorm_fused(x, gamma, beta, coef, out, g, C, inner, eps, affine_per_row, unbiased, act, slope, stream);
+    return launch_status();
+}
+
+int gz_adain_const_fwd(const float* x, const float* sb, float* coef, float* out, int N, int C, int inner, float eps,
+                       int act, float slope, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
+    RowGeom g = row_geom((long long)N * C, inner);
+    launch_rownorm_fused(x, sb, sb + C, coef, out, g, C, inner, eps, 2, 1, act, slope, stream, C);
+    return launch_status();
+}
+
+int gz_adain_const_bwd(const float* gout, const float* x, const float* coef, float* dx, float* dsb, int N, int C,
+                       int inner, int act, float slope, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
+    RowGeom g = row_geom(C, inner);
+    if ((g.q4 + g.lpr - 1) / g.lpr > 4) return GZ_ERR_UNSUPPORTED;        // rows of more than 1024 floats
+    const int waves = (C + g.rpw - 1) / g.rpw;
+    hipLaunchKernelGGL(adain_const_bwd_kernel, dim3((waves + 3) / 4), dim3(PW_THREADS), 0, stream, gout, x, coef, dx,
+                       dsb, g, N, C, inner, act, slope);
     return launch_status();
 }
 

@@ -1129,6 +1129,44 @@ def adain_act_packed(x, sb, eps=1e-8, act=ACT_RELU, slope=0.0):
     return _AdaINActPacked.apply(x, sb, eps, act, slope)
 
 
+class _AdaINConst(torch.autograd.Function):
+    """adain_act_packed(x.repeat(N, ...), sb) for a constant x of shape [1, C, ...] without materialising the
+    repeat or the per-sample input gradient (reference hologan_generator.py:141-142)."""
+
+    @staticmethod
+    def forward(ctx, x, sb, eps, act, slope):
+        x, sb = _req(x, "x"), _req(sb, "scale|shift")
+        N, C = sb.shape[0], x.shape[1]
+        inner = x.numel() // C
+        if x.shape[0] != 1 or sb.shape[1] != 2 * C:
+            raise RuntimeError("adain_const: expected x [1, C, ...] and scale|shift [N, 2C]")
+        coef = torch.empty(4 * N * C, device=x.device, dtype=torch.float32)
+        out = torch.empty((N,) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+        check(lib.gz_adain_const_fwd(_p(x), _p(sb), _p(coef), _p(out), N, C, inner, eps, act, slope, _stream()),
+              "adain_const_fwd")
+        ctx.save_for_backward(x, coef)
+        ctx.cfg = (N, C, inner, act, slope)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        x, coef = ctx.saved_tensors
+        N, C, inner, act, slope = ctx.cfg
+        gout = _req(gout)
+        dx = torch.empty_like(x)
+        dsb = torch.empty((N, 2 * C), device=x.device, dtype=torch.float32)
+        check(lib.gz_adain_const_bwd(_p(gout), _p(x), _p(coef), _p(dx), _p(dsb), N, C, inner, act, slope, _stream()),
+              "adain_const_bwd")
+        return dx, dsb, None, None, None
+
+
+def adain_const_act(x, sb, eps=1e-8, act=ACT_RELU, slope=0.0):
+    if x.numel() // x.shape[1] > 1024:          # rows longer than the constant-input kernel keeps in registers
+        return adain_act_packed(x.repeat(sb.shape[0], *([1] * (x.dim() - 1))), sb, eps, act, slope)
+    return _AdaINConst.apply(x, sb, eps, act, slope)
+
+
 class _LinearAct(torch.autograd.Function):
     """act(x @ W^T + b) with bias and activation fused in the GEMM epilogue."""
 

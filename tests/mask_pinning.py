@@ -53,7 +53,7 @@ def record_product_masks(tape):
         def inner(*a, **k):
             out = fn(*a, **k)
             act = k.get(act_kw, a[act_pos] if len(a) > act_pos else F.ACT_NONE)
-            if name in ("adain_act", "adain_act_packed") and act_kw not in k and len(a) <= act_pos:
+            if name in ("adain_act", "adain_act_packed", "adain_const_act") and act_kw not in k and len(a) <= act_pos:
                 act = F.ACT_RELU           # adain_act's default
             if act in (F.ACT_RELU, F.ACT_LRELU):
                 tape.record(out)
@@ -63,6 +63,7 @@ def record_product_masks(tape):
     wrap("linear_act", 3, "act")             # (x, weight, bias, act, slope)
     wrap("adain_act", 4, "act")              # (x, scale, bias, eps, act, slope)
     wrap("adain_act_packed", 3, "act")       # (x, scale|shift, eps, act, slope)
+    wrap("adain_const_act", 3, "act")
     wrap("instance_norm_act", 4, "act")      # (x, gamma, beta, eps, act, slope)
     wrap("conv2d", 4, "act")                 # (x, w, bias, geom, act, slope)
     wrap("conv_transpose2d", 4, "act")

@@ -322,6 +322,24 @@ def test_adain_relu_fwd_bwd(shape):
     assert rel(sbp.grad[:, :C], sr.grad) < TOL and rel(sbp.grad[:, C:], br.grad) < TOL
 
 
+def test_adain_of_a_shared_constant_equals_adain_of_its_repeat():
+    """HoloGAN's first layer (reference hologan_generator.py:141-142): AdaIN(self.x.repeat(N, ...)) without the repeat;
+    the constant's gradient is the sum over the samples."""
+    F = _F()
+    N, C = 6, 24
+    x = (rnd(1, C, 4, 4, 4, seed=111) + 0.3).cuda()
+    sb = (rnd(N, 2 * C, seed=112).abs() + 0.2).cuda()
+    go = rnd(N, C, 4, 4, 4, seed=113).cuda()
+    xa, sa = x.clone().requires_grad_(), sb.clone().requires_grad_()
+    ya = F.adain_act_packed(xa.repeat(N, 1, 1, 1, 1), sa, 1e-8, F.ACT_RELU)
+    ya.backward(go)
+    xb, sbb = x.clone().requires_grad_(), sb.clone().requires_grad_()
+    yb = F.adain_const_act(xb, sbb, 1e-8, F.ACT_RELU)
+    yb.backward(go)
+    assert torch.equal(ya, yb)
+    assert rel(xb.grad, xa.grad) < 1e-5 and rel(sbb.grad, sa.grad) < 1e-5
+
+
 @pytest.mark.parametrize("inner_shape", [(8, 8, 8), (32, 32)])
 def test_row_norms_keep_their_digits_when_the_mean_dwarfs_the_spread(inner_shape):
     """AdaIN / InstanceNorm rows with |mean| = 300 sigma (the output of a convolution over an all-positive, nearly

@@ -33,7 +33,7 @@ def wrap(name):
     setattr(F, name, traced)
 
 
-for n in ("conv2d", "conv_transpose2d", "conv_transpose3d", "adain_act_packed", "instance_norm_act", "linear_act",
+for n in ("conv2d", "conv_transpose2d", "conv_transpose3d", "adain_act_packed", "adain_const_act", "instance_norm_act", "linear_act",
           "rigid_resample", "spectral_normalize", "bce_logits_mean", "mse_mean"):
     wrap(n)
 inputs, golden, cond = load_golden("hologan", "full", stable=True)
