@@ -1950,6 +1950,35 @@ __global__ __launch_bounds__(64 * WAVES) void splitk_finish_kernel(const float* 
     }
 }
 
+// The same second pass for the row-major epilogue when there are many slabs over few outputs (the nn.Linear heads:
+// 64 x 128 outputs, K = 8192 / 32768): an output element per lane, four lanes per element taking every fourth slab
+// (coalesced along the row), partial sums meeting in LDS in a fixed order.  The block-per-32x32 form above gave such a
+// launch 8 workgroups walking 64+ slabs one after the other (27 us at K = 8192, 96 us at K = 32768).
+template <int ZL>      // lanes per output element (a template so that the header can be included by several sources)
+__global__ __launch_bounds__(64 * ZL) void splitk_finish_rowmajor_kernel(const float* __restrict__ slab, int nz,
+                                                                        EpiRowMajor::Params pe, int ny) {
+    static_assert(ZL == 4, "the LDS combine below is written for four slab lanes");
+    __shared__ float part[3][64];
+    const int lane = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    const long long mn = (long long)pe.M * pe.N;
+    const long long e = (long long)blockIdx.x * 64 + lane;
+    const bool live = e < mn * ny;
+    const long long y = live ? e / mn : 0, idx = live ? e - y * mn : 0;
+    float s = 0.f;
+    if (live) {
+        const float* c = slab + y * nz * mn + idx;
+        for (int z = zl; z < nz; z += 4) s += c[(long long)z * mn];
+    }
+    if (zl > 0) part[zl - 1][lane] = s;
+    __syncthreads();
+    if (zl == 0 && live) {
+        s += (part[0][lane] + part[1][lane]) + part[2][lane];
+        const int m = (int)(idx / pe.N), n = (int)(idx - (long long)m * pe.N);
+        const float bv = pe.bias ? pe.bias[n] : 0.f;
+        pe.c[y * pe.slab_stride + (long long)m * pe.ldc + n] = act_fwd(s + bv, pe.act, pe.slope);
+    }
+}
+
 inline int split_nz(int K, int splits) {
     int chunks = (K + BK - 1) / BK;
     if (splits < 1) splits = 1;
@@ -2006,7 +2035,15 @@ inline int launch_igemm(const typename AL::Params& pa, const typename BL::Params
     hipLaunchKernelGGL((igemm_kernel<Cfg, AL, BL, Epi>), grid, dim3(NT), dyn_lds, stream, pa, pb, pe, gm);
     if (gm.slab) {
         const int fm = (M + 31) / 32, fn = (N + 31) / 32;
-        // many slabs over few output blocks (the K = 8192 / 32768 linear heads): 16 wavefronts share the slab walk
+        if constexpr (std::is_same<Epi, EpiRowMajor>::value) {
+            if (nz > 8) {
+                const long long total = (long long)M * N * ny;
+                hipLaunchKernelGGL(splitk_finish_rowmajor_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream,
+                                   slab, nz, pe, ny);
+                return launch_status();
+            }
+        }
+        // many slabs over few output blocks: 8 wavefronts share the slab walk
         if (nz > 16)
             hipLaunchKernelGGL((splitk_finish_kernel<Epi, 8>), dim3(fm * fn * ny), dim3(512), 0, stream, slab, nz, M, N,
                                pe, fn, ny, sm);
