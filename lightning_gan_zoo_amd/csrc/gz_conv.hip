@@ -306,10 +306,21 @@ static int fwd_kdim(const ConvShape& s) {
     return G::kh * G::kw * (fwd_tap_major(s.C, G::kh, G::kw) ? round_bk(s.C) : s.C);
 }
 
+// Forward tile.  One correction to the score: k4 s2 p1 with output rows shorter than 16 pixels runs on the K4V gather
+// loader, whose 64x64 form is its weak spot (bs 128, G.block2's input gradient: 93 vs 107 TFLOP/s; bs 512, D.block2
+// forward: 110 vs 113) -- with >= 512 tiles of 128x128 the chip is half full and that kernel still wins.
+static TileId pick_tile_fwd(long long M, int K, int OW, int kh, int kw, int stride) {
+    TileId t = pick_tile(M, K, 1);
+    if (forced_tile() < 0 && kh == 4 && kw == 4 && stride == 2 && OW < 16 && t == T64x64 && K > 64 &&
+        tile_count(T128x128, M, K, 1) >= 512)
+        t = T128x128;
+    return t;
+}
+
 template <class G>
 static SplitPlan fwd_plan(const ConvShape& s) {
     long long M = (long long)s.N * s.OH * s.OW;
-    return plan_split(M, s.K, fwd_kdim<G>(s), 1, pick_tile(M, s.K, 1));
+    return plan_split(M, s.K, fwd_kdim<G>(s), 1, pick_tile_fwd(M, s.K, s.OW, G::kh, G::kw, G::s));
 }
 
 template <class G>
@@ -322,7 +333,8 @@ static int dispatch_fwd(const float* x, const float* wp, const float* bias, floa
                         int act, float slope, float* ws, size_t ws_bytes, hipStream_t st) {
     long long M = (long long)s.N * s.OH * s.OW;
     SplitPlan sp = fwd_plan<G>(s);
-    if (sp.splits > 1 && (!ws || ws_bytes < fwd_ws_bytes<G>(s))) sp = SplitPlan{pick_tile(M, s.K, 1), 1};
+    if (sp.splits > 1 && (!ws || ws_bytes < fwd_ws_bytes<G>(s)))
+        sp = SplitPlan{pick_tile_fwd(M, s.K, s.OW, G::kh, G::kw, G::s), 1};
     float* slab = sp.splits > 1 ? ws : nullptr;
     switch (sp.tile) {
         case T128x128: return run_fwd<G, Cfg128x128>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
@@ -1345,7 +1357,7 @@ int gz_conv2d_fwd_any(const float* x, const float* wpack, const float* bias, flo
 
 /* which tile configuration a launch of op (0 F, 1 Dg, 2 Wg) would use: 0 128x128, 1 128x64, 2 128x32, 3 64x64 */
 int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S) {
-    if (op == 0) return pick_tile((long long)N * OH * OW, K, 1);
+    if (op == 0) return pick_tile_fwd((long long)N * OH * OW, K, OW, KH, KW, S);
     if (op == 1) return pick_tile((long long)N * (H / S) * (W / S), C, S * S);
     long long NTOT = (long long)C * KH * KW;
     int t;
