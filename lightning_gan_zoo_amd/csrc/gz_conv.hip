@@ -47,13 +47,20 @@ static int min_wgs() {
 // ~108 TFLOP/s (64x64); one that leaves workgroup slots empty loses in proportion (D.block3's dgrad: 512 tiles of
 // 128x128 on 1024 slots -> the 2048 64x64 tiles win), and between one and two rounds part of the second round is
 // exposed.  Score = shape efficiency x fill and take the best; narrow N gets narrow tiles.
-static TileId pick_tile(long long M, long long N, int ny) {
+static TileId pick_tile(long long M, long long N, int ny, int kdim = 0) {
     int f = forced_tile();
     if (f >= 0 && f <= 3) {
         if (!(f == T128x128 && N <= 64) ) return (TileId)f;
     }
     if (N <= 32) return T128x32;
     auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * ny; };
+    // A launch with >= 34 GFLOP of work (65536 tile-chunks of 128x128x16) always has enough of it for ~1024 workgroups of
+    // the 128x128 shape with >= 64 chunks each once the reduction is split (plan_split), and that beats the smaller
+    // shapes whatever the tile count says: bs 128, G.block2's input gradient 0.370 -> 0.305 ms, G.block3's 0.309 ->
+    // 0.295, their forward 0.337 -> 0.324 / 0.299 -> 0.293; the 8.6 GFLOP discriminator layers of that batch lose 10 %
+    // the same way (16 chunks per workgroup: prologue, slab write and finish dominate) and stay with the score.
+    static const bool no_big = getenv("GZ_NO_BIG_SPLIT") != nullptr;
+    if (!no_big && kdim > 0 && N > 64 && tiles(128, 128) * ((kdim + BK - 1) / BK) >= 65536) return T128x128;
     if (getenv("GZ_MIN_WGS")) {           // round-1 rule, kept for experiments
         const long long want = min_wgs();
         if (N <= 64) return tiles(128, 64) >= want ? T128x64 : T64x64;
@@ -309,8 +316,8 @@ static int fwd_kdim(const ConvShape& s) {
 // Forward tile.  One correction to the score: k4 s2 p1 with output rows shorter than 16 pixels runs on the K4V gather
 // loader, whose 64x64 form is its weak spot (bs 128, G.block2's input gradient: 93 vs 107 TFLOP/s; bs 512, D.block2
 // forward: 110 vs 113) -- with >= 512 tiles of 128x128 the chip is half full and that kernel still wins.
-static TileId pick_tile_fwd(long long M, int K, int OW, int kh, int kw, int stride) {
-    TileId t = pick_tile(M, K, 1);
+static TileId pick_tile_fwd(long long M, int K, int OW, int kh, int kw, int stride, int kdim) {
+    TileId t = pick_tile(M, K, 1, kdim);
     if (forced_tile() < 0 && kh == 4 && kw == 4 && stride == 2 && OW < 16 && t == T64x64 && K > 64 &&
         tile_count(T128x128, M, K, 1) >= 512)
         t = T128x128;
@@ -320,7 +327,7 @@ static TileId pick_tile_fwd(long long M, int K, int OW, int kh, int kw, int stri
 template <class G>
 static SplitPlan fwd_plan(const ConvShape& s) {
     long long M = (long long)s.N * s.OH * s.OW;
-    return plan_split(M, s.K, fwd_kdim<G>(s), 1, pick_tile_fwd(M, s.K, s.OW, G::kh, G::kw, G::s));
+    return plan_split(M, s.K, fwd_kdim<G>(s), 1, pick_tile_fwd(M, s.K, s.OW, G::kh, G::kw, G::s, fwd_kdim<G>(s)));
 }
 
 template <class G>
@@ -334,7 +341,7 @@ static int dispatch_fwd(const float* x, const float* wp, const float* bias, floa
     long long M = (long long)s.N * s.OH * s.OW;
     SplitPlan sp = fwd_plan<G>(s);
     if (sp.splits > 1 && (!ws || ws_bytes < fwd_ws_bytes<G>(s)))
-        sp = SplitPlan{pick_tile_fwd(M, s.K, s.OW, G::kh, G::kw, G::s), 1};
+        sp = SplitPlan{pick_tile_fwd(M, s.K, s.OW, G::kh, G::kw, G::s, 0), 1};
     float* slab = sp.splits > 1 ? ws : nullptr;
     switch (sp.tile) {
         case T128x128: return run_fwd<G, Cfg128x128>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
@@ -655,7 +662,7 @@ static SplitPlan dgrad_plan(const ConvShape& s) {
     constexpr int TAPS = ((G::kh + G::s - 1) / G::s) * ((G::kw + G::s - 1) / G::s);
     long long M = (long long)s.N * (s.H / G::s) * (s.W / G::s);
     const int kk = dgrad_tap_major(s.K, G::kh, G::kw, G::s) ? round_bk(s.K) : s.K;
-    return plan_split(M, s.C, kk * TAPS, G::s * G::s, pick_tile(M, s.C, G::s * G::s));
+    return plan_split(M, s.C, kk * TAPS, G::s * G::s, pick_tile(M, s.C, G::s * G::s, kk * TAPS));
 }
 
 template <class G>
@@ -1357,8 +1364,10 @@ int gz_conv2d_fwd_any(const float* x, const float* wpack, const float* bias, flo
 
 /* which tile configuration a launch of op (0 F, 1 Dg, 2 Wg) would use: 0 128x128, 1 128x64, 2 128x32, 3 64x64 */
 int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S) {
-    if (op == 0) return pick_tile_fwd((long long)N * OH * OW, K, OW, KH, KW, S);
-    if (op == 1) return pick_tile((long long)N * (H / S) * (W / S), C, S * S);
+    // (the reduction lengths below ignore the channel padding of the tap-major loaders: labels only)
+    if (op == 0) return pick_tile_fwd((long long)N * OH * OW, K, OW, KH, KW, S, C * KH * KW);
+    if (op == 1)
+        return pick_tile((long long)N * (H / S) * (W / S), C, S * S, K * ((KH + S - 1) / S) * ((KW + S - 1) / S));
     long long NTOT = (long long)C * KH * KW;
     int t;
     if (NTOT <= 32) t = T128x32;
