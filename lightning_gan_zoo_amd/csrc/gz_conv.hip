@@ -990,6 +990,14 @@ static int wgrad_splits(long long tiles, int chunks, bool big_tile = true) {
     long long target = big_tile ? wg_target() : 512;   // narrow tiles (3-channel layers) are slab-traffic bound
     if (tiles * 4 >= target * 3) return 1;
     long long want = (target + tiles - 1) / tiles;
+    if (big_tile) {
+        // ... but a 128x128 workgroup that reduces fewer than 32 chunks spends its time on the prologue and its 64 KB
+        // slab: keep >= 32 chunks per split as long as >= 512 workgroups remain (bs 128, D.block1 / block2: 128 x 16
+        // chunks -> 64 x 32, 0.111 -> 0.105 and 0.116 -> 0.110 ms; every bs 512 layer keeps its plan)
+        const long long by_len = chunks / 32 > 0 ? chunks / 32 : 1, want_min = (512 + tiles - 1) / tiles;
+        const long long floor_ = by_len > want_min ? by_len : want_min;
+        if (floor_ < want) want = floor_;
+    }
     long long cap = chunks / 8 > 0 ? chunks / 8 : 1;  // keep >= 8 chunks (128 pixels) per split
     long long s = want < cap ? want : cap;
     return (int)(s < 1 ? 1 : s);
