@@ -49,6 +49,15 @@ int gz_conv2d_pack_fwd(const float* w, float* wpack, int K, int C, int KH, int K
 /* w -> [S*S phases][K*TY*TX][round4(C)] GEMM-B images for gz_conv2d_dgrad */
 int gz_conv2d_pack_dgrad(const float* w, float* wpack, int K, int C, int KH, int KW, int S, int P,
                          hipStream_t stream);
+/* Re-packing every weight of a network in ONE launch (the packs follow each optimizer step: ~15 launches per G+D pair).
+ * gz_conv2d_pack_job fills one host-side job record (gz_conv2d_pack_job_bytes() bytes) for the pair (w, wp) -- the
+ * same image gz_conv2d_pack_fwd / _dgrad would write -- and returns the number of workgroups it needs (its first one is
+ * `block0` = the sum over the jobs before it); the records are copied to the device as one array and
+ * gz_conv2d_pack_multi runs them all. */
+size_t gz_conv2d_pack_job_bytes(void);
+int gz_conv2d_pack_job(void* job_out, const float* w, float* wp, int is_dgrad, int K, int C, int KH, int KW, int S, int P,
+                       int block0);
+int gz_conv2d_pack_multi(const void* jobs_dev, int njobs, int total_blocks, hipStream_t stream);
 
 /* y = act(conv2d(x, w) + bias).  Replaces aten::convolution for nn.Conv2d forward
  * (standard_networks.py:20-24,36-43) and the input gradient of nn.ConvTranspose2d. */

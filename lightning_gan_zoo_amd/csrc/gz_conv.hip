@@ -122,12 +122,16 @@ static size_t split_bytes(const SplitPlan& sp, long long M, long long N, int Kdi
 // ---------------------------------------------------------------------------
 // weight packing
 // ---------------------------------------------------------------------------
+__host__ __device__ constexpr int round4(int v) { return (v + 3) & ~3; }
+
+// The pack kernels exist twice: as their own launches (bx / by / gx = blockIdx / gridDim) and as the bodies of
+// pack_multi_kernel, which re-packs every weight of a network in one launch (a job table maps a block to its tensor).
 // dst[c][ld] (c < COLS) = src[r][c] transposed: dst[c*ld + r] = src[r*COLS + c]; zero for r in [R, ld)
-__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ src,
-                                                            float* __restrict__ dst, int R, int COLS, int ld) {
+__device__ __forceinline__ void transpose_pad_body(const float* __restrict__ src, float* __restrict__ dst, int R,
+                                                   int COLS, int ld, int bx, int by) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int c0 = bx * 32, r0 = by * 32;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int r = r0 + ty + 8 * i, c = c0 + tx;
@@ -139,6 +143,11 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
         int c = c0 + ty + 8 * i, r = r0 + tx;
         if (c < COLS && r < ld) dst[(long long)c * ld + r] = tile[tx][ty + 8 * i];
     }
+}
+
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ src,
+                                                            float* __restrict__ dst, int R, int COLS, int ld) {
+    transpose_pad_body(src, dst, R, COLS, ld, blockIdx.x, blockIdx.y);
 }
 
 // Tap-major reduction order (gz_igemm.h: ConvFwdALoaderTap / ConvDgALoaderTap) is used when the tap count does not
@@ -156,10 +165,10 @@ static bool dgrad_tap_major(int K, int KH, int KW, int S) {
 }
 
 // wp[(tap, c)][ld] = w[ko][c][tap], c padded to a multiple of BK with zero rows
-__global__ __launch_bounds__(256) void pack_fwd_tap_kernel(const float* __restrict__ w, float* __restrict__ wp, int K,
-                                                           int C, int taps, int cpad, int ld) {
+__device__ __forceinline__ void pack_fwd_tap_body(const float* __restrict__ w, float* __restrict__ wp, int K, int C,
+                                                  int taps, int cpad, int ld, int bx, int gx) {
     const long long total = (long long)taps * cpad * ld;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    for (long long i = (long long)bx * 256 + threadIdx.x; i < total; i += (long long)gx * 256) {
         int ko = (int)(i % ld);
         long long row = i / ld;
         int c = (int)(row % cpad), tap = (int)(row / cpad);
@@ -167,18 +176,22 @@ __global__ __launch_bounds__(256) void pack_fwd_tap_kernel(const float* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void pack_fwd_tap_kernel(const float* __restrict__ w, float* __restrict__ wp, int K,
+                                                           int C, int taps, int cpad, int ld) {
+    pack_fwd_tap_body(w, wp, K, C, taps, cpad, ld, blockIdx.x, gridDim.x);
+}
+
 // wp[phase][(tap, ko)][ldc] = w[ko][c][ky][kx] over the phase's own ny x nx taps (tap = ty * nx + tx), ko padded
 // to a multiple of BK; the unused tail of the phase's fixed-size TY*TX*kpad-row region is never read
-__global__ __launch_bounds__(256) void pack_dgrad_tap_kernel(const float* __restrict__ w, float* __restrict__ wp, int K,
-                                                             int C, int KH, int KW, int S, int P, int TY, int TX,
-                                                             int kpad, int ldc) {
-    const int phase = blockIdx.y;
+__device__ __forceinline__ void pack_dgrad_tap_body(const float* __restrict__ w, float* __restrict__ wp, int K, int C,
+                                                    int KH, int KW, int S, int P, int TY, int TX, int kpad, int ldc,
+                                                    int bx, int phase, int gx) {
     const int py = phase / S, px = phase % S;
     const int ry = (py + P) % S, rx = (px + P) % S;
     const int ny = dg_taps(KH, S, P, py), nx = dg_taps(KW, S, P, px);
     float* dst = wp + (long long)phase * TY * TX * kpad * ldc;
     const long long total = (long long)ny * nx * kpad * ldc;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    for (long long i = (long long)bx * 256 + threadIdx.x; i < total; i += (long long)gx * 256) {
         int c = (int)(i % ldc);
         long long row = i / ldc;
         int ko = (int)(row % kpad), tap = (int)(row / kpad);
@@ -187,26 +200,63 @@ __global__ __launch_bounds__(256) void pack_dgrad_tap_kernel(const float* __rest
     }
 }
 
+__global__ __launch_bounds__(256) void pack_dgrad_tap_kernel(const float* __restrict__ w, float* __restrict__ wp, int K,
+                                                             int C, int KH, int KW, int S, int P, int TY, int TX,
+                                                             int kpad, int ldc) {
+    pack_dgrad_tap_body(w, wp, K, C, KH, KW, S, P, TY, TX, kpad, ldc, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
 // dgrad pack: wp[phase][(ko, ty, tx)][ldc] = w[ko][c][ky][kx], ky = ((py+P)%S) + S*ty.  A phase only has the taps
 // whose ky < KH (kx < KW): ny(py) * nx(px) of them (dg_taps); its rows are packed tightly and the rest of the
 // phase's fixed-size K*TY*TX-row region is zero.  (k5 s2: 9/6/6/4 taps instead of 4 x 9.)
-__global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp,
-                                                         int K, int C, int KH, int KW, int S, int P, int TY,
-                                                         int TX, int ldc) {
-    const int ko = blockIdx.x;
-    const int phase = blockIdx.y;
+__device__ __forceinline__ void pack_dgrad_body(const float* __restrict__ w, float* __restrict__ wp, int K, int C,
+                                                int KH, int KW, int S, int P, int TY, int TX, int ldc, int ko,
+                                                int phase) {
     const int py = phase / S, px = phase % S;
     const int ry = (py + P) % S, rx = (px + P) % S;
     const int ny = dg_taps(KH, S, P, py), nx = dg_taps(KW, S, P, px);
     const int taps = ny * nx, pad = TY * TX - taps;
     float* dst = wp + (long long)phase * K * TY * TX * ldc;
-    for (int i = threadIdx.x; i < taps * ldc; i += blockDim.x) {
+    for (int i = threadIdx.x; i < taps * ldc; i += 256) {
         int tap = i / ldc, c = i - tap * ldc;
         int ky = ry + S * (tap / nx), kx = rx + S * (tap % nx);
         dst[((long long)ko * taps + tap) * ldc + c] = c < C ? w[(((long long)ko * C + c) * KH + ky) * KW + kx] : 0.f;
     }
-    for (int i = threadIdx.x; i < pad * ldc; i += blockDim.x)
+    for (int i = threadIdx.x; i < pad * ldc; i += 256)
         dst[((long long)K * taps + (long long)ko * pad) * ldc + i] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                                         int K, int C, int KH, int KW, int S, int P, int TY,
+                                                         int TX, int ldc) {
+    pack_dgrad_body(w, wp, K, C, KH, KW, S, P, TY, TX, ldc, blockIdx.x, blockIdx.y);
+}
+
+// One launch for many packs: jobs[j] describes one (weight, packed image) pair and the grid it would have had as a
+// launch of its own; block b belongs to the job with block0 <= b < block0 + gx * gy.
+struct PackJob {
+    const float* w;
+    float* wp;
+    int kind;                 // 0 transpose_pad (forward), 1 forward tap-major, 2 dgrad, 3 dgrad tap-major
+    int K, C, KH, KW, S, P;
+    int gx, gy, block0;
+};
+
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    const int b = blockIdx.x;
+    int j = 0;
+    while (j + 1 < njobs && jobs[j + 1].block0 <= b) ++j;
+    const PackJob jb = jobs[j];
+    const int l = b - jb.block0, bx = l % jb.gx, by = l / jb.gx;
+    const int TY = (jb.KH + jb.S - 1) / jb.S, TX = (jb.KW + jb.S - 1) / jb.S;
+    switch (jb.kind) {
+        case 0: transpose_pad_body(jb.w, jb.wp, jb.K, jb.C * jb.KH * jb.KW, round4(jb.K), bx, by); break;
+        case 1: pack_fwd_tap_body(jb.w, jb.wp, jb.K, jb.C, jb.KH * jb.KW, round_bk(jb.C), round4(jb.K), bx, jb.gx); break;
+        case 2: pack_dgrad_body(jb.w, jb.wp, jb.K, jb.C, jb.KH, jb.KW, jb.S, jb.P, TY, TX, round4(jb.C), bx, by); break;
+        default:
+            pack_dgrad_tap_body(jb.w, jb.wp, jb.K, jb.C, jb.KH, jb.KW, jb.S, jb.P, TY, TX, round_bk(jb.K), round4(jb.C), bx,
+                                by, jb.gx);
+    }
 }
 
 // out[i] = sum_s slab[s][i].  Small weight tensors reach here with hundreds of slabs (split-K over a 1M-long
@@ -252,7 +302,6 @@ __global__ __launch_bounds__(64 * RS_WAVES) void reduce_slabs_kernel(const float
     }
 }
 
-static inline int round4(int v) { return (v + 3) & ~3; }
 
 template <int KH, int KW, int S, int P>
 struct Geo {
@@ -1173,6 +1222,45 @@ int gz_conv2d_pack_dgrad(const float* w, float* wp, int K, int C, int KH, int KW
     }
     hipLaunchKernelGGL(pack_dgrad_kernel, dim3(K, S * S), dim3(256), 0, stream, w, wp, K, C, KH, KW, S, P, TY, TX,
                        round4(C));
+    return launch_status();
+}
+
+size_t gz_conv2d_pack_job_bytes(void) { return sizeof(PackJob); }
+
+int gz_conv2d_pack_job(void* job_out, const float* w, float* wp, int is_dgrad, int K, int C, int KH, int KW, int S, int P,
+                       int block0) {
+    if (!job_out || K <= 0 || C <= 0 || KH <= 0 || KW <= 0 || S <= 0) return GZ_ERR_BAD_SHAPE;
+    PackJob jb{w, wp, 0, K, C, KH, KW, S, P, 1, 1, block0};
+    const int TY = (KH + S - 1) / S, TX = (KW + S - 1) / S;
+    if (!is_dgrad) {
+        if (fwd_tap_major(C, KH, KW)) {
+            const long long total = (long long)KH * KW * round_bk(C) * round4(K);
+            jb.kind = 1;
+            jb.gx = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        } else {
+            jb.kind = 0;
+            jb.gx = (C * KH * KW + 31) / 32;
+            jb.gy = (round4(K) + 31) / 32;
+        }
+    } else if (dgrad_tap_major(K, KH, KW, S)) {
+        const long long total = (long long)TY * TX * round_bk(K) * round4(C);
+        jb.kind = 3;
+        jb.gx = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+        jb.gy = S * S;
+    } else {
+        jb.kind = 2;
+        jb.gx = K;
+        jb.gy = S * S;
+    }
+    *reinterpret_cast<PackJob*>(job_out) = jb;
+    return jb.gx * jb.gy;
+}
+
+int gz_conv2d_pack_multi(const void* jobs_dev, int njobs, int total_blocks, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (!jobs_dev || njobs <= 0 || total_blocks <= 0) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(pack_multi_kernel, dim3(total_blocks), dim3(256), 0, stream,
+                       reinterpret_cast<const PackJob*>(jobs_dev), njobs);
     return launch_status();
 }
 

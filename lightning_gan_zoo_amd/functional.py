@@ -120,42 +120,129 @@ _pack_cache_enabled = True     # harness.GraphedTrainer turns it off: a captured
 def set_pack_cache(enabled):
     global _pack_cache_enabled
     _pack_cache_enabled = bool(enabled)
-    _pack_cache.clear()
+    clear_pack_cache()
     _pack3_cache.clear()
+
+
+# Pack groups: the conv weights one optimizer updates.  After its step every packed image of the group is stale at
+# once, and the first miss re-packs them ALL in one launch (gz_conv2d_pack_multi) into their existing buffers instead
+# of one launch per image as the step walks through the layers (15 launches per DCGAN pair; they were 0.5 % of the
+# bs 512 pair and 1.4 % of the bs 128 pair).  Images keep their buffers; the job table lives on the device and is
+# rebuilt only when the set of images changes (the first steps).
+_pack_group_of = {}       # parameter data_ptr -> group id
+_group_keys = {}          # group id -> set of (data_ptr, kind)
+_group_table = {}         # group id -> (signature, device table, number of jobs, total workgroups)
+_NO_PACK_GROUPS = bool(os.environ.get("GZ_NO_PACK_GROUPS"))      # experiment: one launch per image, as in round 1
+
+
+class _PackEntry:
+    __slots__ = ("ref", "version", "shape", "wp", "geom", "stale")
+
+    def __init__(self, w, wp, geom):
+        self.ref, self.version, self.shape, self.wp, self.geom, self.stale = weakref.ref(w), w._version, tuple(w.shape), wp, geom, False
+
+
+def register_pack_group(params):
+    """Called by the fused optimizers with the parameters they update; returns the group id."""
+    gid = len(_group_keys) + 1
+    _group_keys[gid] = set()
+    for p in params:
+        if p.dim() == 4 and p.is_cuda:
+            _pack_group_of[p.data_ptr()] = gid
+    return gid
+
+
+def _pack_one(w, wp, kind, geom):
+    K, C, KH, KW = w.shape
+    if kind == "f":
+        check(lib.gz_conv2d_pack_fwd(_p(w), _p(wp), K, C, KH, KW, _stream()), "conv2d_pack_fwd")
+    else:
+        check(lib.gz_conv2d_pack_dgrad(_p(w), _p(wp), K, C, KH, KW, geom.stride, geom.pad, _stream()),
+              "conv2d_pack_dgrad")
+
+
+def _repack_group(gid):
+    live = []
+    for key in sorted(_group_keys[gid]):
+        e = _pack_cache.get(key)
+        w = e.ref() if e is not None else None
+        if w is None or w.data_ptr() != key[0] or tuple(w.shape) != e.shape:
+            _group_keys[gid].discard(key)
+            _pack_cache.pop(key, None)
+            continue
+        live.append((key, e, w))
+    sig = tuple((key, e.wp.data_ptr()) for key, e, _ in live)
+    tab = _group_table.get(gid)
+    if tab is None or tab[0] != sig:
+        nb = lib.gz_conv2d_pack_job_bytes()
+        host = (ctypes.c_char * (nb * len(live)))()
+        block0 = 0
+        for i, (key, e, w) in enumerate(live):
+            K, C, KH, KW = e.shape
+            n = lib.gz_conv2d_pack_job(ctypes.c_void_p(ctypes.addressof(host) + i * nb), _p(w), _p(e.wp),
+                                       0 if key[1] == "f" else 1, K, C, KH, KW,
+                                       e.geom.stride if e.geom is not None else 1, e.geom.pad if e.geom is not None else 0,
+                                       block0)
+            check(min(n, 0), "conv2d_pack_job")
+            block0 += n
+        dev = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(live[0][2].device)
+        tab = (sig, dev, len(live), block0)
+        _group_table[gid] = tab
+    check(lib.gz_conv2d_pack_multi(_p(tab[1]), tab[2], tab[3], _stream()), "conv2d_pack_multi")
+    for _, e, w in live:
+        e.version, e.stale = w._version, False
 
 
 def _packed(w, kind, geom):
     key = (w.data_ptr(), kind)
     cacheable = _pack_cache_enabled and isinstance(w, torch.nn.Parameter)
-    if cacheable:
-        hit = _pack_cache.get(key)
-        if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == tuple(w.shape):
-            return hit[3]
+    e = _pack_cache.get(key) if cacheable else None
+    if e is not None and (e.ref() is not w or e.shape != tuple(w.shape)):
+        _pack_cache.pop(key, None)
+        e = None
+    if e is not None and e.version == w._version and not e.stale:
+        return e.wp
+    gid = None if (_NO_PACK_GROUPS or not cacheable) else _pack_group_of.get(key[0])
+    if e is not None and gid is not None and key in _group_keys[gid]:
+        _repack_group(gid)
+        return e.wp
     K, C, KH, KW = w.shape
     if kind == "f":
         n = lib.gz_conv2d_pack_fwd_elems(K, C, KH, KW)
-        wp = torch.empty(n, device=w.device, dtype=torch.float32)
-        check(lib.gz_conv2d_pack_fwd(_p(w), _p(wp), K, C, KH, KW, _stream()), "conv2d_pack_fwd")
     else:
         n = lib.gz_conv2d_pack_dgrad_elems(K, C, KH, KW, geom.stride)
-        wp = torch.empty(n, device=w.device, dtype=torch.float32)
-        check(lib.gz_conv2d_pack_dgrad(_p(w), _p(wp), K, C, KH, KW, geom.stride, geom.pad, _stream()),
-              "conv2d_pack_dgrad")
+    wp = torch.empty(n, device=w.device, dtype=torch.float32)
+    _pack_one(w, wp, kind, geom)
     if cacheable:
-        _pack_cache[key] = (weakref.ref(w), w._version, tuple(w.shape), wp)
+        _pack_cache[key] = _PackEntry(w, wp, geom)
+        if gid is not None:
+            _group_keys[gid].add(key)
     return wp
 
 
 def clear_pack_cache():
     _pack_cache.clear()
+    _group_table.clear()
+    for keys in _group_keys.values():
+        keys.clear()
 
 
 def invalidate(w):
-    """Forget the packed images of `w` after its memory was rewritten without a version bump
-    (raw in-place kernels: clamp_, the fused optimizers)."""
-    for cache in (_pack_cache, _pack3_cache):
-        cache.pop((w.data_ptr(), "f"), None)
-        cache.pop((w.data_ptr(), "d"), None)
+    """The packed images of `w` are stale: its memory was rewritten without a version bump (raw in-place kernels:
+    clamp_, the fused optimizers).  Images that belong to a pack group keep their buffers and are re-packed together
+    at the next use; the others are dropped."""
+    ptr = w.data_ptr()
+    grouped = not _NO_PACK_GROUPS and ptr in _pack_group_of
+    for kind in ("f", "d"):
+        e = _pack_cache.get((ptr, kind))
+        if e is None:
+            continue
+        if grouped:
+            e.stale = True
+        else:
+            _pack_cache.pop((ptr, kind), None)
+    _pack3_cache.pop((ptr, "f"), None)
+    _pack3_cache.pop((ptr, "d"), None)
 
 
 # ---------------------------------------------------------------------------

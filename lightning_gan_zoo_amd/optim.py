@@ -84,6 +84,8 @@ class Adam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         loss = closure() if closure is not None else None
+        if getattr(self, "_pack_group", None) is None:      # the conv weights this optimizer rewrites re-pack together
+            self._pack_group = F.register_pack_group([p for g in self.param_groups for p in g["params"]])
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for group in self.param_groups:
             if group.get("_tick") is not None:
@@ -137,6 +139,8 @@ class RMSprop(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         loss = closure() if closure is not None else None
+        if getattr(self, "_pack_group", None) is None:      # the conv weights this optimizer rewrites re-pack together
+            self._pack_group = F.register_pack_group([p for g in self.param_groups for p in g["params"]])
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for group in self.param_groups:
             plist = []

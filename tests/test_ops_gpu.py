@@ -820,3 +820,30 @@ def test_second_order_through_fused_tanh_and_bias():
         outs.append([t.detach().cpu() for t in (y, gx, gb, xd.grad, wd.grad, bd.grad)])
     for got, want in zip(outs[1], outs[0]):
         assert rel(got, want) < TOL
+
+
+def test_group_repack_equals_single_packs():
+    """gz_conv2d_pack_multi (one launch for every packed image of an optimizer's weights) writes exactly what the
+    per-image pack launches write: all four layouts (forward / transposed, reduction in (c, tap) or tap-major order)."""
+    F = _F()
+    F.clear_pack_cache()
+    geoms = [F.K4S2P1, F.Geom(5, 5, 2, 2), F.Geom(3, 3, 1, 1), F.Geom(5, 5, 2, 2)]
+    shapes = [(24, 12, 4, 4), (40, 32, 5, 5), (16, 20, 3, 3), (6, 3, 5, 5)]
+    ws = [torch.nn.Parameter(rnd(*s, seed=300 + i).cuda()) for i, s in enumerate(shapes)]
+    F.register_pack_group(ws)
+    first = [(F._packed(w, "f", g), F._packed(w, "d", g)) for w, g in zip(ws, geoms)]       # single launches
+    with torch.no_grad():
+        for i, w in enumerate(ws):
+            w.mul_(1.5).add_(0.01 * i)                    # version bump: every image is stale
+    again = [(F._packed(w, "f", g), F._packed(w, "d", g)) for w, g in zip(ws, geoms)]       # one group launch
+    for (f0, d0), (f1, d1), w, g in zip(first, again, ws, geoms):
+        assert f0.data_ptr() == f1.data_ptr() and d0.data_ptr() == d1.data_ptr()            # buffers kept
+        for kind, got in (("f", f1), ("d", d1)):
+            ref = torch.empty_like(got)
+            F._pack_one(w, ref, kind, g)
+            assert torch.equal(got, ref), (tuple(w.shape), kind)
+    F.invalidate(ws[0])                                   # raw in-place rewrite: stale without a version bump
+    with torch.no_grad():
+        ws[0].data.zero_()
+    assert float(F._packed(ws[0], "f", geoms[0]).abs().sum()) == 0.0
+    F.clear_pack_cache()
