@@ -313,6 +313,9 @@ const char* gz_last_error(void);
 
 /* library identification: returns the gfx target string the kernels were compiled for */
 const char* gz_build_info(void);
+/* content digest (sha256 prefix, hex) of the kernel sources, headers and flags this library was built from;
+ * lightning_gan_zoo_amd/_lib.py refuses a library whose digest is not the digest of the tree it runs from */
+const char* gz_source_digest(void);
 
 #ifdef __cplusplus
 }

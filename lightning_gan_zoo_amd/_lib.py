@@ -76,11 +76,30 @@ class _Lib:
                 fn = getattr(dll, name)   # AttributeError if the library does not export it
                 fn.restype = restype
                 fn.argtypes = argtypes
+            _check_digest(dll)
             self._dll = dll
             return dll
 
     def __getattr__(self, name):
         return getattr(self.load(), name)
+
+
+def _check_digest(dll):
+    """The library must have been built from the kernel sources lying next to it: a snapshot that carries an old
+    .so beside newer sources would otherwise run kernels the tests are not about.  GZ_LIB builds (experimental
+    variants with extra -D flags, tools/) are exempt; GZ_ALLOW_STALE=1 turns the refusal into a warning."""
+    if os.environ.get("GZ_LIB"):
+        return
+    from .build import source_digest
+    built, tree = dll.gz_source_digest().decode(), source_digest()
+    if built != tree:
+        msg = ("lightning_gan_zoo_amd: %s was built from other sources (library digest %s, tree digest %s); "
+               "rebuild with `python -m lightning_gan_zoo_amd.build`" % (LIB_PATH, built, tree))
+        if os.environ.get("GZ_ALLOW_STALE") == "1":
+            import warnings
+            warnings.warn(msg)
+        else:
+            raise RuntimeError(msg)
 
 
 lib = _Lib()

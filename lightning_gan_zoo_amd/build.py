@@ -3,9 +3,14 @@
     python -m lightning_gan_zoo_amd.build [--force]
 
 hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels to
-the GPU box with the repo snapshot.  Objects are rebuilt only when a source or header
-is newer (or with --force).
+the GPU box with the repo snapshot.
+
+Staleness is decided by CONTENT, not by mtime (a snapshot or checkout can reset mtimes): every object carries a
+sidecar ``<obj>.sha`` = sha256 of its source, every header and the flags it was compiled with, and the library
+embeds ``source_digest()`` -- sha256 over all kernel sources, headers and flags -- as ``gz_source_digest()``.
+``_lib.load`` compares that with the digest of the tree it runs from and refuses a library built from other sources.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -16,6 +21,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libgz_hip.so")
 ARCH = "gfx950"
+DIGEST_SOURCE = "gz_build_id.hip"          # holds gz_source_digest(); compiled with -DGZ_SOURCE_DIGEST=...
 SOURCES = ["gz_conv.hip", "gz_conv3d.hip", "gz_norm.hip", "gz_misc.hip", "gz_resample.hip", "gz_optim.hip", "gz_resnet.hip", "gz_loss.hip", "gz_infer.hip"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE]
 
@@ -27,13 +33,35 @@ def _hipcc():
     return "hipcc"
 
 
-def _newest_header():
-    t = 0.0
+def _read(path):
+    with open(path, "rb") as f:
+        return f.read()
+
+
+def _headers():
+    out = []
     for d in (CSRC, INCLUDE):
-        for f in os.listdir(d):
-            if f.endswith(".h"):
-                t = max(t, os.path.getmtime(os.path.join(d, f)))
-    return t
+        out += [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(".h")]
+    return out
+
+
+def _sha(parts):
+    h = hashlib.sha256()
+    for p in parts:
+        b = p if isinstance(p, bytes) else str(p).encode()
+        h.update(len(b).to_bytes(8, "little"))
+        h.update(b)
+    return h.hexdigest()
+
+
+def source_digest(extra_flags=()):
+    """sha256 over every kernel source, every header (csrc/*.h, include/*.h) and the compile flags, by content."""
+    files = [os.path.join(CSRC, s) for s in SOURCES + [DIGEST_SOURCE]] + _headers()
+    parts = []
+    for f in files:
+        parts += [os.path.basename(f), _read(f)]
+    flags = [f for f in FLAGS if f != INCLUDE] + list(extra_flags)
+    return "g" + _sha(parts + flags)[:31]      # an identifier: travels through hipcc's -D quoting unharmed
 
 
 def build(force=False, verbose=True, extra_flags=None, suffix=""):
@@ -42,17 +70,20 @@ def build(force=False, verbose=True, extra_flags=None, suffix=""):
     hipcc = _hipcc()
     extra_flags = list(extra_flags or [])
     lib_path = LIB_PATH.replace(".so", suffix + ".so")
-    hdr_t = _newest_header()
-    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    jobs = []
-    objs = []
-    for s in srcs:
+    digest = source_digest(extra_flags)
+    hdr = [_read(h) for h in _headers()]
+    flags = [f for f in FLAGS if f != INCLUDE] + extra_flags
+    jobs, objs, stamps = [], [], []
+    for s in SOURCES + [DIGEST_SOURCE]:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", suffix + ".o"))
         objs.append(obj)
-        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t)
-        if stale:
-            jobs.append([hipcc] + FLAGS + extra_flags + ["-c", src, "-o", obj])
+        define = ['-DGZ_SOURCE_DIGEST=%s' % digest] if s == DIGEST_SOURCE else []
+        want = _sha([_read(src)] + hdr + flags + define)
+        have = _read(obj + ".sha").decode() if os.path.exists(obj + ".sha") and os.path.exists(obj) else None
+        if force or have != want:
+            jobs.append([hipcc] + FLAGS + extra_flags + define + ["-c", src, "-o", obj])
+            stamps.append((obj + ".sha", want))
 
     def run(cmd):
         if verbose:
@@ -63,12 +94,20 @@ def build(force=False, verbose=True, extra_flags=None, suffix=""):
         return r
 
     if jobs:
+        for path, _ in stamps:          # a half-finished build must not look fresh
+            if os.path.exists(path):
+                os.remove(path)
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    need_link = bool(jobs) or not os.path.exists(lib_path) or any(
-        os.path.getmtime(o) > os.path.getmtime(lib_path) for o in objs)
-    if need_link:
+        for path, want in stamps:
+            with open(path, "w") as f:
+                f.write(want)
+    link_stamp = lib_path + ".sha"
+    linked = _read(link_stamp).decode() if os.path.exists(link_stamp) and os.path.exists(lib_path) else None
+    if jobs or linked != digest:
         run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_path] + objs)
+        with open(link_stamp, "w") as f:
+            f.write(digest)
     return lib_path
 
 

@@ -52,7 +52,7 @@ def locate(path):
 def instantiate(node, *args, **kwargs):
     """``hydra.utils.instantiate`` for the subset the hot path uses: import
     ``_target_`` and call it with the node's other keys merged with kwargs."""
-    node = dict(node)
+    node = _plain(node)
     target = locate(node.pop("_target_"))
     recursive = node.pop("_recursive_", True)
     for k, v in list(node.items()):
@@ -62,6 +62,15 @@ def instantiate(node, *args, **kwargs):
                 and any(isinstance(x, float) for x in v):
             node[k] = [float(x) for x in v]                # ``betas: [0, 0.9]`` (conf/expt/wgan_gp.yaml): torch wants floats
     return target(*args, **{**node, **kwargs})
+
+
+def _plain(node):
+    """A Hydra / OmegaConf node (the reference's own harness hands the step classes a DictConfig) as a resolved
+    plain dict; plain mappings are shallow-copied."""
+    if type(node).__module__.startswith("omegaconf"):
+        from omegaconf import OmegaConf
+        return OmegaConf.to_container(node, resolve=True)
+    return dict(node)
 
 
 PRODUCT_ROOT = "lightning_gan_zoo_amd.core"

@@ -16,21 +16,36 @@ import torch
 from .. import functional as F
 from ..config import instantiate
 from ..harness import LightningModule, draw_on_host
-from .utils.utils import compute_grad2, gradient_penalty
+from .utils.utils import VerboseShapeExecution, compute_grad2, gradient_penalty
 
 
-class _Identity:
-    def __call__(self, x):
-        return x
+class _HostImageTransform:
+    """Resize((S, S)) -> ToTensor -> Normalize(mean, std) for installations without torchvision: PIL bilinear resize,
+    HWC uint8 -> CHW float in [0, 1], then (x - mean) / std.  Tensors pass through (synthetic / tensor datasets)."""
+
+    def __init__(self, size, mean, std, channels):
+        self.size, self.mean, self.std, self.channels = size, float(mean), float(std), channels
+
+    def __call__(self, img):
+        if torch.is_tensor(img):
+            return img
+        import numpy as np
+        from PIL import Image
+        if not isinstance(img, Image.Image):
+            img = Image.fromarray(np.asarray(img))
+        img = img.resize((self.size, self.size), Image.BILINEAR)
+        a = np.asarray(img, dtype=np.float32)
+        a = a[:, :, None] if a.ndim == 2 else a
+        return torch.from_numpy(a).permute(2, 0, 1).div(255.0).sub(self.mean).div(self.std)
 
 
 def _build_transform(cfg):
-    """Resize -> ToTensor -> Normalize (reference :42-47); torchvision is optional here."""
+    """Resize -> ToTensor -> Normalize (reference :42-47); torchvision's when it is installed."""
+    t = cfg.train
     try:
         from torchvision import transforms
-    except Exception:  # noqa: BLE001 - synthetic / tensor datasets need no transform
-        return _Identity()
-    t = cfg.train
+    except Exception:  # noqa: BLE001
+        return _HostImageTransform(t.img_size, t.data_mean, t.data_std, t.channels_img)
     return transforms.Compose([
         transforms.Resize((t.img_size, t.img_size)),
         transforms.ToTensor(),
@@ -50,6 +65,8 @@ class BaseGAN(LightningModule):
         self.criterion = instantiate(cfg.train.criterion)
         self.noise_distn = instantiate(cfg.model.noise_distn)
         self.fixed_noise = self.noise_distn.sample((8, cfg.model.noise_dim))
+        if cfg.debug.verbose_shape:                      # reference :53-54
+            self.apply(VerboseShapeExecution)
 
     @abstractmethod
     def training_step(self, batch, batch_idx, optimizer_idx):
@@ -108,6 +125,25 @@ class BaseGAN(LightningModule):
                  "frequency": self.cfg.optimisation.disc_freq},
                 {"optimizer": opt_gen, "lr_scheduler": scheduler_gen,
                  "frequency": self.cfg.optimisation.gen_freq})
+
+
+    # -- data hooks Lightning's ``trainer.fit(model)`` calls (reference :89-102): the dataset node of the config
+    #    (``torchvision.datasets.ImageFolder`` in conf/dataset/celeb_a.yaml) with this module's transform, the
+    #    configured batch size and worker count, NO shuffling, incomplete last batch kept.  The batches are host
+    #    tensors; Lightning moves them to ``self.device`` before ``training_step``.
+    def _loader(self, split):
+        from torch.utils.data import DataLoader
+        dataset = instantiate(self.cfg.dataset[split], transform=self.transform)
+        return DataLoader(dataset, num_workers=self.cfg.train.num_workers, batch_size=self.cfg.train.batch_size)
+
+    def train_dataloader(self):
+        return self._loader("train")
+
+    def val_dataloader(self):
+        return self._loader("val")
+
+    def test_dataloader(self):
+        return self._loader("test")
 
 
 class DCGAN(BaseGAN):

@@ -6,14 +6,55 @@ from ... import functional as F
 from ...harness import draw_on_host
 
 
-@torch.no_grad()
+_INIT_RULES = (
+    # (layer types, attribute, mean, std) -- the DCGAN-paper initialisation the reference defines at utils.py:5-11
+    # and never applies (its two call sites are commented out, lightning_module.py:51-52)
+    ((nn.Conv2d, nn.ConvTranspose2d), "weight", 0.0, 0.02),
+    ((nn.BatchNorm2d,), "weight", 1.0, 0.02),
+    ((nn.BatchNorm2d,), "bias", 0.0, 0.0),
+)
+
+
 def init_weights(m):
-    # reference utils.py:5-11 (its call sites are commented out at lightning_module.py:51-52)
-    if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
-        nn.init.normal_(m.weight.data, 0.0, 0.02)
-    elif isinstance(m, (nn.BatchNorm2d)):
-        nn.init.normal_(m.weight.data, 1.0, 0.02)
-        nn.init.constant_(m.bias.data, 0)
+    """``net.apply(init_weights)``: N(0, 0.02) conv weights, N(1, 0.02) BatchNorm scales, zero BatchNorm shifts."""
+    for types, attr, mean, std in _INIT_RULES:
+        t = getattr(m, attr, None) if isinstance(m, types) else None
+        if t is None:
+            continue
+        with torch.no_grad():
+            t.normal_(mean, std) if std > 0 else t.fill_(mean)
+
+
+class VerboseShapeExecution(nn.Module):
+    """``cfg.debug.verbose_shape`` (reference utils.py:13-27, used as ``self.apply(VerboseShapeExecution)`` at
+    lightning_module.py:53-54): constructing it on a module makes every direct child print
+    ``<child name>: <input shape> --> <output shape>`` after each forward.  ``Module.apply`` constructs one per
+    module of the tree (and throws the wrapper away), so every layer of both networks reports once per call."""
+
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+        for child_name, child in model.named_children():
+            child.__name__ = child_name
+            child.register_forward_hook(_print_shapes)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+def _print_shapes(layer, inputs, output):
+    print(f"{layer.__name__}: {inputs[0].shape} --> {output.shape}")
+
+
+def interpolate_sphere(z1, z2, t):
+    """Spherical interpolation between latent rows (reference utils.py:29-37; the figure callbacks import it from
+    this module).  Latent-sized host / device arithmetic, not part of the image path."""
+    cos_omega = (z1 * z2).sum(dim=1, keepdim=True)
+    cos_omega = cos_omega / z1.pow(2).sum(dim=1, keepdim=True).sqrt()
+    cos_omega = cos_omega / z2.pow(2).sum(dim=1, keepdim=True).sqrt()
+    omega = torch.acos(cos_omega)
+    so = torch.sin(omega)
+    return torch.sin((1 - t) * omega) / so * z1 + torch.sin(t * omega) / so * z2
 
 
 def gradient_penalty(critic, real, fake, device="cpu", alpha=None):

@@ -46,3 +46,23 @@ def test_product_never_imports_oracle():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_a_library_built_from_other_sources_is_refused(monkeypatch):
+    """build.py stamps the library with a content digest of the kernel sources / headers / flags (no mtimes); the
+    loader compares it with the tree it runs from, so a snapshot carrying an old .so next to newer sources cannot
+    run stale kernels silently."""
+    from lightning_gan_zoo_amd import build
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    dll.gz_source_digest.restype = ctypes.c_char_p
+    assert dll.gz_source_digest().decode() == build.source_digest(), "rebuild: python -m lightning_gan_zoo_amd.build"
+    real = build._read
+    target = os.path.join(build.CSRC, "gz_common.h")
+    monkeypatch.setattr(build, "_read", lambda p: real(p) + (b"// edited\n" if p == target else b""))
+    assert build.source_digest() != dll.gz_source_digest().decode()
+    monkeypatch.delenv("GZ_LIB", raising=False)
+    with pytest.raises(RuntimeError, match="built from other sources"):
+        _lib._check_digest(dll)
+    monkeypatch.setenv("GZ_ALLOW_STALE", "1")
+    with pytest.warns(UserWarning, match="built from other sources"):
+        _lib._check_digest(dll)
