@@ -37,7 +37,15 @@ FLOP_PER_SAMPLE_CYCLE = {
     # passes + the R1 double backward) + G step 2,354,610,176, traced on the oracle as PyTorch autograd executes it
     "gan_stability_r1": 7_037_173_760,
 }
+# HoloGAN EXT-128 (the reference cannot run at 128x128): traced the same way on the oracle's
+# extension, tools/flop_trace.py hologan 128 -> D step 11.4411 G + 2 x G step 13.7115 G
+FLOP_PER_SAMPLE_CYCLE_EXT128 = {"hologan": 38_864_160_640}
 NATIVE_IMG_SIZE = {"gan_stability_r1": 128}
+# BASELINE.json configs measured in the default single-GPU run next to the headline (configs[1] = dc_gan bs 512):
+# the metric string's own batch, config 3 (wgan_gp bs 256) and config 5's per-GPU workload (hologan bs 64, at the
+# parity-pinned 64x64 and as EXT-128)
+SUB_CONFIGS = (("dc_gan_bs128", "dc_gan", 128, 64), ("wgan_gp_bs256", "wgan_gp", 256, 64),
+               ("hologan_bs64", "hologan", 64, 64), ("hologan_ext128_bs64", "hologan", 64, 128))
 DEFAULT_BATCH = {"dc_gan": 512, "wgan": 512, "wgan_gp": 256, "hologan": 64, "gan_stability_r1": 64}
 PEAK_FP32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
 TIMER_EVERY = 4     # per-launch HIP events on every 4th cycle of the timed region (they cost ~5 % when always on)
@@ -55,7 +63,9 @@ def parse_args(argv=None):
     ap.add_argument("--img-size", type=int, default=None,
                     help="default 64 (128 for gan_stability_r1); 128 with --expt hologan is EXT-128, not parity-pinned")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-bs128", action="store_true")
+    ap.add_argument("--no-bs128", "--no-sub-configs", dest="no_bs128", action="store_true",
+                    help="headline configuration only (skip the dc_gan bs128 / wgan_gp / hologan sub-records)")
+    ap.add_argument("--sub-steps", type=int, default=10, help="timed optimizer cycles per repetition of a sub-record")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay each optimizer step from a captured HIP graph (single GPU)")
@@ -239,6 +249,55 @@ def roofline_of(timer, ms_per_step, steps, flop_cycle):
     }
 
 
+def flop_per_cycle(expt, batch, img_size):
+    if img_size == NATIVE_IMG_SIZE.get(expt, 64):
+        return FLOP_PER_SAMPLE_CYCLE[expt] * batch
+    if img_size == 128 and expt in FLOP_PER_SAMPLE_CYCLE_EXT128:
+        return FLOP_PER_SAMPLE_CYCLE_EXT128[expt] * batch
+    return float("nan")                # no traced FLOP count for this size
+
+
+def sub_record(F, expt, batch, img_size, device, steps, warmup, reps, use_timer):
+    """One more BASELINE configuration on this GPU, measured exactly like the headline (same trainer, same timed
+    region, per-launch HIP events on the launch stream for the roofline of its dominant kernel)."""
+    import torch
+    module, trainer = build_trainer(expt, batch, device, 1, img_size=img_size)
+    data = synthetic_batch(batch, device, 0, img_size)
+    timer = F.KernelTimer()
+    for _ in range(2):
+        trainer.step(data)
+    trainer.finish()
+    if use_timer:
+        F.set_kernel_timer(timer)
+    times, _, dt = timed_pairs(trainer, data, steps, warmup, 1, timer, reps)
+    F.set_kernel_timer(None)
+    torch.cuda.synchronize()
+    ms = dt / steps * 1e3
+    per_cycle = len(trainer.order)
+    rec = {"workload": "%s synthetic %dx%d bs=%d/GPU, one optimizer cycle of %d batches%s"
+                       % (expt, img_size, img_size, batch, per_cycle,
+                          " (EXT-128: stride-2 extension, not parity-pinned)" if expt == "hologan" and img_size == 128 else ""),
+           "value": round(per_cycle * batch * steps / dt, 1), "unit": "images/s", "ms_per_step": round(ms, 3),
+           "steps": steps, "ms_per_step_each": [round(t / steps * 1e3, 3) for t in times]}
+    fl = flop_per_cycle(expt, batch, img_size)
+    roof = roofline_of(timer, times[0] / steps * 1e3, steps, fl)
+    if roof is not None:
+        if roof["whole_step"] is not None:
+            a = fl / (ms * 1e-3) / 1e12
+            roof["whole_step"].update(achieved=round(a, 2), frac=round(a / PEAK_FP32_MFMA_TFLOPS, 4))
+        roof["traffic"] = None
+        rec["roofline"] = roof
+    elif fl == fl:
+        a = fl / (ms * 1e-3) / 1e12
+        rec["roofline"] = {"whole_step": {"flop_per_step": fl, "achieved": round(a, 2),
+                                          "frac": round(a / PEAK_FP32_MFMA_TFLOPS, 4)}}
+    del trainer, module, data
+    gc.unfreeze()
+    gc.collect()
+    torch.cuda.empty_cache()
+    return rec
+
+
 def run_rank(args):
     import torch
     import torch.distributed as dist
@@ -291,12 +350,10 @@ def run_rank(args):
     ms_per_step = dt / args.steps * 1e3
     per_cycle = len(trainer.order)            # batches per optimizer cycle: 2 (dc_gan, wgan_gp), 6 (wgan), 3 (hologan)
     value = per_cycle * args.batch * world * args.steps / dt
-    flop_cycle = FLOP_PER_SAMPLE_CYCLE[args.expt] * args.batch
-    if args.img_size != NATIVE_IMG_SIZE.get(args.expt, 64):
-        flop_cycle = float("nan")      # the reference cannot run this size; no traced FLOP count exists
+    flop_cycle = flop_per_cycle(args.expt, args.batch, args.img_size)
 
     out = {
-        "metric": "images/sec (G+D step) at %dx%d" % (args.img_size, args.img_size),
+        "metric": "images/sec (G+D step) at %dx%d bs=%d/GPU" % (args.img_size, args.img_size, args.batch),
         "value": round(value, 1),
         "unit": "images/s",
         "n_gpus": world,
@@ -332,28 +389,25 @@ def run_rank(args):
                 a = flop_cycle / (ms_per_step * 1e-3) / 1e12
                 roof["whole_step"].update(achieved=round(a, 2), frac=round(a / PEAK_FP32_MFMA_TFLOPS, 4))
             out["roofline"] = roof
-        if world == 1 and not args.no_bs128 and args.batch != 128 and args.expt == "dc_gan":
-            # BASELINE.json's metric string quotes bs=128/GPU: the same measurement at that batch, with its own
-            # per-kernel roofline
+        if world == 1 and not args.no_bs128 and args.expt == "dc_gan" and args.img_size == 64:
+            # the other BASELINE configurations a single GPU runs: the metric string's bs=128/GPU, config 3
+            # (wgan_gp bs 256), config 5's per-GPU workload (hologan bs 64; 64x64 parity-pinned and EXT-128)
             del trainer, module
+            gc.unfreeze()
+            gc.collect()
             torch.cuda.empty_cache()
-            m2, t2 = build_trainer(args.expt, 128, device, 1)
-            b2 = synthetic_batch(128, device, 0)
-            timer2 = F.KernelTimer()
-            if not args.no_kernel_timer:
-                F.set_kernel_timer(timer2)
-            times2, _, dt2 = timed_pairs(t2, b2, args.steps, args.warmup, 1, timer2, args.reps)
-            F.set_kernel_timer(None)
-            ms2 = dt2 / args.steps * 1e3
-            out["bs128"] = {"value": round(per_cycle * 128 * args.steps / dt2, 1), "unit": "images/s",
-                            "ms_per_step": round(ms2, 3),
-                            "ms_per_step_each": [round(t / args.steps * 1e3, 3) for t in times2]}
-            roof2 = roofline_of(timer2, times2[0] / args.steps * 1e3, args.steps, FLOP_PER_SAMPLE_CYCLE[args.expt] * 128)
-            if roof2 is not None:
-                a = FLOP_PER_SAMPLE_CYCLE[args.expt] * 128 / (ms2 * 1e-3) / 1e12
-                roof2["whole_step"].update(achieved=round(a, 2), frac=round(a / PEAK_FP32_MFMA_TFLOPS, 4))
-                roof2["traffic"] = None
-                out["bs128"]["roofline"] = roof2
+            out["sub_configs"] = {}
+            for key, expt, bs, img in SUB_CONFIGS:
+                if expt == args.expt and bs == args.batch and img == args.img_size:
+                    continue
+                steps = args.steps if expt == "dc_gan" else min(args.steps, args.sub_steps)
+                out["sub_configs"][key] = sub_record(F, expt, bs, img, device, steps, args.warmup, args.reps,
+                                                     not args.no_kernel_timer)
+            if "dc_gan_bs128" in out["sub_configs"]:
+                b = out["sub_configs"]["dc_gan_bs128"]
+                out["bs128"] = b                 # the key earlier rounds' records used
+                out["config"]["workload"] += ("; the metric string's bs=128/GPU on the same GPU: %.0f images/s, "
+                                              "%.3f ms per pair (sub_configs.dc_gan_bs128)" % (b["value"], b["ms_per_step"]))
         if world == 1 and not args.no_cpu_baseline and args.expt == "dc_gan":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), file=result_out, flush=True)

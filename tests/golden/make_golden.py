@@ -6,6 +6,7 @@ Run in the build container only (the reference does not exist on the GPU box):
 
     python tests/golden/make_golden.py            # all fixtures
     python tests/golden/make_golden.py dc_gan     # one experiment
+    python tests/golden/make_golden.py pinned     # the *_full_pinned.npz fixtures (reference mask decisions)
 
 Each fixture holds the latent / alpha inputs (``in/...``; the synthetic reals are regenerated
 from their seeds and pinned by a checksum), everything tests/scenario.py records (``out/...``)
@@ -82,7 +83,7 @@ class _MaskMargins:
         self.handle.remove()
 
 
-def run_reference(expt, size, stable, dtype, full, inputs):
+def run_reference(expt, size, stable, dtype, full, inputs, **scenario_kw):
     """The step is always CONSTRUCTED under the float32 default dtype, whatever ``dtype`` the run uses: the
     spectral-norm ``weight_u / weight_v`` buffers are drawn at construction, and drawing them in double gives
     different vectors -- the fp64 run would then measure "another u/v", not fp32 rounding (that is what the
@@ -106,11 +107,38 @@ def run_reference(expt, size, stable, dtype, full, inputs):
     torch.set_default_dtype(dtype)
     try:
         out = scenario.run_scenario(step, inputs, "cpu", full=full, set_alpha=set_alpha, stable=stable,
-                                    dtype=dtype)
+                                    dtype=dtype, **scenario_kw)
     finally:
         torch.set_default_dtype(torch.float32)
         ns.utils.torch = torch
     return out
+
+
+PINNED_EXPTS = ("dc_gan", "wgan", "wgan_gp")
+PINNED_KW = dict(pairs=1, skip_opt=True, probe=False)
+
+
+def make_pinned(expt):
+    """``<expt>_full_pinned.npz``: the features-64 / bs-8 scenario on the plain (un-stabilised) closed-form
+    parameters, one D step and one G step from those parameters (no optimizer step in between), together with every
+    ReLU / LeakyReLU decision the reference took (``mask/NNN`` packed bits in call order, ``mask_shape/NNN``;
+    observed with a global forward hook -- tests/mask_pinning.py -- the reference is not modified).  Oracle and
+    product are re-run with exactly these decisions and compared at the plain 1e-3, every gradient included."""
+    from mask_pinning import MaskTape, record_module_masks
+    inputs = scenario.make_inputs(expt, "full")
+    tape = MaskTape()
+    with record_module_masks(tape):
+        out = run_reference(expt, "full", False, torch.float32, False, inputs, **PINNED_KW)
+    blob = {"in/" + k: v.numpy() for k, v in inputs.items() if not k.startswith("real_")}
+    blob["in/real_checksum"] = np.float64(sum(float(v.double().sum()) for k, v in sorted(inputs.items())
+                                              if k.startswith("real_")))
+    blob.update({"out/" + k: np.asarray(v) for k, v in out.items()})
+    blob.update(tape.to_arrays())
+    path = os.path.join(HERE, f"{expt}_full_pinned.npz")
+    np.savez_compressed(path, **blob)
+    bits = sum(m.numel() for m in tape.masks)
+    print(f"{path}: {len(tape.masks)} mask decisions, {bits / 8e6:.2f} MB of bits, file "
+          f"{os.path.getsize(path) / 1e6:.2f} MB, loss_d0={out['loss_d0']:.6f} loss_g0={out['loss_g0']:.6f}")
 
 
 def sensitivity(o32, o64):
@@ -129,6 +157,10 @@ def sensitivity(o32, o64):
 
 def main(argv):
     torch.set_num_threads(8)
+    if argv and argv[0] == "pinned":
+        for expt in argv[1:] or PINNED_EXPTS:
+            make_pinned(expt)
+        return
     expts = argv or list(scenario.STD_EXPTS)
     for expt in expts:
         variants = [("tiny", False), ("full", False)]

@@ -29,10 +29,37 @@ class MaskTape:
     def record(self, out):
         self.masks.append((out.detach() > 0).cpu())
 
+    # -- fixture form: one packed bit array + one shape per decision, in call order
+    def to_arrays(self):
+        import numpy as np
+        blob = {}
+        for i, m in enumerate(self.masks):
+            blob["mask/%03d" % i] = np.packbits(m.numpy().reshape(-1))
+            blob["mask_shape/%03d" % i] = np.asarray(m.shape, dtype=np.int64)
+        return blob
+
+    @classmethod
+    def from_arrays(cls, blob):
+        import numpy as np
+        tape = cls()
+        keys = sorted(k for k in blob.keys() if k.startswith("mask/"))
+        for k in keys:
+            shape = tuple(int(d) for d in blob["mask_shape/" + k[5:]])
+            n = int(np.prod(shape))
+            bits = np.unpackbits(np.asarray(blob[k]))[:n].astype(bool).reshape(shape)
+            tape.masks.append(torch.from_numpy(bits))
+        return tape
+
+    def rewind(self):
+        self.cursor = 0
+        self.mismatches = []
+        return self
+
     def replay(self, x, slope):
         mask = self.masks[self.cursor]
         self.cursor += 1
         assert mask.shape == x.shape, (self.cursor, tuple(mask.shape), tuple(x.shape))
+        mask = mask.to(x.device)
         natural = x.detach() > 0
         diff = int((natural != mask).sum())
         if diff:
@@ -110,3 +137,83 @@ def pinned_oracle_masks(step, tape):
         H.torch = old_torch
         for obj, name, mod in saved:
             setattr(obj, name, mod)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Reference-pinned decisions (round 3): tests/golden/make_golden.py records the mask decisions of the UNMODIFIED
+# reference (``*_pinned.npz``); the oracle (plain nn.ReLU / nn.LeakyReLU modules) and the product (fused HIP
+# activation epilogues) are then both run with THOSE decisions, so every gradient can be held to the plain 1e-3
+# against the reference's own numbers, with no conditioning slack.
+# ---------------------------------------------------------------------------------------------------------------
+_ACT_MODULES = (torch.nn.ReLU, torch.nn.LeakyReLU)
+
+
+def _slope_of(mod):
+    return float(getattr(mod, "negative_slope", 0.0))
+
+
+@contextlib.contextmanager
+def record_module_masks(tape):
+    """Observe every nn.ReLU / nn.LeakyReLU forward of whatever runs inside (the reference, the oracle): a global
+    forward hook, nothing is modified."""
+    def hook(mod, inp, out):
+        if isinstance(mod, _ACT_MODULES):
+            tape.record(out)
+    handle = torch.nn.modules.module.register_module_forward_hook(hook)
+    try:
+        yield tape
+    finally:
+        handle.remove()
+
+
+@contextlib.contextmanager
+def pinned_module_masks(tape):
+    """Every nn.ReLU / nn.LeakyReLU forward inside takes its decision from ``tape``: the global forward hook
+    replaces the module's output by ``where(mask, x, slope * x)``."""
+    def hook(mod, inp, out):
+        if isinstance(mod, _ACT_MODULES):
+            return tape.replay(inp[0], _slope_of(mod))
+        return None
+    handle = torch.nn.modules.module.register_module_forward_hook(hook)
+    try:
+        yield tape
+    finally:
+        handle.remove()
+
+
+@contextlib.contextmanager
+def pinned_product_masks(tape):
+    """The product's fused ops with the activation taken OUT of the kernel epilogue and decided by ``tape``: the op
+    runs with ACT_NONE (same convolution / normalisation kernels, forward and backward) and the activation is
+    ``where(mask, y, slope * y)`` on the device.  For every element on whose sign the product and the tape agree this
+    is the fused epilogue's own result; the others are counted in ``tape.mismatches`` with their magnitude."""
+    from lightning_gan_zoo_amd import functional as F
+    saved = {}
+
+    def wrap(name, act_pos, slope_pos):
+        fn = getattr(F, name)
+        saved[name] = fn
+
+        def inner(*a, **k):
+            a = list(a)
+            act = k.get("act", a[act_pos] if len(a) > act_pos else F.ACT_NONE)
+            slope = k.get("slope", a[slope_pos] if len(a) > slope_pos else 0.0)
+            if act not in (F.ACT_RELU, F.ACT_LRELU):
+                return fn(*a, **k)
+            if len(a) > act_pos:
+                a[act_pos] = F.ACT_NONE
+            else:
+                k["act"] = F.ACT_NONE
+            y = fn(*a, **k)
+            return tape.replay(y, float(slope) if act == F.ACT_LRELU else 0.0)
+        setattr(F, name, inner)
+
+    wrap("batch_norm_act", 9, 10)       # (x, gamma, beta, rm, rv, nbt, training, momentum, eps, act, slope, stats)
+    wrap("instance_norm_act", 4, 5)     # (x, gamma, beta, eps, act, slope)
+    wrap("conv2d", 4, 5)                # (x, w, bias, geom, act, slope)
+    wrap("conv_transpose2d", 4, 5)
+    try:
+        yield tape
+    finally:
+        for name, fn in saved.items():
+            setattr(F, name, fn)

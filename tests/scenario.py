@@ -204,7 +204,7 @@ def initial_params(step, full=True, stable=False):
 
 
 def run_scenario(step, inputs, device="cpu", full=True, set_alpha=None, pairs=2, stable=False,
-                 dtype=torch.float32, shadow=None):
+                 dtype=torch.float32, shadow=None, skip_opt=None, probe=True):
     """``set_alpha(step, alpha)`` installs the GP interpolation coefficients for
     implementations that accept injection; the reference draws them from the
     host RNG, so make_golden.py patches torch.rand instead.  ``dtype=float64`` is used only to
@@ -214,7 +214,12 @@ def run_scenario(step, inputs, device="cpu", full=True, set_alpha=None, pairs=2,
     state_dict of ``step`` (as trained so far) and evaluates the same batch; its loss is recorded
     as ``shadow_loss_*``.  Losses after optimizer steps cannot be compared with a fixture at 1e-3
     (Adam turns rounding-level gradient differences into +-lr parameter differences), but they
-    can be compared with the oracle evaluated on the very same parameters."""
+    can be compared with the oracle evaluated on the very same parameters.
+
+    ``skip_opt`` (default: ``stable``): no optimizer step between the training steps and gradients recorded for
+    every pair -- a pure gradient check from the starting parameters.  ``probe=False`` leaves out the no-grad
+    G / D probe pass (the pinned-mask fixtures: fewer mask decisions to store)."""
+    skip_opt = stable if skip_opt is None else skip_opt
     dev = torch.device(device)
     _prepare(step, stable)
     step.to(dev)
@@ -225,15 +230,16 @@ def run_scenario(step, inputs, device="cpu", full=True, set_alpha=None, pairs=2,
     out = {}
     labels = torch.zeros(len(inputs["real_d0"]), dtype=torch.int64, device=dev)
 
-    probe = copy.deepcopy(step)
-    seed_views(step, 7000)          # HoloGAN draws its views from numpy's global generator
-    with torch.no_grad():
-        fake = probe.generator(inputs["z_d0"].to(dev))
-        d_out = probe.discriminator(fake)
-        logit = d_out[0] if isinstance(d_out, tuple) else d_out
-    out["probe/fake"] = fake.cpu().numpy() if full else summarize(fake, 64)
-    out["probe/logits"] = logit.reshape(-1).cpu().numpy()
-    del probe
+    if probe:
+        probe = copy.deepcopy(step)
+        seed_views(step, 7000)          # HoloGAN draws its views from numpy's global generator
+        with torch.no_grad():
+            fake = probe.generator(inputs["z_d0"].to(dev))
+            d_out = probe.discriminator(fake)
+            logit = d_out[0] if isinstance(d_out, tuple) else d_out
+        out["probe/fake"] = fake.cpu().numpy() if full else summarize(fake, 64)
+        out["probe/logits"] = logit.reshape(-1).cpu().numpy()
+        del probe
 
     for pair in range(pairs):
         for idx, tag in ((0, "d"), (1, "g")):
@@ -260,7 +266,7 @@ def run_scenario(step, inputs, device="cpu", full=True, set_alpha=None, pairs=2,
             out[f"loss_{tag}{pair}"] = np.float64(loss.item())
             for k, v in step.logged.items():
                 out[f"log{pair}{tag}/{k}"] = np.float64(float(v))
-            if pair == 0 or stable:
+            if pair == 0 or skip_opt:
                 net = step.discriminator if idx == 0 else step.generator
                 gtag = f"grad_{tag}" if pair == 0 else f"grad{pair}_{tag}"
                 _dump(gtag, ((n, p.grad) for n, p in net.named_parameters()), out, full)
@@ -270,7 +276,7 @@ def run_scenario(step, inputs, device="cpu", full=True, set_alpha=None, pairs=2,
                 if pair == 0:
                     _buffers(f"buf_{tag}", step, out)
             opt = opts[idx]["optimizer"]
-            if not stable:      # stable-mask runs are pure gradient checks: with activations ~8 one Adam
+            if not skip_opt:    # stable-mask runs are pure gradient checks: with activations ~8 one Adam
                 opt.step()      # step of D would saturate BCE / tanh and zero the G gradients
             opt.zero_grad()
     _dump("final/generator", step.generator.named_parameters(), out, full)

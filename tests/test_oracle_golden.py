@@ -215,3 +215,58 @@ def test_oracle_state_dict_names_match_reference_listing():
     assert not any(k.startswith("resnet.1.") for k in g)          # Upsample holds no state
     assert d[:2] == ["conv_img.weight", "conv_img.bias"] and d[-2:] == ["fc.weight", "fc.bias"]
     assert {"resnet.0.conv_0.bias", "resnet.2.conv_s.weight", "resnet.6.conv_1.weight"} <= set(d)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# reference-pinned mask fixtures (tests/golden/make_golden.py pinned)
+# ---------------------------------------------------------------------------------------------------------------
+PINNED_EXPTS = ("dc_gan", "wgan", "wgan_gp")
+PINNED_KW = dict(pairs=1, skip_opt=True, probe=False)
+
+
+def load_pinned(expt):
+    """-> (inputs, the reference's outputs, MaskTape holding the reference's ReLU / LeakyReLU decisions)"""
+    from mask_pinning import MaskTape
+    blob = np.load(os.path.join(GOLDEN_DIR, f"{expt}_full_pinned.npz"))
+    inputs = scenario.make_inputs(expt, "full")
+    for k in blob.files:
+        if k.startswith("in/") and k != "in/real_checksum":
+            assert torch.equal(inputs[k[3:]], torch.from_numpy(blob[k])), f"host RNG drift in {k}"
+    chk = sum(float(v.double().sum()) for k, v in sorted(inputs.items()) if k.startswith("real_"))
+    assert abs(chk - float(blob["in/real_checksum"])) < 1e-6 * max(1.0, abs(chk)), "host RNG drift in reals"
+    golden = {k[4:]: blob[k] for k in blob.files if k.startswith("out/")}
+    return inputs, golden, MaskTape.from_arrays(blob)
+
+
+def pinned_scale(expt):
+    """logit scale of the scenario (WGAN's losses are differences of logit means, ~1e-6 on clipped weights)"""
+    return float(np.abs(load_golden(expt, "full")[1]["probe/logits"]).max())
+
+
+@pytest.mark.parametrize("expt", PINNED_EXPTS)
+def test_oracle_takes_the_reference_mask_decisions(expt):
+    """The oracle on the pinned scenario (plain closed-form parameters, features 64, bs 8, one D and one G step):
+    (1) by itself it takes the reference's ReLU / LeakyReLU decisions -- all ~7 M of them -- and reproduces the
+    reference's losses, gradients and buffers at 1e-5; (2) run THROUGH the pinning hook (decisions replayed from the
+    fixture) it gives the same numbers, i.e. the hook is the identity when the decisions agree.  This is the link
+    'oracle + reference masks == reference' that the GPU test builds on."""
+    from mask_pinning import MaskTape, pinned_module_masks, record_module_masks
+    torch.set_num_threads(4)
+    inputs, golden, ref_tape = load_pinned(expt)
+    scale = pinned_scale(expt)
+    own = MaskTape()
+    with record_module_masks(own):
+        out = scenario.run_scenario(build_oracle_step(expt, "full"), inputs, "cpu", full=False, set_alpha=set_alpha,
+                                    **PINNED_KW)
+    compare(out, golden, 1e-5, f"oracle {expt}/full/pinned (natural)", atol_scale=scale)
+    assert len(own.masks) == len(ref_tape.masks)
+    differing = sum(int((a != b).sum()) for a, b in zip(own.masks, ref_tape.masks))
+    total = sum(m.numel() for m in ref_tape.masks)
+    print(f"{expt}: {differing} of {total} decisions differ between oracle and reference")
+    assert differing <= 4, differing            # same torch CPU kernels; a thread-count-dependent last bit at most
+    with pinned_module_masks(ref_tape.rewind()):
+        out = scenario.run_scenario(build_oracle_step(expt, "full"), inputs, "cpu", full=False, set_alpha=set_alpha,
+                                    **PINNED_KW)
+    assert ref_tape.cursor == len(ref_tape.masks)
+    assert sum(m[1] for m in ref_tape.mismatches) <= 4, ref_tape.mismatches
+    compare(out, golden, 1e-5, f"oracle {expt}/full/pinned (replayed)", atol_scale=scale)
