@@ -21,7 +21,29 @@ using Cfg128x64 = TileCfg<2, 2, 2, 1>;
 using Cfg128x32 = TileCfg<4, 1, 1, 1>;
 using Cfg64x64 = TileCfg<2, 2, 1, 1>;
 
-enum TileId { T128x128 = 0, T128x64 = 1, T128x32 = 2, T64x64 = 3 };
+// round 3 (gz_igemm.h, igemm2): one wavefront per SIMD, 128x128 / 128x64 accumulators per wavefront
+using Cfg256x256 = TileCfg2<2, 2, 4, 1>;
+using Cfg256x128 = TileCfg2<2, 2, 2, 2>;
+
+enum TileId { T128x128 = 0, T128x64 = 1, T128x32 = 2, T64x64 = 3, T256x256 = 4, T256x128 = 5 };
+
+// Which launches take the igemm2 skeleton: its workgroup is a whole CU's worth of matrix pipes (one wavefront per
+// SIMD), so 256 tiles already fill the chip and anything from there up runs at the loop's rate; fewer would leave
+// CUs idle (those launches keep igemm_kernel + split-K).  256x128 tiles keep two workgroups per CU, whose prologues /
+// epilogues overlap each other's main loops: preferred unless that halves a long reduction's operand reuse for nothing.
+static TileId pick_tile2(long long M, long long N, int ny, int kdim) {
+    static const bool off = getenv("GZ_NO_IGEMM2") != nullptr;
+    if (off || N < 128 || kdim < 256) return T64x64;            // "not applicable"
+    const long long t128 = ((M + 255) / 256) * ((N + 127) / 128) * ny;
+    const long long t256 = ((M + 255) / 256) * ((N + 255) / 256) * ny;
+    static const int force = getenv("GZ_IGEMM2_TILE") ? atoi(getenv("GZ_IGEMM2_TILE")) : 0;
+    if (force == 256 && N >= 256 && t256 >= 256) return T256x256;
+    if (force == 128 && t128 >= 256) return T256x128;
+    if (t128 >= 512) return T256x128;
+    if (N >= 256 && t256 >= 256) return T256x256;
+    if (t128 >= 256) return T256x128;
+    return T64x64;
+}
 
 static int g_force_tile = -2;
 
@@ -94,6 +116,7 @@ struct SplitPlan {
 };
 
 static long long tile_count(TileId t, long long M, long long N, int ny) {
+    if (t == T256x256 || t == T256x128) return ((M + 255) / 256) * ((N + (t == T256x256 ? 255 : 127)) / (t == T256x256 ? 256 : 128)) * ny;
     const int bm = t == T64x64 ? 64 : 128;
     const int bn = t == T128x128 ? 128 : (t == T128x32 ? 32 : 64);
     return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * ny;
@@ -700,6 +723,31 @@ static int run_dgrad(const float* y, const float* wp, const float* bias, float* 
     return launch_igemm<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kg, G::s * G::s, splits, st, slab);
 }
 
+// k4 s2 p1 transposed convolution on the igemm2 skeleton (row-shared A rows by LDS-DMA, packed per-phase weights)
+template <class Cfg>
+static int run_dgrad2(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s, int act,
+                      float slope, hipStream_t st, float* stats = nullptr) {
+    using AL = ConvDgA2<Cfg::BM>;
+    using BL = MContigB2<Cfg::BN>;
+    using Epi = EpiPhaseB<2>;
+    const int AH = s.H / 2, AW = s.W / 2;
+    typename AL::Params pa{y, s, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW)};
+    const int Kg = s.K * 4;
+    const int ldc = round4(s.C);
+    typename BL::Params pb{wp, Kg, ldc, ldc, (long long)Kg * ldc};
+    const int M = s.N * AH * AW;
+    typename Epi::Params pe{x, M, s.C, s.H, s.W, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW), bias, act, slope,
+                            reinterpret_cast<f32x2*>(stats), ((M + Cfg::BM - 1) / Cfg::BM) * Cfg::WM};
+    return launch_igemm2<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kg, 4, 1, st);
+}
+
+template <class G>
+static bool dgrad2_ok(const ConvShape& s) {
+    // ConvDgA2: 16-byte pieces of whole pixel quads; a tile's first pixel starts an image row (256 % AW == 0)
+    return G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1 && s.H == 2 * s.OH && s.W == 2 * s.OW && s.OW % 4 == 0 &&
+           256 % s.OW == 0 && s.K % 4 == 0;
+}
+
 template <class G>
 static bool dgrad_direct(const float* x, const ConvShape& s) {
     return G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1 && s.C <= 4 && s.H == 2 * s.OH && s.W == 2 * s.OW &&
@@ -711,6 +759,10 @@ static SplitPlan dgrad_plan(const ConvShape& s) {
     constexpr int TAPS = ((G::kh + G::s - 1) / G::s) * ((G::kw + G::s - 1) / G::s);
     long long M = (long long)s.N * (s.H / G::s) * (s.W / G::s);
     const int kk = dgrad_tap_major(s.K, G::kh, G::kw, G::s) ? round_bk(s.K) : s.K;
+    if (dgrad2_ok<G>(s)) {
+        const TileId t2 = pick_tile2(M, s.C, 4, s.K * 4);
+        if (t2 == T256x256 || t2 == T256x128) return SplitPlan{t2, 1};
+    }
     return plan_split(M, s.C, kk * TAPS, G::s * G::s, pick_tile(M, s.C, G::s * G::s, kk * TAPS));
 }
 
@@ -738,7 +790,11 @@ static int dispatch_dgrad(const float* y, const float* wp, const float* bias, fl
     SplitPlan sp = dgrad_plan<G>(s);
     if (sp.splits > 1 && (!ws || ws_bytes < dgrad_ws_bytes<G>(s))) sp = SplitPlan{pick_tile(M, s.C, G::s * G::s), 1};
     float* slab = sp.splits > 1 ? ws : nullptr;
+    if ((sp.tile == T256x256 || sp.tile == T256x128) && (((uintptr_t)y) & 15) != 0)
+        sp = SplitPlan{pick_tile(M, s.C, G::s * G::s), 1};        // unaligned tensor: the element-wise loaders
     switch (sp.tile) {
+        case T256x256: return run_dgrad2<Cfg256x256>(y, wp, bias, x, s, act, slope, st);
+        case T256x128: return run_dgrad2<Cfg256x128>(y, wp, bias, x, s, act, slope, st);
         case T128x128: return run_dgrad<G, Cfg128x128>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
         case T128x64: return run_dgrad<G, Cfg128x64>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
         case T128x32: return run_dgrad<G, Cfg128x32>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
@@ -1343,6 +1399,7 @@ int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* dbias, flo
 // ---- convolution + BatchNorm statistics in one launch --------------------------------------------------------
 static int stats_wm(TileId t) { return t == T128x32 ? 4 : 2; }
 static int stats_tm_rows(TileId t, long long M) {       // partial rows per phase: tiles_m * WM
+    if (t == T256x256 || t == T256x128) return (int)((M + 255) / 256) * 2;
     const int bm = t == T64x64 ? 64 : 128;
     return (int)((M + bm - 1) / bm) * stats_wm(t);
 }
@@ -1397,6 +1454,8 @@ int gz_conv2d_dgrad_stats(const float* y, const float* wpack, float* x, float* s
 #define CALL(G)                                                                                                        \
     [&]() -> int {                                                                                                     \
         switch (dgrad_plan<G>(s).tile) {                                                                               \
+            case T256x256: return run_dgrad2<Cfg256x256>(y, wpack, nullptr, x, s, 0, 0.f, stream, stats);               \
+            case T256x128: return run_dgrad2<Cfg256x128>(y, wpack, nullptr, x, s, 0, 0.f, stream, stats);               \
             case T128x128: return run_dgrad<G, Cfg128x128>(y, wpack, nullptr, x, s, 0, 0.f, stream, 1, nullptr, stats); \
             case T128x64: return run_dgrad<G, Cfg128x64>(y, wpack, nullptr, x, s, 0, 0.f, stream, 1, nullptr, stats);   \
             case T128x32: return run_dgrad<G, Cfg128x32>(y, wpack, nullptr, x, s, 0, 0.f, stream, 1, nullptr, stats);   \
@@ -1458,12 +1517,24 @@ int gz_conv2d_fwd_any(const float* x, const float* wpack, const float* bias, flo
     }
 }
 
+#ifdef GZ2_STAMPS
+/* diagnostic builds only: copies the per-workgroup stamps of the last igemm2 launch (n x 8 x u64) */
+int gz_debug_read_stamps(void* out, int nwg) {
+    return hip_status(hipMemcpyFromSymbol(out, HIP_SYMBOL(gz::gz2_stamps), (size_t)nwg * 64, 0, hipMemcpyDeviceToHost));
+}
+#endif
+
 /* which tile configuration a launch of op (0 F, 1 Dg, 2 Wg) would use: 0 128x128, 1 128x64, 2 128x32, 3 64x64 */
 int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S) {
     // (the reduction lengths below ignore the channel padding of the tap-major loaders: labels only)
     if (op == 0) return pick_tile_fwd((long long)N * OH * OW, K, OW, KH, KW, S, C * KH * KW);
-    if (op == 1)
+    if (op == 1) {
+        if (KH == 4 && KW == 4 && S == 2 && H == 2 * OH && W == 2 * OW && OW % 4 == 0 && 256 % OW == 0 && K % 4 == 0) {
+            const TileId t2 = pick_tile2((long long)N * (H / S) * (W / S), C, 4, K * 4);
+            if (t2 == T256x256 || t2 == T256x128) return t2;
+        }
         return pick_tile((long long)N * (H / S) * (W / S), C, S * S, K * ((KH + S - 1) / S) * ((KW + S - 1) / S));
+    }
     long long NTOT = (long long)C * KH * KW;
     int t;
     if (NTOT <= 32) t = T128x32;

@@ -1624,6 +1624,57 @@ struct EpiPhase3D {
     }
 };
 
+// EpiPhase with a lean store path for the igemm2 skeleton, where a workgroup's epilogue is NOT hidden behind three
+// other resident workgroups: when there is no bias / activation and the wavefront's channel block lies inside the
+// tensor, an accumulator goes out as  v_accvgpr_read + buffer_store  with a per-lane byte offset computed once per
+// 32-pixel block (pixel decode, 4 VGPRs) and the channel advanced through the SCALAR offset -- ~3 instructions per
+// store instead of ~20 (address arithmetic, predicates and branches per element; 34-55 k cycles per 128 accumulators
+// measured with in-kernel stamps).  Pixels past M carry an out-of-range offset (dropped by the range check).
+template <int S>
+struct EpiPhaseB {
+    static constexpr bool SWAP = true;
+    using Params = typename EpiPhase<S>::Params;
+    template <int TM, int TN>
+    __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
+                                                 int n_base, int lane, int y, int z) {
+        const bool fast = !p.bias && p.act == ACT_NONE && n_base + TN * 32 <= p.C;       // wave-uniform
+        if (!fast) {
+            EpiPhase<S>::template store<TM, TN>(p, acc, m_base, n_base, lane, y, z);
+            return;
+        }
+        const int col_l = lane & 31, half = lane >> 5;
+        if (p.stats)
+            tile_channel_stats<TM, TN>(acc, p.stats, (long long)y * p.stats_rows + m_base / (TM * 32), p.C, n_base, lane);
+        const int py = y / S, px = y % S;
+        const uint32_t chs = (uint32_t)(p.H * p.W) * 4u;                 // bytes between channel planes
+        __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.out, (uint32_t)(p.M / (p.AH * p.AW)) * (uint32_t)p.C * chs);
+        uint32_t voff[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m_base + i * 32 + col_l;
+            const uint32_t n = fdiv((uint32_t)m, p.div_ahw);
+            const uint32_t pix = (uint32_t)m - n * (uint32_t)(p.AH * p.AW);
+            const uint32_t a = fdiv(pix, p.div_aw);
+            const uint32_t b = pix - a * (uint32_t)p.AW;
+            const uint32_t o = ((n * (uint32_t)p.C + 4u * half) * (uint32_t)p.H + (S * a + py)) * (uint32_t)p.W + (S * b + px);
+            voff[i] = m < p.M ? o * 4u : OOB;
+        }
+        uint32_t soff = (uint32_t)n_base * chs;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t so = soff + (uint32_t)(j * 32 + (r & 3) + 8 * (r >> 2)) * chs;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float v = acc[i][j][r];      // (bit_cast of the vector-element expression itself reads element 0)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, voff[i], so, 0);
+                }
+            }
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------
@@ -2044,6 +2095,491 @@ inline int launch_igemm(const typename AL::Params& pa, const typename BL::Params
             }
         }
         // many slabs over few output blocks: 8 wavefronts share the slab walk
+        if (nz > 16)
+            hipLaunchKernelGGL((splitk_finish_kernel<Epi, 8>), dim3(fm * fn * ny), dim3(512), 0, stream, slab, nz, M, N,
+                               pe, fn, ny, sm);
+        else
+            hipLaunchKernelGGL((splitk_finish_kernel<Epi, 4>), dim3(fm * fn * ny), dim3(NT), 0, stream, slab, nz, M, N, pe,
+                               fn, ny, sm);
+    }
+    return launch_status();
+}
+
+// =====================================================================================================================
+// Round 3: the one-wavefront-per-SIMD skeleton (igemm2).
+//
+// Why: four co-resident 128x128 workgroups per CU (igemm_kernel) keep the matrix pipe busy 80-83 % of the time; the
+// loop itself (no global loads) tops out at 0.87-0.91 because four wavefronts per SIMD arbitrate for one pipe and each
+// of them stalls at a barrier every 32 MFMAs.  Here ONE wavefront per SIMD owns a 128 x 128 (or 128 x 64) accumulator
+// tile -- a 256 x 256 / 256 x 128 workgroup tile -- and runs an in-order, software-pipelined stream in which the
+// MFMAs issue back to back and everything else sits in their shadow:
+//   * operands arrive by LDS-DMA into a THREE-deep ring of stages; the pieces of chunk t+2 are issued one per k-step
+//     between the MFMAs of chunk t, waited for with a COUNTED s_waitcnt vmcnt(N) (never 0 inside the loop) and made
+//     visible by ONE raw s_barrier per chunk (128 MFMAs per wavefront) -- __syncthreads() would drain the DMA queue;
+//   * the wait + barrier sit inside the LAST k-step of a chunk, in front of its MFMAs, so the first fragments of the
+//     next chunk are fetched under those MFMAs;
+//   * fragments are double-buffered in registers one k-step ahead (8 ds_read_b32 per 16 MFMAs).
+// tools/igemm2_probe.hip is this loop on a plain GEMM: 148-149 TFLOP/s (0.945 of the 157.3 peak) at K = 2048, main
+// loop 98.2 % of the MFMA-issue bound (in-kernel s_memtime stamps), against 125-130 for igemm_kernel on the same size.
+// Fragment / accumulator maps, LDS images ([k][m], m contiguous), GridMap, split-K slabs and the epilogues are the
+// ones of igemm_kernel; the loaders are piece-wise:
+//   static constexpr int LD, ROWS (LDS rows per chunk), PIECES (LDS-DMA instructions per wavefront and chunk);
+//   void init(const Params&, int tile, int y, int tid);
+//   void issue_piece(int kc, float* stage_base, int p, bool live);   // p in [0, PIECES), wave-uniform control flow
+// =====================================================================================================================
+constexpr int STAGES2 = 3;
+#ifndef GZ2_RD2
+#define GZ2_RD2 1
+#endif
+constexpr uint32_t SOFF_OOB = 0x80000000u;      // scalar offset that puts every lane of a buffer access out of range
+
+template <int WM_, int WN_, int TN_, int OCC_>
+struct TileCfg2 {
+    static constexpr int WM = WM_, WN = WN_, TM = 4, TN = TN_, OCC = OCC_;      // OCC: workgroups per CU (= waves / SIMD)
+    static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    static_assert(WM * WN == 4, "4 wavefronts per workgroup, one per SIMD");
+};
+
+// B operand [K rows][ld], N contiguous (packed weights; plain GEMM): a piece is 256 consecutive floats of the
+// [BK][BN] image = one k row (BN = 256) or two (BN = 128).  Rows past K are out of the descriptor's range (zeros).
+template <int BN>
+struct MContigB2 {
+    static_assert(BN == 128 || BN == 256, "piece mapping");
+    using Params = typename MContigLoader<BN>::Params;
+    static constexpr int LD = BN, ROWS = BK;
+    static constexpr int PIECES = BK * BN / 256 / 4;
+    static constexpr int RPP = 256 / BN;                  // k rows per piece
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff, ldb;
+    int wave;
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        rsrc = make_rsrc(p.base + (long long)y * p.batch_stride, (uint32_t)p.K * p.ld * 4u);
+        const int lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int f = lane * 4, r = f / BN, col = f % BN;
+        const int n = tile * BN + col;
+        ldb = (uint32_t)p.ld * 4u;
+        voff = n < p.MN ? (uint32_t)(r * p.ld + n) * 4u : OOB;
+    }
+    __device__ __forceinline__ void issue_piece(int kc, float* stage, int p, bool live) {
+        const int piece = wave * PIECES + p;
+        bload_lds16(rsrc, stage + piece * 256, voff, live ? (uint32_t)(kc * BK + piece * RPP) * ldb : SOFF_OOB);
+    }
+};
+
+// A operand of the k4 s2 p1 TRANSPOSED convolution, row-shared like ConvDgALoaderRow4 (a chunk's image is 8 rows =
+// 4 feature channels x 2 vertical taps of UNSHIFTED feature rows; the horizontal tap is applied on the fragment
+// read, the one column a shifted read takes from the neighbouring row is zeroed in the register).  One piece = one
+// LDS row of 256 pixels; wavefront w stages channel w of the chunk, its two vertical taps.
+template <int BM>
+struct ConvDgA2 {
+    static_assert(BM == 256, "one piece per LDS row");
+    using Params = typename ConvDgALoader<BM, 4, 4, 2, 1>::Params;
+    // LDS rows carry 4 pad floats that are zeroed once and never written again: a lane whose shifted read would take
+    // its value from the neighbouring image row reads that column instead (no v_cndmask in the loop -- an f32 MFMA
+    // holds the SIMD's vector issue for its whole duration, so every VALU instruction between MFMAs costs its full
+    // issue time)
+    static constexpr int LD = BM + 4, ROWS = BK / 2, PIECES = 2;
+    static constexpr int ZERO_COL = BM;
+    static constexpr bool ROWSHARE = true;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[2];
+    int wave, K, OHW, shift_half1;
+    __device__ __forceinline__ void init(const Params& p, int tile, int phase, int tid) {
+        const ConvShape& s = p.s;
+        rsrc = make_rsrc(p.y, (uint32_t)s.N * s.K * s.OH * s.OW * 4u);
+        const int lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        K = s.K; OHW = s.OH * s.OW;
+        const int py = phase / 2, px = phase % 2;
+        shift_half1 = (px + 1) / 2 - 1;
+        const uint32_t m = (uint32_t)tile * BM + lane * 4;
+        const bool m_ok = m < (uint32_t)s.N * p.AH * p.AW;
+        const uint32_t n = fdiv(m, p.div_ahw);
+        const uint32_t pix = m - n * (uint32_t)(p.AH * p.AW);
+        const uint32_t a = fdiv(pix, p.div_aw);
+        const uint32_t b = pix - a * (uint32_t)p.AW;
+#pragma unroll
+        for (int ty = 0; ty < 2; ++ty) {
+            const int oy = (int)a + (py + 1) / 2 - ty;
+            const bool ok = m_ok && (unsigned)oy < (unsigned)s.OH;
+            voff[ty] = ok ? (n * (uint32_t)(s.K * OHW) + (uint32_t)(oy * s.OW) + b) * 4u : OOB;
+        }
+    }
+    __device__ __forceinline__ int frag_shift(int half) const { return half ? shift_half1 : shift_half1 + 1; }
+    __device__ __forceinline__ void issue_piece(int kc, float* stage, int p, bool live) {
+        const int kol = kc * (BK / 4) + wave;
+        bload_lds16(rsrc, stage + (wave * 2 + p) * LD, voff[p],
+                    (live && kol < K) ? (uint32_t)kol * (uint32_t)OHW * 4u : SOFF_OOB);
+    }
+};
+
+// A operand of the k4 s2 p1 FORWARD convolution: the raw input rows the tile touches (ConvFwdALoaderRow4's image:
+// per segment of OW output pixels its four input rows of 2*OW columns, 8*BM floats per input channel), taps applied
+// on the fragment read.  Needs W = 2*OW, H = 2*OH, BM % OW == 0, OW >= 2, 16-byte alignment.
+template <int BM>
+struct ConvFwdA2 {
+    static_assert(BM == 256, "piece mapping");
+    using Params = typename ConvFwdALoader<BM, 4, 4, 2, 1>::Params;
+    static constexpr int LD = BM, ROWS = BK / 2, PIECES = 2;
+    static constexpr bool FWDROWS = true;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[2];
+    int wave, HW, OW, twoOW, C;
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        const ConvShape& s = p.s;
+        rsrc = make_rsrc(p.x, (uint32_t)(s.N * s.C * s.H * s.W) * 4u);
+        const int lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        HW = s.H * s.W; OW = s.OW; twoOW = 2 * s.OW; C = s.C;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f = ((wave * 2 + q) * 64 + lane) * 4;
+            const int seg = f / (8 * OW), rem = f - seg * 8 * OW;
+            const int ky = rem / twoOW, col = rem - ky * twoOW;
+            const uint32_t m = (uint32_t)tile * BM + seg * OW;           // first pixel of the segment
+            const bool m_ok = m < (uint32_t)s.N * s.OH * s.OW;
+            const uint32_t n = fdiv(m, p.div_ohw);
+            const uint32_t oy = fdiv(m - n * (uint32_t)(s.OH * s.OW), p.div_ow);
+            const int iy = (int)oy * 2 - 1 + ky;
+            const bool ok = m_ok && (unsigned)iy < (unsigned)s.H;
+            voff[q] = ok ? (n * (uint32_t)(s.C * HW) + (uint32_t)(iy * s.W + col)) * 4u : OOB;
+        }
+    }
+    __device__ __forceinline__ void frag(int m_local, int half, int& base, bool& z_even, bool& z_odd) const {
+        const int seg = m_local / OW, ox = m_local - seg * OW;
+        base = seg * 8 * OW + 2 * ox - 1 + half;
+        z_even = half == 0 && ox == 0;              // kx = 0
+        z_odd = half == 1 && ox == OW - 1;          // kx = 3
+    }
+    __device__ __forceinline__ void issue_piece(int kc, float* stage, int p, bool live) {
+        bload_lds16(rsrc, stage + (wave * 2 + p) * 256, voff[p], (live && kc < C) ? (uint32_t)kc * (uint32_t)HW * 4u : SOFF_OOB);
+    }
+};
+
+#ifdef GZ2_STAMPS       // diagnostic builds only (tools/conv_bench2.py --stamps): per-workgroup s_memtime stamps
+__device__ unsigned long long gz2_stamps[8192 * 8];
+#define GZ2_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define GZ2_STAMP(var)
+#endif
+
+// ---- hand-ordered instruction stream of one k-step ---------------------------------------------------------------
+// hipcc's scheduler is not latency-aware here: it puts the v_cndmask that zeroes a fragment right behind the ds_read
+// that fetches it (sched_group_barrier / sched_barrier variants all ended with an exposed LDS latency per k-step:
+// 78-90 % of the MFMA-issue bound for a wavefront that has its SIMD to itself).  So the stream is written out:
+//   ds_read (next k-step's fragments) ... the TM*TN MFMAs of this k-step ... s_waitcnt lgkmcnt(0) (in the shadow of
+//   the last MFMA: the reads are ~1000 cycles old) ... masks of the next k-step.
+// Every piece is an `asm volatile`; the wait statement takes the freshly read registers as in/out operands, so no use
+// of them can be scheduled above it, and the compiler's own code (LDS-DMA issue, loop control) can only fall between
+// pieces.  Accumulators live in AGPRs ("+a").
+// (no wait states needed in front of the MFMAs: their A / B registers are written by ds_read only -- the zero column
+// replaced the v_cndmask masks -- and s_waitcnt covers that)
+#ifndef GZ2_EXP_NOP
+#define GZ2_NOP ""
+#else
+#define GZ2_NOP "s_nop 1\n\t"
+#endif
+template <int OFF>
+__device__ __forceinline__ float lds_rd(uint32_t byte_addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF) : "memory");
+    return v;
+}
+// two dwords at byte_addr + 4 * {D0, D1} (one LDS instruction: a single wavefront per SIMD issues ds_read_b32 at only a
+// fraction of the LDS rate -- MI355X_MICROARCH.md, LDS -- so the number of LDS instructions per k-step matters)
+template <int D0, int D1>
+__device__ __forceinline__ void lds_rd2(uint32_t byte_addr, float& x, float& y) {
+    f32x2 v;
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(byte_addr), "n"(D0), "n"(D1) : "memory");
+    x = v.x;
+    y = v.y;
+}
+__device__ __forceinline__ void mfma_row(f32x16 (&c)[4], float a, const float (&b)[4]) {
+    // s_nop 1: a VALU write (the zeroing v_cndmask) needs two wait states before an MFMA reads the register, and the
+    // hazard recognizer does not look inside asm statements
+    asm volatile(GZ2_NOP
+                 "v_mfma_f32_32x32x2_f32 %0, %5, %4, %0\n\t"
+                 "v_mfma_f32_32x32x2_f32 %1, %6, %4, %1\n\t"
+                 "v_mfma_f32_32x32x2_f32 %2, %7, %4, %2\n\t"
+                 "v_mfma_f32_32x32x2_f32 %3, %8, %4, %3"
+                 : "+a"(c[0]), "+a"(c[1]), "+a"(c[2]), "+a"(c[3])
+                 : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+}
+__device__ __forceinline__ void mfma_row(f32x16 (&c)[2], float a, const float (&b)[2]) {
+    asm volatile(GZ2_NOP
+                 "v_mfma_f32_32x32x2_f32 %0, %3, %2, %0\n\t"
+                 "v_mfma_f32_32x32x2_f32 %1, %4, %2, %1"
+                 : "+a"(c[0]), "+a"(c[1])
+                 : "v"(a), "v"(b[0]), "v"(b[1]));
+}
+__device__ __forceinline__ void lgkm_done(float (&a)[4], float (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+__device__ __forceinline__ void lgkm_done(float (&a)[4], float (&b)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]));
+}
+
+// A-fragment addressing modes of igemm2_kernel (byte offsets relative to the stage base; TM = 4)
+template <int LDA, bool RS, int S>      // plain / row-shared [k][m] image: k-step S, block i
+struct AOff {
+    static constexpr int step = (RS ? LDA : 2 * LDA) * S * 4;
+};
+
+template <class Cfg, class AL, class BL, class Epi>
+__global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Params pa, typename BL::Params pb,
+                                                              typename Epi::Params pe, GridMap gm) {
+    constexpr int LDA = AL::LD, LDB = BL::LD;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN;
+    static_assert(TM == 4 && (TN == 2 || TN == 4), "fragment registers of the hand-ordered k-step");
+    constexpr int A_ELEMS = AL::ROWS * LDA, B_ELEMS = BL::ROWS * LDB;
+    constexpr int STAGE = A_ELEMS + B_ELEMS;
+    constexpr int PAD = 16;      // row-shared / forward-row fragment reads reach one column outside the A image (masked)
+    extern __shared__ __attribute__((aligned(16))) float smem2[];
+    float* const ring = smem2 + PAD;                     // stage i: [B image][A image]
+    GZ2_STAMP(st0);
+#ifdef GZ2_STAMPS
+    const unsigned long long sr0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st1 = st0, st2 = st0;
+#endif
+
+    const int tid = threadIdx.x;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    if (!gm.no_swizzle) {
+        const int q = nwg >> 3, rr = nwg & 7, x = bid & 7, i = bid >> 3;
+        bid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + i;
+    }
+    const int y = bid % gm.ny;
+    bid /= gm.ny;
+    const int tile_n = bid % gm.tiles_n;
+    const int tile_m = bid / gm.tiles_n;
+    const int z = blockIdx.z;
+    const int kc0 = z * gm.chunks_per_split;
+    const int kc1 = min(gm.chunks, kc0 + gm.chunks_per_split);
+
+    AL al;
+    BL bl;
+    al.init(pa, tile_m, y, tid);
+    bl.init(pb, tile_n, y, tid);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int half = lane >> 5, l32 = lane & 31;
+    constexpr bool RS = is_rowshare<AL>::value;
+    constexpr bool FR = is_fwdrows<AL>::value;
+    static_assert(!FR, "forward-row images: see igemm2f_kernel");
+    // byte addresses (LDS) of this lane's fragment columns inside stage 0
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)ring;
+    uint32_t a_addr[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+        a_addr[i] = lds0 + (uint32_t)(B_ELEMS + half * (RS ? 0 : LDA) + wm * TM * 32 + i * 32 + l32) * 4u;
+    if constexpr (RS) {
+        const int sh = al.frag_shift(half);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int b = (tile_m * Cfg::BM + wm * TM * 32 + i * 32 + l32) % pa.AW;
+            const bool zero = (sh < 0 && b == 0) || (sh > 0 && b == pa.AW - 1);
+            a_addr[i] = zero ? lds0 + (uint32_t)(B_ELEMS + AL::ZERO_COL) * 4u : a_addr[i] + (uint32_t)(sh * 4);
+        }
+        // the pad columns of every row of every stage
+        if (tid < STAGES2 * AL::ROWS * 4) {
+            const int st = tid / (AL::ROWS * 4), q = tid % (AL::ROWS * 4);
+            ring[st * STAGE + B_ELEMS + (q >> 2) * LDA + AL::ZERO_COL + (q & 3)] = 0.f;
+        }
+    }
+    const uint32_t b_addr = lds0 + (uint32_t)(half * LDB + wn * TN * 32 + l32) * 4u;
+
+    constexpr int NPA = AL::PIECES, NPB = BL::PIECES, NP = NPA + NPB, STEPS = BK / 2;
+    static_assert(NP <= STEPS, "at most one LDS-DMA piece per k-step");
+    auto issue_piece = [&](int kc, int st, int p, bool live) {
+#ifdef GZ2_EXP_NODMA       // timing experiments only (wrong results)
+        if (kc >= kc0 + 2) return;
+#endif
+#ifdef GZ2_EXP_SAMECHUNK
+        if (kc >= kc0 + 2) kc = kc0;
+#endif
+        float* sb = ring + st * STAGE;
+        if (p < NPA) al.issue_piece(kc, sb + B_ELEMS, p, live);
+        else bl.issue_piece(kc, sb, p - NPA, live);
+    };
+    // k-step S of the stage whose byte offset is `so`: raw fragments
+    auto fetch = [&](auto Sc, uint32_t so, float (&af)[TM], float (&bf)[TN]) {
+        constexpr int S = decltype(Sc)::value;
+        constexpr int AO = (RS ? LDA : 2 * LDA) * S * 4, BO = 2 * S * LDB * 4;
+#ifdef GZ2_EXP_NOFETCH
+        if (so != 0xFFFFFFFFu) return;
+#endif
+        // immediate offsets only: no VALU address arithmetic inside the loop (`a_addr[i] + so` is per-chunk)
+        af[0] = lds_rd<AO>(a_addr[0] + so);
+        af[1] = lds_rd<AO>(a_addr[1] + so);
+        af[2] = lds_rd<AO>(a_addr[2] + so);
+        af[3] = lds_rd<AO>(a_addr[3] + so);
+        {
+        bf[0] = lds_rd<BO>(b_addr + so);
+        bf[1] = lds_rd<BO + 128>(b_addr + so);
+        if constexpr (TN == 4) {
+            bf[2] = lds_rd<BO + 256>(b_addr + so);
+            bf[3] = lds_rd<BO + 384>(b_addr + so);
+        }
+        }
+    };
+    auto mask = [&](float (&)[TM]) {};      // (row-shared images: the zero column replaces the register masks)
+
+    if (kc0 < kc1) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) issue_piece(kc0, 0, p, true);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) issue_piece(kc0 + 1, 1, p, kc0 + 1 < kc1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+        __builtin_amdgcn_s_barrier();
+#ifdef GZ2_STAMPS
+        st1 = __builtin_amdgcn_s_memtime();
+#endif
+        float af[2][TM], bf[2][TN];
+#ifdef GZ2_STEP_STAMPS
+        unsigned long long step_cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, step_t = __builtin_amdgcn_s_memtime();
+#endif
+        fetch(std::integral_constant<int, 0>{}, 0u, af[0], bf[0]);
+        lgkm_done(af[0], bf[0]);
+        mask(af[0]);
+        int stage = 0;
+        for (int kc = kc0; kc < kc1; ++kc) {
+            int s1 = stage + 1; if (s1 >= STAGES2) s1 -= STAGES2;
+            int s2 = s1 + 1; if (s2 >= STAGES2) s2 -= STAGES2;
+            const uint32_t so = (uint32_t)(stage * STAGE * 4), sno = (uint32_t)(s1 * STAGE * 4);
+            const bool more = kc + 2 < kc1;
+            auto kstep = [&](auto Sc) {
+                constexpr int S = decltype(Sc)::value;
+                constexpr int c = S & 1, n = c ^ 1;
+                if constexpr (S + 1 < STEPS) {
+                    fetch(std::integral_constant<int, S + 1>{}, so, af[n], bf[n]);
+                    mfma_row(acc[0], af[c][0], bf[c]);
+                    mfma_row(acc[1], af[c][1], bf[c]);
+                    // chunk kc+2's pieces go out in the FIRST NP k-steps (the stage they overwrite was last read in
+                    // chunk kc-1, behind its barrier), so that by the last k-step exactly NP are in flight
+                    if constexpr (S < NP) issue_piece(kc + 2, s2, S, more);
+                    mfma_row(acc[2], af[c][2], bf[c]);
+                    mfma_row(acc[3], af[c][3], bf[c]);
+                } else {
+                    // last k-step: half of its MFMAs, then chunk kc+1 must have landed (all but the NP pieces of chunk
+                    // kc+2) and every wavefront must be done with this stage's fragments; the first fragments of
+                    // chunk kc+1 are fetched under the other half
+                    mfma_row(acc[0], af[c][0], bf[c]);
+                    mfma_row(acc[1], af[c][1], bf[c]);
+                    if constexpr (S < NP) issue_piece(kc + 2, s2, S, more);
+#ifndef GZ2_EXP_NOVMWAIT
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+#endif
+#ifndef GZ2_EXP_NOBARRIER
+                    __builtin_amdgcn_s_barrier();
+#endif
+                    fetch(std::integral_constant<int, 0>{}, sno, af[n], bf[n]);
+                    mfma_row(acc[2], af[c][2], bf[c]);
+                    mfma_row(acc[3], af[c][3], bf[c]);
+                }
+#ifdef GZ2_STEP_STAMPS      // diagnostic: cycles per k-step position, summed over the chunks
+                {
+                    const unsigned long long t = __builtin_amdgcn_s_memtime();
+                    step_cyc[S] += t - step_t;
+                    step_t = t;
+                }
+#endif
+                lgkm_done(af[n], bf[n]);
+                mask(af[n]);
+            };
+            kstep(std::integral_constant<int, 0>{});
+            kstep(std::integral_constant<int, 1>{});
+            kstep(std::integral_constant<int, 2>{});
+            kstep(std::integral_constant<int, 3>{});
+            kstep(std::integral_constant<int, 4>{});
+            kstep(std::integral_constant<int, 5>{});
+            kstep(std::integral_constant<int, 6>{});
+            kstep(std::integral_constant<int, 7>{});
+            stage = s1;
+        }
+        // drain the LDS-DMA queue; MFMA results must have retired before the epilogue's v_accvgpr_read (the hazard
+        // recognizer does not look inside the asm statements)
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#ifdef GZ2_STAMPS
+        st2 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef GZ2_STEP_STAMPS
+        if (tid == 0 && blockIdx.x < 64)
+            for (int q = 0; q < 8; ++q) gz2_stamps[(size_t)(8192 - 64 + blockIdx.x) * 8 + q] = step_cyc[q];
+#endif
+    }
+
+#ifdef GZ2_EXP_NOSTORE   // timing experiment: keep one store so the accumulators stay live
+    if (acc[0][0][0] == 123456.789f)
+#endif
+    if (gm.slab)
+        store_slab<Epi::SWAP, TM, TN>(gm, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32, lane,
+                                      y * (int)gridDim.z + z);
+    else
+        Epi::template store<TM, TN>(pe, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32,
+                                    lane, y, z);
+#ifdef GZ2_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0 && blockIdx.x < 8192) {
+        unsigned long long* o = gz2_stamps + (size_t)blockIdx.x * 8;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memtime();
+        o[4] = sr0; o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = kc1 - kc0; o[7] = TM * TN;
+    }
+#endif
+}
+
+template <class Cfg, class AL, class BL>
+constexpr size_t igemm2_lds_bytes() {
+    return (size_t)(STAGES2 * (AL::ROWS * AL::LD + BL::ROWS * BL::LD) + 32) * 4;
+}
+
+// same contract as launch_igemm (phases of equal length only)
+template <class Cfg, class AL, class BL, class Epi>
+inline int launch_igemm2(const typename AL::Params& pa, const typename BL::Params& pb, const typename Epi::Params& pe,
+                         int M, int N, int K, int ny, int splits, hipStream_t stream, float* slab = nullptr) {
+    static_assert(Epi::SWAP, "transposed accumulators (lanes along m)");
+    GridMap gm;
+    static int no_swz = getenv("GZ_NO_XCD_SWIZZLE") ? 1 : 0;
+    gm.no_swizzle = no_swz;
+    gm.var_chunks = 0;
+    gm.slab = nullptr;
+    gm.slab_m = M;
+    gm.slab_n = N;
+    gm.tiles_m = (M + Cfg::BM - 1) / Cfg::BM;
+    gm.tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
+    gm.chunks = (K + BK - 1) / BK;
+    if (splits < 1) splits = 1;
+    gm.chunks_per_split = (gm.chunks + splits - 1) / splits;
+    int nz = (gm.chunks + gm.chunks_per_split - 1) / gm.chunks_per_split;
+    if (nz < 1) nz = 1;
+    gm.ny = ny;
+    dim3 grid(gm.tiles_m * gm.tiles_n * ny, 1, nz);
+    if (slab && nz > 1) gm.slab = slab;
+    SlabMap sm;
+    sm.var = 0;
+    for (int i = 0; i < 8; ++i) gm.phase_nz[i] = sm.nz[i] = gm.phase_slab0[i] = sm.slab0[i] = 0;
+    static const size_t lds_extra = getenv("GZ_IGEMM2_LDS") ? (size_t)atoi(getenv("GZ_IGEMM2_LDS")) : 0;   // experiment:
+    const size_t lds = igemm2_lds_bytes<Cfg, AL, BL>() + lds_extra;             // throttles workgroups per CU
+    auto kern = igemm2_kernel<Cfg, AL, BL, Epi>;
+    static bool attr_done = false;       // per instantiation
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return launch_status();
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, pa, pb, pe, gm);
+    if (gm.slab) {
+        const int fm = (M + 31) / 32, fn = (N + 31) / 32;
         if (nz > 16)
             hipLaunchKernelGGL((splitk_finish_kernel<Epi, 8>), dim3(fm * fn * ny), dim3(512), 0, stream, slab, nz, M, N,
                                pe, fn, ny, sm);

@@ -850,3 +850,48 @@ def test_group_repack_equals_single_packs():
         ws[0].data.zero_()
     assert float(F._packed(ws[0], "f", geoms[0]).abs().sum()) == 0.0
     F.clear_pack_cache()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 3: the one-wavefront-per-SIMD implicit GEMM (csrc/gz_igemm.h igemm2, 256x256 / 256x128 workgroup tiles)
+# ---------------------------------------------------------------------------------------------------------------
+IGEMM2_DG_CASES = [
+    # N, K (feature channels), OH (feature side), C (output channels): label expected from gz_conv2d_tile
+    (64, 64, 32, 128, "256x128"),        # G.block4-like: 32x32 phase grid, 1024 tiles of 256x128
+    (64, 96, 16, 256, "256x128"),        # K = 96: 24 chunks, the ring wraps 8 times; 512 tiles
+    (128, 64, 8, 512, "256x128"),        # 8x8 feature rows (32 rows of a tile), 512 tiles
+    (128, 72, 8, 384, "256x256"),        # 10 chunks; 256 tiles of 256x256 (384 tiles of 256x128 would not fill two per CU)
+    (512, 72, 4, 512, "256x128"),        # 4x4 feature maps: 64 image rows per tile; 18 chunks
+    (52, 64, 16, 384, "256x128"),        # ragged pixel tail (13312 = 52 * 256) and 3 N tiles
+    (67, 68, 16, 160, "256x128"),        # pixel tail inside a tile (67 * 256 = 17152 = 67 tiles), channel tail 160 = 128 + 32
+]
+
+
+@pytest.mark.parametrize("case", IGEMM2_DG_CASES)
+def test_igemm2_transposed_conv_matches_torch(case):
+    """ConvTranspose2d k4 s2 p1 (= the data gradient of the strided conv) on the igemm2 skeleton against torch's CPU
+    operator: plain, with bias + activation epilogue, and with the BatchNorm partial sums (bit-identical output,
+    sums = per-channel sums of the output)."""
+    F = _F()
+    from lightning_gan_zoo_amd._lib import lib
+    N, K, OH, C, label = case
+    H = 2 * OH
+    tile = lib.gz_conv2d_tile(1, N, C, H, H, K, OH, OH, 4, 4, 2)
+    assert F._TILES[tile] == label, (F._TILES[tile], label)
+    gy = rnd(N, K, OH, OH, seed=11)
+    w = rnd(K, C, 4, 4, seed=12, scale=0.1)
+    b = rnd(C, seed=13)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = TF.conv_transpose2d(gy, w, None, 2, 1)
+    gyd, wd = gy.cuda(), w.cuda()
+    out = F._conv_dgrad_raw(gyd, wd, None, F.K4S2P1, (H, H), F.ACT_NONE, 0.0)
+    assert out.shape == ref.shape
+    err = rel(out, ref)
+    assert err < TOL, err
+    out_b = F._conv_dgrad_raw(gyd, wd, b.cuda(), F.K4S2P1, (H, H), F.ACT_LRELU, 0.2)
+    assert rel(out_b, TF.leaky_relu(ref + b.view(1, -1, 1, 1), 0.2)) < TOL
+    y, stats = F.conv_transpose2d_with_stats(gyd, wd, F.K4S2P1)
+    assert torch.equal(y, out)
+    st = stats.double().sum(0)
+    o64 = out.double()
+    assert rel(st[:, 0], o64.sum((0, 2, 3))) < 1e-5 and rel(st[:, 1], (o64 * o64).sum((0, 2, 3))) < 1e-5
