@@ -380,6 +380,40 @@ static int run_fwd(const float* x, const float* wp, const float* bias, float* y,
     return launch_igemm<Cfg, AL, BL, EpiNCHW>(pa, pb, pe, M, s.K, Kg, 1, splits, st, slab);
 }
 
+// k4 s2 p1 forward convolution on the igemm2 skeleton (raw input rows by LDS-DMA, taps on the fragment read)
+template <class Cfg, int OWC>
+static int run_fwd2(const float* x, const float* wp, const float* bias, float* y, const ConvShape& s, int act,
+                    float slope, hipStream_t st, int splits, float* slab, float* stats) {
+    using AL = ConvFwdA2<Cfg::BM, OWC>;
+    using BL = MContigB2<Cfg::BN>;
+    typename AL::Params pa{x, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW)};
+    const int M = s.N * s.OH * s.OW;
+    EpiNCHWB::Params pe{y, M, s.K, s.OH * s.OW, make_fastdiv(s.OH * s.OW), bias, act, slope,
+                        reinterpret_cast<f32x2*>(stats)};
+    const int Kg = s.C * 16;
+    typename BL::Params pb{wp, Kg, round4(s.K), round4(s.K), 0};
+    return launch_igemm2<Cfg, AL, BL, EpiNCHWB>(pa, pb, pe, M, s.K, Kg, 1, splits, st, slab);
+}
+
+template <class Cfg>
+static int run_fwd2_ow(const float* x, const float* wp, const float* bias, float* y, const ConvShape& s, int act,
+                       float slope, hipStream_t st, int splits = 1, float* slab = nullptr, float* stats = nullptr) {
+    switch (s.OW) {
+        case 4: return run_fwd2<Cfg, 4>(x, wp, bias, y, s, act, slope, st, splits, slab, stats);
+        case 8: return run_fwd2<Cfg, 8>(x, wp, bias, y, s, act, slope, st, splits, slab, stats);
+        case 16: return run_fwd2<Cfg, 16>(x, wp, bias, y, s, act, slope, st, splits, slab, stats);
+        case 32: return run_fwd2<Cfg, 32>(x, wp, bias, y, s, act, slope, st, splits, slab, stats);
+        case 64: return run_fwd2<Cfg, 64>(x, wp, bias, y, s, act, slope, st, splits, slab, stats);
+        default: return GZ_ERR_UNSUPPORTED;
+    }
+}
+
+template <class G>
+static bool fwd2_ok(const ConvShape& s) {
+    return G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1 && s.H == 2 * s.OH && s.W == 2 * s.OW &&
+           (s.OW == 4 || s.OW == 8 || s.OW == 16 || s.OW == 32 || s.OW == 64);
+}
+
 template <class G>
 static int fwd_kdim(const ConvShape& s) {
     return G::kh * G::kw * (fwd_tap_major(s.C, G::kh, G::kw) ? round_bk(s.C) : s.C);
@@ -396,9 +430,33 @@ static TileId pick_tile_fwd(long long M, int K, int OW, int kh, int kw, int stri
     return t;
 }
 
+// igemm2 plan of a forward launch: tile and reduction splits (few M tiles: the reduction is cut so that >= 256
+// workgroups exist, each with >= 32 chunks)
+template <class G>
+static SplitPlan fwd2_plan(const ConvShape& s) {
+    if (!fwd2_ok<G>(s)) return SplitPlan{T64x64, 1};
+    const long long M = (long long)s.N * s.OH * s.OW;
+    TileId t = pick_tile2(M, s.K, 1, s.C * 16);
+    if (t == T256x256 || t == T256x128) return SplitPlan{t, 1};
+    static const bool off = getenv("GZ_NO_IGEMM2") != nullptr;
+    if (off || s.K < 128) return SplitPlan{T64x64, 1};
+    const long long tiles = ((M + 255) / 256) * ((s.K + 127) / 128);
+    const int chunks = s.C;
+    if (tiles >= 64 && chunks >= 64) {
+        int splits = (int)((256 + tiles - 1) / tiles);
+        while (splits > 1 && chunks / splits < 32) --splits;
+        if (splits > 1 && tiles * splits >= 256) return SplitPlan{T256x128, splits};
+    }
+    return SplitPlan{T64x64, 1};
+}
+
 template <class G>
 static SplitPlan fwd_plan(const ConvShape& s) {
     long long M = (long long)s.N * s.OH * s.OW;
+    {
+        const SplitPlan p2 = fwd2_plan<G>(s);
+        if (p2.tile == T256x256 || p2.tile == T256x128) return p2;
+    }
     return plan_split(M, s.K, fwd_kdim<G>(s), 1, pick_tile_fwd(M, s.K, s.OW, G::kh, G::kw, G::s, fwd_kdim<G>(s)));
 }
 
@@ -415,7 +473,13 @@ static int dispatch_fwd(const float* x, const float* wp, const float* bias, floa
     if (sp.splits > 1 && (!ws || ws_bytes < fwd_ws_bytes<G>(s)))
         sp = SplitPlan{pick_tile_fwd(M, s.K, s.OW, G::kh, G::kw, G::s, 0), 1};
     float* slab = sp.splits > 1 ? ws : nullptr;
+    if ((sp.tile == T256x256 || sp.tile == T256x128) && (((uintptr_t)x) & 15) != 0) {
+        sp = SplitPlan{pick_tile_fwd(M, s.K, s.OW, G::kh, G::kw, G::s, 0), 1};      // unaligned tensor
+        slab = nullptr;
+    }
     switch (sp.tile) {
+        case T256x256: return run_fwd2_ow<Cfg256x256>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
+        case T256x128: return run_fwd2_ow<Cfg256x128>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
         case T128x128: return run_fwd<G, Cfg128x128>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
         case T128x64: return run_fwd<G, Cfg128x64>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
         case T128x32: return run_fwd<G, Cfg128x32>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
@@ -1424,6 +1488,8 @@ int gz_conv2d_fwd_stats(const float* x, const float* wpack, float* y, float* sta
 #define CALL(G)                                                                                                      \
     [&]() -> int {                                                                                                   \
         switch (fwd_plan<G>(s).tile) {                                                                               \
+            case T256x256: return run_fwd2_ow<Cfg256x256>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats); \
+            case T256x128: return run_fwd2_ow<Cfg256x128>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats); \
             case T128x128: return run_fwd<G, Cfg128x128>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats); \
             case T128x64: return run_fwd<G, Cfg128x64>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats);   \
             case T128x32: return run_fwd<G, Cfg128x32>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats);   \
@@ -1527,7 +1593,14 @@ int gz_debug_read_stamps(void* out, int nwg) {
 /* which tile configuration a launch of op (0 F, 1 Dg, 2 Wg) would use: 0 128x128, 1 128x64, 2 128x32, 3 64x64 */
 int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S) {
     // (the reduction lengths below ignore the channel padding of the tap-major loaders: labels only)
-    if (op == 0) return pick_tile_fwd((long long)N * OH * OW, K, OW, KH, KW, S, C * KH * KW);
+    if (op == 0) {
+        if (KH == 4 && KW == 4 && S == 2) {
+            ConvShape s{N, C, H, W, K, OH, OW};
+            const SplitPlan p2 = fwd2_plan<G4421>(s);
+            if (p2.tile == T256x256 || p2.tile == T256x128) return p2.tile;
+        }
+        return pick_tile_fwd((long long)N * OH * OW, K, OW, KH, KW, S, C * KH * KW);
+    }
     if (op == 1) {
         if (KH == 4 && KW == 4 && S == 2 && H == 2 * OH && W == 2 * OW && OW % 4 == 0 && 256 % OW == 0 && K % 4 == 0) {
             const TileId t2 = pick_tile2((long long)N * (H / S) * (W / S), C, 4, K * 4);

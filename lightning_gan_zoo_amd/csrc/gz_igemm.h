@@ -1624,6 +1624,48 @@ struct EpiPhase3D {
     }
 };
 
+// EpiNCHW with the lean store path of EpiPhaseB (below): no bias / activation, channel block inside the tensor ->
+// buffer_store straight from the accumulator registers, per-lane byte offset once per 32-pixel block, channel through
+// the scalar offset.
+struct EpiNCHWB {
+    static constexpr bool SWAP = true;
+    using Params = EpiNCHW::Params;
+    template <int TM, int TN>
+    __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
+                                                 int n_base, int lane, int y, int z) {
+        const bool fast = !p.bias && p.act == ACT_NONE && n_base + TN * 32 <= p.CH;       // wave-uniform
+        if (!fast) {
+            EpiNCHW::template store<TM, TN>(p, acc, m_base, n_base, lane, y, z);
+            return;
+        }
+        const int col_l = lane & 31, half = lane >> 5;
+        if (p.stats) tile_channel_stats<TM, TN>(acc, p.stats, m_base / (TM * 32), p.CH, n_base, lane);
+        const uint32_t chs = (uint32_t)p.HW * 4u;
+        __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.out, (uint32_t)(p.M / p.HW) * (uint32_t)p.CH * chs);
+        uint32_t voff[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m_base + i * 32 + col_l;
+            const uint32_t n = fdiv((uint32_t)m, p.div_hw);
+            const uint32_t pix = (uint32_t)m - n * (uint32_t)p.HW;
+            voff[i] = m < p.M ? ((n * (uint32_t)p.CH + 4u * half) * (uint32_t)p.HW + pix) * 4u : OOB;
+        }
+        const uint32_t soff = (uint32_t)n_base * chs;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t so = soff + (uint32_t)(j * 32 + (r & 3) + 8 * (r >> 2)) * chs;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float v = acc[i][j][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, voff[i], so, 0);
+                }
+            }
+        }
+    }
+};
+
 // EpiPhase with a lean store path for the igemm2 skeleton, where a workgroup's epilogue is NOT hidden behind three
 // other resident workgroups: when there is no bias / activation and the wavefront's channel block lies inside the
 // tensor, an accumulator goes out as  v_accvgpr_read + buffer_store  with a per-lane byte offset computed once per
@@ -2215,29 +2257,35 @@ struct ConvDgA2 {
 };
 
 // A operand of the k4 s2 p1 FORWARD convolution: the raw input rows the tile touches (ConvFwdALoaderRow4's image:
-// per segment of OW output pixels its four input rows of 2*OW columns, 8*BM floats per input channel), taps applied
-// on the fragment read.  Needs W = 2*OW, H = 2*OH, BM % OW == 0, OW >= 2, 16-byte alignment.
-template <int BM>
+// per segment of OW output pixels its four input rows of 2*OW columns, 8*BM floats per input channel = one chunk),
+// taps applied on the fragment read:  lane (segment, ox), k = (ky, kx) reads  image[seg][ky][2*ox + kx - 1].
+// OW is a template parameter so that the row step 2*OW sits in the ds_read's immediate offset (no VALU in the loop);
+// the column left of the image (ox = 0, kx = 0) and right of it (ox = OW-1, kx = 3) are read from a zeroed region
+// behind the image instead of being masked in registers.  Needs W = 2*OW, H = 2*OH, BM % OW == 0, 16-byte alignment.
+template <int BM, int OWC>
 struct ConvFwdA2 {
-    static_assert(BM == 256, "piece mapping");
+    static_assert(BM == 256 && BM % OWC == 0 && OWC >= 2, "piece mapping");
     using Params = typename ConvFwdALoader<BM, 4, 4, 2, 1>::Params;
     static constexpr int LD = BM, ROWS = BK / 2, PIECES = 2;
+    static constexpr int OW_C = OWC;
+    static constexpr int EXTRA = (6 * OWC + 4 + 3) & ~3;     // zeroed floats behind the image: every immediate row offset
+                                                             // (up to 3 * 2*OW) of a redirected read stays inside
     static constexpr bool FWDROWS = true;
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff[2];
-    int wave, HW, OW, twoOW, C;
+    int wave, HW, C;
     __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
         const ConvShape& s = p.s;
         rsrc = make_rsrc(p.x, (uint32_t)(s.N * s.C * s.H * s.W) * 4u);
         const int lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        HW = s.H * s.W; OW = s.OW; twoOW = 2 * s.OW; C = s.C;
+        HW = s.H * s.W; C = s.C;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int f = ((wave * 2 + q) * 64 + lane) * 4;
-            const int seg = f / (8 * OW), rem = f - seg * 8 * OW;
-            const int ky = rem / twoOW, col = rem - ky * twoOW;
-            const uint32_t m = (uint32_t)tile * BM + seg * OW;           // first pixel of the segment
+            const int seg = f / (8 * OWC), rem = f - seg * 8 * OWC;
+            const int ky = rem / (2 * OWC), col = rem - ky * 2 * OWC;
+            const uint32_t m = (uint32_t)tile * BM + seg * OWC;           // first pixel of the segment
             const bool m_ok = m < (uint32_t)s.N * s.OH * s.OW;
             const uint32_t n = fdiv(m, p.div_ohw);
             const uint32_t oy = fdiv(m - n * (uint32_t)(s.OH * s.OW), p.div_ow);
@@ -2246,18 +2294,21 @@ struct ConvFwdA2 {
             voff[q] = ok ? (n * (uint32_t)(s.C * HW) + (uint32_t)(iy * s.W + col)) * 4u : OOB;
         }
     }
-    __device__ __forceinline__ void frag(int m_local, int half, int& base, bool& z_even, bool& z_odd) const {
-        const int seg = m_local / OW, ox = m_local - seg * OW;
-        base = seg * 8 * OW + 2 * ox - 1 + half;
-        z_even = half == 0 && ox == 0;              // kx = 0
-        z_odd = half == 1 && ox == OW - 1;          // kx = 3
+    // float offsets (inside the A image) of the lane that owns tile pixel m_local, half-wave `half` (kx = 2*(s&1) +
+    // half): even k-steps read `even`, odd ones `odd`, both plus (s >> 1) * 2*OW; ZERO = the zeroed region
+    static constexpr int ZERO = ROWS * LD;
+    __device__ __forceinline__ void frag(int m_local, int half, int& even, int& odd) const {
+        const int seg = m_local / OWC, ox = m_local - seg * OWC;
+        const int base = seg * 8 * OWC + 2 * ox - 1 + half;
+        even = (half == 0 && ox == 0) ? ZERO : base;                  // kx = 0 left of the image
+        odd = (half == 1 && ox == OWC - 1) ? ZERO : base + 2;         // kx = 3 right of it
     }
     __device__ __forceinline__ void issue_piece(int kc, float* stage, int p, bool live) {
         bload_lds16(rsrc, stage + (wave * 2 + p) * 256, voff[p], (live && kc < C) ? (uint32_t)kc * (uint32_t)HW * 4u : SOFF_OOB);
     }
 };
 
-#ifdef GZ2_STAMPS       // diagnostic builds only (tools/conv_bench2.py --stamps): per-workgroup s_memtime stamps
+#ifdef GZ2_STAMPS       // diagnostic builds only (tools/igemm2_conv_probe.hip, tools/conv_bench2.py --stamps)
 __device__ unsigned long long gz2_stamps[8192 * 8];
 #define GZ2_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #else
@@ -2320,11 +2371,18 @@ __device__ __forceinline__ void lgkm_done(float (&a)[4], float (&b)[2]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]));
 }
 
-// A-fragment addressing modes of igemm2_kernel (byte offsets relative to the stage base; TM = 4)
-template <int LDA, bool RS, int S>      // plain / row-shared [k][m] image: k-step S, block i
-struct AOff {
-    static constexpr int step = (RS ? LDA : 2 * LDA) * S * 4;
-};
+template <class AL, class = void>
+struct a_extra_of { static constexpr int value = 0; };
+template <class AL>
+struct a_extra_of<AL, std::void_t<decltype(AL::EXTRA)>> { static constexpr int value = AL::EXTRA; };
+template <class AL>
+constexpr int igemm2_a_extra() { return a_extra_of<AL>::value; }
+template <class AL, class = void>
+struct fwd_ow_of { static constexpr int value = 1; };
+template <class AL>
+struct fwd_ow_of<AL, std::void_t<decltype(AL::OW_C)>> { static constexpr int value = AL::OW_C; };
+template <class AL>
+constexpr int fwd_ow() { return fwd_ow_of<AL>::value; }
 
 template <class Cfg, class AL, class BL, class Epi>
 __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Params pa, typename BL::Params pb,
@@ -2332,9 +2390,12 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
     constexpr int LDA = AL::LD, LDB = BL::LD;
     constexpr int TM = Cfg::TM, TN = Cfg::TN;
     static_assert(TM == 4 && (TN == 2 || TN == 4), "fragment registers of the hand-ordered k-step");
-    constexpr int A_ELEMS = AL::ROWS * LDA, B_ELEMS = BL::ROWS * LDB;
+    constexpr bool RS = is_rowshare<AL>::value;
+    constexpr bool FR = is_fwdrows<AL>::value;
+    constexpr int A_EXTRA = igemm2_a_extra<AL>();
+    constexpr int A_ELEMS = AL::ROWS * LDA + A_EXTRA, B_ELEMS = BL::ROWS * LDB;
     constexpr int STAGE = A_ELEMS + B_ELEMS;
-    constexpr int PAD = 16;      // row-shared / forward-row fragment reads reach one column outside the A image (masked)
+    constexpr int PAD = 16;
     extern __shared__ __attribute__((aligned(16))) float smem2[];
     float* const ring = smem2 + PAD;                     // stage i: [B image][A image]
     GZ2_STAMP(st0);
@@ -2374,9 +2435,6 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
     const int half = lane >> 5, l32 = lane & 31;
-    constexpr bool RS = is_rowshare<AL>::value;
-    constexpr bool FR = is_fwdrows<AL>::value;
-    static_assert(!FR, "forward-row images: see igemm2f_kernel");
     // byte addresses (LDS) of this lane's fragment columns inside stage 0
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)ring;
     uint32_t a_addr[TM];
@@ -2396,6 +2454,18 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
             const int st = tid / (AL::ROWS * 4), q = tid % (AL::ROWS * 4);
             ring[st * STAGE + B_ELEMS + (q >> 2) * LDA + AL::ZERO_COL + (q & 3)] = 0.f;
         }
+    }
+    uint32_t a_odd[TM];            // forward-row images: the odd k-steps' addresses (a_addr: the even ones)
+    if constexpr (FR) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int e, o;
+            al.frag(wm * TM * 32 + i * 32 + l32, half, e, o);
+            a_addr[i] = lds0 + (uint32_t)(B_ELEMS + e) * 4u;
+            a_odd[i] = lds0 + (uint32_t)(B_ELEMS + o) * 4u;
+        }
+        for (int q = tid; q < STAGES2 * A_EXTRA; q += NT)
+            ring[(q / A_EXTRA) * STAGE + B_ELEMS + AL::ZERO + q % A_EXTRA] = 0.f;
     }
     const uint32_t b_addr = lds0 + (uint32_t)(half * LDB + wn * TN * 32 + l32) * 4u;
 
@@ -2420,10 +2490,18 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
         if (so != 0xFFFFFFFFu) return;
 #endif
         // immediate offsets only: no VALU address arithmetic inside the loop (`a_addr[i] + so` is per-chunk)
-        af[0] = lds_rd<AO>(a_addr[0] + so);
-        af[1] = lds_rd<AO>(a_addr[1] + so);
-        af[2] = lds_rd<AO>(a_addr[2] + so);
-        af[3] = lds_rd<AO>(a_addr[3] + so);
+        if constexpr (FR) {
+            constexpr int FO = (S >> 1) * 2 * fwd_ow<AL>() * 4;
+            af[0] = lds_rd<FO>(((S & 1) ? a_odd[0] : a_addr[0]) + so);
+            af[1] = lds_rd<FO>(((S & 1) ? a_odd[1] : a_addr[1]) + so);
+            af[2] = lds_rd<FO>(((S & 1) ? a_odd[2] : a_addr[2]) + so);
+            af[3] = lds_rd<FO>(((S & 1) ? a_odd[3] : a_addr[3]) + so);
+        } else {
+            af[0] = lds_rd<AO>(a_addr[0] + so);
+            af[1] = lds_rd<AO>(a_addr[1] + so);
+            af[2] = lds_rd<AO>(a_addr[2] + so);
+            af[3] = lds_rd<AO>(a_addr[3] + so);
+        }
         {
         bf[0] = lds_rd<BO>(b_addr + so);
         bf[1] = lds_rd<BO + 128>(b_addr + so);
@@ -2540,7 +2618,7 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
 
 template <class Cfg, class AL, class BL>
 constexpr size_t igemm2_lds_bytes() {
-    return (size_t)(STAGES2 * (AL::ROWS * AL::LD + BL::ROWS * BL::LD) + 32) * 4;
+    return (size_t)(STAGES2 * (AL::ROWS * AL::LD + igemm2_a_extra<AL>() + BL::ROWS * BL::LD) + 32) * 4;
 }
 
 // same contract as launch_igemm (phases of equal length only)

@@ -895,3 +895,45 @@ def test_igemm2_transposed_conv_matches_torch(case):
     st = stats.double().sum(0)
     o64 = out.double()
     assert rel(st[:, 0], o64.sum((0, 2, 3))) < 1e-5 and rel(st[:, 1], (o64 * o64).sum((0, 2, 3))) < 1e-5
+
+
+IGEMM2_F_CASES = [
+    # N, C (input channels), H (input side), K (output channels), expected label
+    (64, 64, 64, 128, "256x128"),        # OW = 32: 8 output rows per tile, 256 tiles
+    (128, 64, 32, 128, "256x128"),       # D.block1-like: OW = 16
+    (512, 72, 16, 256, "256x128"),       # OW = 8, 72 chunks
+    (512, 64, 8, 512, "256x128"),        # OW = 4 (64 output rows per tile)
+    (100, 68, 32, 384, "256x128"),       # ragged pixel tail (25600 = 100 tiles), 3 column tiles
+    (512, 256, 8, 512, "256x128"),       # 32 row tiles x 4 column tiles = 128 tiles: reduction split in two
+]
+
+
+@pytest.mark.parametrize("case", IGEMM2_F_CASES)
+def test_igemm2_forward_conv_matches_torch(case):
+    """Conv2d k4 s2 p1 on the igemm2 skeleton (raw input rows staged by LDS-DMA, taps on the fragment read, borders
+    read from a zeroed LDS region) against torch's CPU operator: plain, bias + activation, BatchNorm partial sums,
+    and -- last case -- with the reduction split over two workgroups (slab + finish kernel)."""
+    F = _F()
+    from lightning_gan_zoo_amd._lib import lib
+    N, C, H, K, label = case
+    OH = H // 2
+    tile = lib.gz_conv2d_tile(0, N, C, H, H, K, OH, OH, 4, 4, 2)
+    assert F._TILES[tile] == label, (F._TILES[tile], label)
+    x = rnd(N, C, H, H, seed=21)
+    w = rnd(K, C, 4, 4, seed=22, scale=0.1)
+    b = rnd(K, seed=23)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = TF.conv2d(x, w, None, 2, 1)
+    xd, wd = x.cuda(), w.cuda()
+    out = F._conv_fwd_raw(xd, wd, None, F.K4S2P1, F.ACT_NONE, 0.0)
+    assert out.shape == ref.shape
+    err = rel(out, ref)
+    assert err < TOL, err
+    out_b = F._conv_fwd_raw(xd, wd, b.cuda(), F.K4S2P1, F.ACT_LRELU, 0.2)
+    assert rel(out_b, TF.leaky_relu(ref + b.view(1, -1, 1, 1), 0.2)) < TOL
+    y, stats = F.conv2d_with_stats(xd, wd, F.K4S2P1)
+    assert torch.equal(y, out)
+    if stats.numel():               # (a split reduction is not fused with the statistics, by design)
+        st = stats.double().sum(0)
+        o64 = out.double()
+        assert rel(st[:, 0], o64.sum((0, 2, 3))) < 1e-5 and rel(st[:, 1], (o64 * o64).sum((0, 2, 3))) < 1e-5
