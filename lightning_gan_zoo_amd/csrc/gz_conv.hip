@@ -1220,6 +1220,61 @@ static int launch_wgrad(const typename AL::Params& pa, const typename BL::Params
     return rc;
 }
 
+// Weight gradient on the igemm2 skeleton (register-staged transposing loaders, two LDS stages).  Tile 256 (output
+// channels) x 128 ((c, ky, kx) columns); the reduction over the pixels is split so that >= 512 workgroups exist.
+using Cfg2Wg = TileCfg2<2, 2, 2, 2>;
+
+template <class G>
+static int wgrad2_splits(const ConvShape& s) {
+    static const bool off = getenv("GZ_NO_IGEMM2") != nullptr || getenv("GZ_NO_IGEMM2_WG") != nullptr;
+    WgRowGeom rg;
+    const int NTOT = s.C * G::kh * G::kw;
+    if (off || s.K < 256 || s.K % 32 || NTOT < 128 || !wg_row_geom<G>(s, &rg)) return 0;
+    const long long tiles = (long long)((s.K + 255) / 256) * ((NTOT + 127) / 128);
+    const int chunks = (s.N * s.OH * s.OW + BK - 1) / BK;
+    int splits = (int)((512 + tiles - 1) / tiles);
+    if (splits < 1) splits = 1;
+    while (splits > 1 && chunks / splits < 64) --splits;       // >= 64 chunks per workgroup
+    return tiles * splits >= 256 ? splits : 0;
+}
+
+template <class G>
+static int run_wgrad2(const float* x, const float* y, float* dw, float* ws, size_t ws_bytes, const ConvShape& s,
+                      int splits, hipStream_t st) {
+    using Cfg = Cfg2Wg;
+    using AL = WgALoaderRow<Cfg::BM>;
+    using BL = WgBLoaderRow<Cfg::BN, G::kh, G::kw, G::s, G::p>;
+    const int KTOT = s.N * s.OH * s.OW;
+    const int NTOT = s.C * G::kh * G::kw;
+    WgRowGeom rg;
+    wg_row_geom<G>(s, &rg);
+    typename AL::Params pa{y, s, rg, KTOT};
+    typename BL::Params pb{x, s, rg, KTOT, NTOT};
+    const long long count = (long long)s.K * NTOT;
+    if (splits > 1) {
+        long long max_splits = (long long)(ws_bytes / 4) / count;
+        if (max_splits < 2) splits = 1;
+        else if (splits > max_splits) splits = (int)max_splits;
+    }
+    const int chunks = (KTOT + BK - 1) / BK;
+    const int cps = (chunks + splits - 1) / splits;
+    const int nz = (chunks + cps - 1) / cps;
+    float* out = nz > 1 ? ws : dw;
+    EpiRowMajorB::Params pe{out, s.K, NTOT, NTOT, count, nullptr, ACT_NONE, 0.f};
+    int rc = launch_igemm2r<Cfg, AL, BL, EpiRowMajorB>(pa, pb, pe, s.K, NTOT, KTOT, splits, st);
+    if (rc != GZ_OK) return rc;
+    if (nz > 1) {
+        if (nz <= 8)
+            hipLaunchKernelGGL(reduce_few_slabs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws, dw,
+                               nz, count);
+        else
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64 * RS_WAVES), 0, st, ws,
+                               dw, nz, count, count, (float*)nullptr, 0ll);
+        rc = launch_status();
+    }
+    return rc;
+}
+
 template <class G, class Cfg>
 static int run_wgrad(const float* x, const float* y, float* dw, float* ws, size_t ws_bytes, const ConvShape& s,
                      hipStream_t st) {
@@ -1247,6 +1302,11 @@ template <class G>
 static int dispatch_wgrad(const float* x, const float* y, float* dw, float* ws, size_t ws_bytes,
                           const ConvShape& s, hipStream_t st) {
     TileId t = (TileId)gz_conv2d_tile(2, s.N, s.C, s.H, s.W, s.K, s.OH, s.OW, G::kh, G::kw, G::s);
+    if (t == T256x128) {
+        const int splits = wgrad2_splits<G>(s);
+        if (splits > 0) return run_wgrad2<G>(x, y, dw, ws, ws_bytes, s, splits, st);
+        t = T128x128;
+    }
     switch (t) {
         case T128x128: return run_wgrad<G, Cfg128x128>(x, y, dw, ws, ws_bytes, s, st);
         case T128x64: return run_wgrad<G, Cfg128x64>(x, y, dw, ws, ws_bytes, s, st);
@@ -1439,6 +1499,10 @@ size_t gz_conv2d_wgrad_workspace_bytes(int N, int C, int H, int W, int K, int OH
     // upper bound over the tile choices: smallest tile count is with 128x128 tiles
     long long tiles = (long long)((K + 127) / 128) * ((C * KH * KW + 127) / 128);
     int splits = wgrad_splits(tiles, chunks);
+    if (KH == 4 && KW == 4) {            // the igemm2 plan (k4 s2 p1) may split further
+        const int s2 = wgrad2_splits<G4421>(s);
+        if (s2 > splits) splits = s2;
+    }
     return splits > 1 ? (size_t)splits * count * 4 : 0;
 }
 
@@ -1610,6 +1674,10 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
     }
     long long NTOT = (long long)C * KH * KW;
     int t;
+    if (KH == 4 && KW == 4 && S == 2 && forced_tile() < 0) {
+        ConvShape s{N, C, H, W, K, OH, OW};
+        if (wgrad2_splits<G4421>(s) > 0) return T256x128;
+    }
     if (NTOT <= 32) t = T128x32;
     else if (NTOT <= 64 || K <= 64) t = (K <= 64 ? T64x64 : T128x64);
     else {

@@ -1624,6 +1624,45 @@ struct EpiPhase3D {
     }
 };
 
+// EpiRowMajor with the lean store path (weight-gradient slabs of the igemm2 skeleton): no bias / activation and the
+// wavefront's rows inside the matrix -> buffer_store from the accumulator registers, column offset per lane, row
+// through the scalar offset.
+struct EpiRowMajorB {
+    static constexpr bool SWAP = false;
+    using Params = EpiRowMajor::Params;
+    template <int TM, int TN>
+    __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
+                                                 int n_base, int lane, int y, int z) {
+        const bool fast = !p.bias && p.act == ACT_NONE && m_base + TM * 32 <= p.M;       // wave-uniform
+        if (!fast) {
+            EpiRowMajor::template store<TM, TN>(p, acc, m_base, n_base, lane, y, z);
+            return;
+        }
+        const int col_l = lane & 31, half = lane >> 5;
+        float* c = p.c + (long long)(z + y) * p.slab_stride;
+        __amdgpu_buffer_rsrc_t rsrc = make_rsrc(c, (uint32_t)p.M * (uint32_t)p.ldc * 4u);
+        const uint32_t rs = (uint32_t)p.ldc * 4u;
+        uint32_t voff[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n_base + j * 32 + col_l;
+            voff[j] = n < p.N ? (uint32_t)n * 4u + 4u * half * rs : OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t so = (uint32_t)(m_base + i * 32 + (r & 3) + 8 * (r >> 2)) * rs;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float v = acc[i][j][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, voff[j], so, 0);
+                }
+            }
+        }
+    }
+};
+
 // EpiNCHW with the lean store path of EpiPhaseB (below): no bias / activation, channel block inside the tensor ->
 // buffer_store straight from the accumulator registers, per-lane byte offset once per 32-pixel block, channel through
 // the scalar offset.
@@ -2364,6 +2403,23 @@ __device__ __forceinline__ void mfma_row(f32x16 (&c)[2], float a, const float (&
                  : "+a"(c[0]), "+a"(c[1])
                  : "v"(a), "v"(b[0]), "v"(b[1]));
 }
+// D[m][n] order (lanes along n): row-major outputs (weight gradient slabs)
+__device__ __forceinline__ void mfma_row_mn(f32x16 (&c)[4], float a, const float (&b)[4]) {
+    asm volatile(GZ2_NOP
+                 "v_mfma_f32_32x32x2_f32 %0, %4, %5, %0\n\t"
+                 "v_mfma_f32_32x32x2_f32 %1, %4, %6, %1\n\t"
+                 "v_mfma_f32_32x32x2_f32 %2, %4, %7, %2\n\t"
+                 "v_mfma_f32_32x32x2_f32 %3, %4, %8, %3"
+                 : "+a"(c[0]), "+a"(c[1]), "+a"(c[2]), "+a"(c[3])
+                 : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+}
+__device__ __forceinline__ void mfma_row_mn(f32x16 (&c)[2], float a, const float (&b)[2]) {
+    asm volatile(GZ2_NOP
+                 "v_mfma_f32_32x32x2_f32 %0, %2, %3, %0\n\t"
+                 "v_mfma_f32_32x32x2_f32 %1, %2, %4, %1"
+                 : "+a"(c[0]), "+a"(c[1])
+                 : "v"(a), "v"(b[0]), "v"(b[1]));
+}
 __device__ __forceinline__ void lgkm_done(float (&a)[4], float (&b)[4]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
 }
@@ -2614,6 +2670,166 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
         o[4] = sr0; o[5] = __builtin_amdgcn_s_memrealtime(); o[6] = kc1 - kc0; o[7] = TM * TN;
     }
 #endif
+}
+
+// The same skeleton for operands that cannot arrive by LDS-DMA (weight gradient: both operands are
+// reduction-contiguous in memory and are transposed on their way into LDS): loaders with the igemm_kernel interface
+// issue() (global -> registers, at the top of a chunk) / commit() (registers -> LDS, late in the chunk), TWO stages
+// (the stage written in chunk kc was last read in chunk kc-1, behind its barrier).  The compiler places the global
+// loads and ds_writes (and the vmcnt wait between them) between the hand-ordered MFMA clusters; the wavefront drains
+// its LDS queue (its own ds_writes) in front of the chunk's barrier.  Epilogue: D[m][n], lanes along n.
+template <class Cfg, class AL, class BL, class Epi>
+__global__ __launch_bounds__(NT, Cfg::OCC) void igemm2r_kernel(typename AL::Params pa, typename BL::Params pb,
+                                                               typename Epi::Params pe, GridMap gm) {
+    constexpr int LDA = AL::LD, LDB = BL::LD;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN;
+    static_assert(TM == 4 && (TN == 2 || TN == 4) && !Epi::SWAP, "fragment registers of the hand-ordered k-step");
+    constexpr int A_ELEMS = BK * LDA, B_ELEMS = BK * LDB;
+    constexpr int STAGE = A_ELEMS + B_ELEMS;
+    extern __shared__ __attribute__((aligned(16))) float smem2[];
+    float* const ring = smem2;                           // stage i: [B image][A image]
+
+    const int tid = threadIdx.x;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    if (!gm.no_swizzle) {
+        const int q = nwg >> 3, rr = nwg & 7, x = bid & 7, i = bid >> 3;
+        bid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + i;
+    }
+    const int y = bid % gm.ny;
+    bid /= gm.ny;
+    const int tile_n = bid % gm.tiles_n;
+    const int tile_m = bid / gm.tiles_n;
+    const int z = blockIdx.z;
+    const int kc0 = z * gm.chunks_per_split;
+    const int kc1 = min(gm.chunks, kc0 + gm.chunks_per_split);
+
+    AL al;
+    BL bl;
+    al.init(pa, tile_m, y, tid);
+    bl.init(pb, tile_n, y, tid);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int half = lane >> 5, l32 = lane & 31;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)ring;
+    const uint32_t a_addr = lds0 + (uint32_t)(B_ELEMS + half * LDA + wm * TM * 32 + l32) * 4u;
+    const uint32_t b_addr = lds0 + (uint32_t)(half * LDB + wn * TN * 32 + l32) * 4u;
+    constexpr int STEPS = BK / 2;
+    auto fetch = [&](auto Sc, uint32_t so, float (&af)[TM], float (&bf)[TN]) {
+        constexpr int S = decltype(Sc)::value;
+        constexpr int AO = 2 * LDA * S * 4, BO = 2 * LDB * S * 4;
+        af[0] = lds_rd<AO>(a_addr + so);
+        af[1] = lds_rd<AO + 128>(a_addr + so);
+        af[2] = lds_rd<AO + 256>(a_addr + so);
+        af[3] = lds_rd<AO + 384>(a_addr + so);
+        bf[0] = lds_rd<BO>(b_addr + so);
+        bf[1] = lds_rd<BO + 128>(b_addr + so);
+        if constexpr (TN == 4) {
+            bf[2] = lds_rd<BO + 256>(b_addr + so);
+            bf[3] = lds_rd<BO + 384>(b_addr + so);
+        }
+    };
+
+    if (kc0 < kc1) {
+        al.issue(kc0);
+        bl.issue(kc0);
+        al.commit(ring + B_ELEMS);
+        bl.commit(ring);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float af[2][TM], bf[2][TN];
+        fetch(std::integral_constant<int, 0>{}, 0u, af[0], bf[0]);
+        lgkm_done(af[0], bf[0]);
+        int stage = 0;
+        for (int kc = kc0; kc < kc1; ++kc) {
+            const uint32_t so = (uint32_t)(stage * STAGE * 4), sno = (uint32_t)((stage ^ 1) * STAGE * 4);
+            float* const nxt = ring + (stage ^ 1) * STAGE;
+            const bool more = kc + 1 < kc1;
+            auto kstep = [&](auto Sc) {
+                constexpr int S = decltype(Sc)::value;
+                constexpr int c = S & 1, n = c ^ 1;
+                if constexpr (S == 0) {
+                    if (more) {
+                        al.issue(kc + 1);
+                        bl.issue(kc + 1);
+                    }
+                }
+                if constexpr (S + 1 < STEPS) {
+                    fetch(std::integral_constant<int, S + 1>{}, so, af[n], bf[n]);
+                    mfma_row_mn(acc[0], af[c][0], bf[c]);
+                    mfma_row_mn(acc[1], af[c][1], bf[c]);
+                    if constexpr (S == STEPS - 3) { if (more) al.commit(nxt + B_ELEMS); }
+                    if constexpr (S == STEPS - 2) { if (more) bl.commit(nxt); }
+                    mfma_row_mn(acc[2], af[c][2], bf[c]);
+                    mfma_row_mn(acc[3], af[c][3], bf[c]);
+                    lgkm_done(af[n], bf[n]);
+                } else {
+                    mfma_row_mn(acc[0], af[c][0], bf[c]);
+                    mfma_row_mn(acc[1], af[c][1], bf[c]);
+                    // this wavefront's ds_writes of the next stage are done (lgkm_done of the previous k-step waited
+                    // for the whole LDS queue); every wavefront is past its last fragment read of this stage
+                    __builtin_amdgcn_s_barrier();
+                    fetch(std::integral_constant<int, 0>{}, sno, af[n], bf[n]);
+                    mfma_row_mn(acc[2], af[c][2], bf[c]);
+                    mfma_row_mn(acc[3], af[c][3], bf[c]);
+                    lgkm_done(af[n], bf[n]);
+                }
+            };
+            kstep(std::integral_constant<int, 0>{});
+            kstep(std::integral_constant<int, 1>{});
+            kstep(std::integral_constant<int, 2>{});
+            kstep(std::integral_constant<int, 3>{});
+            kstep(std::integral_constant<int, 4>{});
+            kstep(std::integral_constant<int, 5>{});
+            kstep(std::integral_constant<int, 6>{});
+            kstep(std::integral_constant<int, 7>{});
+            stage ^= 1;
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    }
+    Epi::template store<TM, TN>(pe, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32, lane, y, z);
+}
+
+// split-K through the epilogue's own slabs (pe.slab_stride), as launch_igemm does for the weight gradient
+template <class Cfg, class AL, class BL, class Epi>
+inline int launch_igemm2r(const typename AL::Params& pa, const typename BL::Params& pb, const typename Epi::Params& pe,
+                          int M, int N, int K, int splits, hipStream_t stream) {
+    GridMap gm;
+    static int no_swz = getenv("GZ_NO_XCD_SWIZZLE") ? 1 : 0;
+    gm.no_swizzle = no_swz;
+    gm.var_chunks = 0;
+    gm.slab = nullptr;
+    gm.slab_m = M;
+    gm.slab_n = N;
+    gm.tiles_m = (M + Cfg::BM - 1) / Cfg::BM;
+    gm.tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
+    gm.chunks = (K + BK - 1) / BK;
+    if (splits < 1) splits = 1;
+    gm.chunks_per_split = (gm.chunks + splits - 1) / splits;
+    int nz = (gm.chunks + gm.chunks_per_split - 1) / gm.chunks_per_split;
+    if (nz < 1) nz = 1;
+    gm.ny = 1;
+    for (int i = 0; i < 8; ++i) gm.phase_nz[i] = gm.phase_slab0[i] = 0;
+    dim3 grid(gm.tiles_m * gm.tiles_n, 1, nz);
+    constexpr size_t lds = (size_t)2 * BK * (AL::LD + BL::LD) * 4;
+    auto kern = igemm2r_kernel<Cfg, AL, BL, Epi>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return launch_status();
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, pa, pb, pe, gm);
+    return launch_status();
 }
 
 template <class Cfg, class AL, class BL>

@@ -937,3 +937,33 @@ def test_igemm2_forward_conv_matches_torch(case):
         st = stats.double().sum(0)
         o64 = out.double()
         assert rel(st[:, 0], o64.sum((0, 2, 3))) < 1e-5 and rel(st[:, 1], (o64 * o64).sum((0, 2, 3))) < 1e-5
+
+
+IGEMM2_WG_CASES = [
+    # N, C (image-side channels), H (image side), K (feature-side channels)
+    (512, 32, 32, 256),         # OW = 16: a chunk is one output row; 1 x 4 tiles, 8192 chunks -> 128-way split
+    (512, 64, 16, 512),         # OW = 8: two rows per chunk; 2 x 8 tiles, 32-way split
+    (1024, 128, 8, 256),        # OW = 4: four rows per chunk (a whole 4x4 map); 1 x 16 tiles, 16-way split
+    (400, 24, 32, 288),         # ragged: 288 = 256 + 32 output channels, 384 columns, 6400 chunks
+]
+
+
+@pytest.mark.parametrize("case", IGEMM2_WG_CASES)
+def test_igemm2_weight_gradient_matches_torch(case):
+    """Weight gradient of the k4 s2 p1 convolution on the igemm2 skeleton (register-staged transposing loaders, two
+    LDS stages, reduction split over workgroups + slab reduction) against torch's CPU operator."""
+    F = _F()
+    from lightning_gan_zoo_amd._lib import lib
+    N, C, H, K = case
+    OH = H // 2
+    tile = lib.gz_conv2d_tile(2, N, C, H, H, K, OH, OH, 4, 4, 2)
+    assert F._TILES[tile] == "256x128", F._TILES[tile]
+    x = rnd(N, C, H, H, seed=31)
+    gy = rnd(N, K, OH, OH, seed=32)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = torch.nn.grad.conv2d_weight(x, (K, C, 4, 4), gy, stride=2, padding=1)
+    dw = F._conv_wgrad_raw(x.cuda(), gy.cuda(), F.K4S2P1)
+    assert dw.shape == ref.shape
+    err = rel(dw, ref)
+    assert err < TOL, err
+    assert torch.equal(dw, F._conv_wgrad_raw(x.cuda(), gy.cuda(), F.K4S2P1))      # fixed summation order
