@@ -120,7 +120,7 @@ def synthetic_batch(batch, device, rank, img_size=64):
     return real, torch.zeros(batch, dtype=torch.int64, device=device)
 
 
-def timed_pairs(trainer, batch, steps, warmup, world, timer=None, reps=1):
+def timed_pairs(trainer, batch, steps, warmup, world, timer=None, reps=1, on_timed_start=None):
     """-> (per-repetition seconds for ``steps`` cycles, max over ranks; per-rank seconds of the median repetition)."""
     import torch
     import torch.distributed as dist
@@ -137,6 +137,8 @@ def timed_pairs(trainer, batch, steps, warmup, world, timer=None, reps=1):
     # generation: later collections only look at the step's own short-lived objects (< 1 ms).
     gc.collect()
     gc.freeze()
+    if on_timed_start is not None:
+        on_timed_start()
     times, per_rank = [], []
     for rep in range(reps):
         if world > 1:
@@ -327,6 +329,8 @@ def run_rank(args):
             dist.init_process_group("nccl", device_id=device)
 
     from lightning_gan_zoo_amd import functional as F
+    if world > 1:
+        os.environ.setdefault("GZ_DDP_MEASURE", "1")      # GradSync brackets its waits for gradient buckets with events
 
     # the host side of the step is launch-only; a big OpenMP team only burns the container's CPU quota
     torch.set_num_threads(min(8, torch.get_num_threads()))
@@ -344,7 +348,9 @@ def run_rank(args):
     trainer.finish()
     if not args.no_kernel_timer:
         F.set_kernel_timer(timer)
-    times, per_rank, dt = timed_pairs(trainer, batch, args.steps, args.warmup, world, timer, args.reps)
+    sync0 = getattr(trainer, "grad_sync", None)
+    times, per_rank, dt = timed_pairs(trainer, batch, args.steps, args.warmup, world, timer, args.reps,
+                                      on_timed_start=(sync0.exposed_wait_ms if sync0 is not None and sync0.measure else None))
     F.set_kernel_timer(None)
     torch.cuda.synchronize()
     ms_per_step = dt / args.steps * 1e3
@@ -381,6 +387,16 @@ def run_rank(args):
         sync = trainer.grad_sync
         out["grad_exchange"] = {"buckets": [[(e - s) * 4 for s, e, _, _ in fg.buckets] for fg in sync.flats],
                                 **sync.stats}
+        if sync.measure:
+            # how much of the exchange was EXPOSED on this rank: time the compute stream sat behind a gradient bucket
+            # that had not been reduced yet (events around every wait), per optimizer cycle of the timed region
+            w = sync.exposed_wait_ms()
+            cycles = args.steps * args.reps
+            out["grad_exchange"]["overlap"] = {
+                "exposed_wait_ms_per_step": {"discriminator": round(w["discriminator"] / cycles, 4),
+                                             "generator": round(w["generator"] / cycles, 4)},
+                "waits_per_step": round(w["waits"] / cycles, 2), "rank": rank,
+                "note": "sum of (wait end - wait start) on the compute stream; 0 = fully hidden behind compute"}
 
     if rank == 0:
         roof = roofline_of(timer, times[0] / args.steps * 1e3, args.steps, flop_cycle)

@@ -54,6 +54,8 @@ def _build_transform(cfg):
 
 
 class BaseGAN(LightningModule):
+    real_first = True        # discriminator steps run D(real) before G(z) (see DCGAN.training_step)
+
     def __init__(self, cfg, logging_dir=None):
         super().__init__()
         # construction order fixes the host RNG stream: D, then G, then fixed_noise (reference :38-50)
@@ -149,10 +151,19 @@ class BaseGAN(LightningModule):
 class DCGAN(BaseGAN):
     def training_step(self, batch, batch_idx, optimizer_idx):
         real, _ = batch
-        fake = self.generator(self.sample_noise(len(real)))
+        noise = self.sample_noise(len(real))         # host RNG order of the reference: the noise is drawn first
 
         if optimizer_idx == 0:      # discriminator (reference :112-121)
-            disc_real = self.discriminator(real).reshape(-1)
+            # D(real) is launched BEFORE G(z) (`real_first`): it does not read the generator, so under data
+            # parallelism the generator's last gradient bucket + optimizer step (ddp.GradSync finalizes them in the
+            # generator's forward-pre hook) hide behind it.  Same kernels on the same operands, D's norm buffers
+            # still see real then fake: bit-identical to the reference's order (tests: test_real_first_order_...)
+            if self.real_first:
+                disc_real = self.discriminator(real).reshape(-1)
+                fake = self.generator(noise)
+            else:
+                fake = self.generator(noise)
+                disc_real = self.discriminator(real).reshape(-1)
             loss_disc_real = self.criterion_const(disc_real, 1.0)
             disc_fake = self.discriminator(fake.detach()).reshape(-1)
             loss_disc_fake = self.criterion_const(disc_fake, 0.0)
@@ -161,6 +172,7 @@ class DCGAN(BaseGAN):
             return loss_disc
 
         if optimizer_idx == 1:      # generator (reference :124-128)
+            fake = self.generator(noise)
             output = self.discriminator(fake).reshape(-1)
             loss_gen = self.criterion_const(output, 1.0)
             self.log("train/g_loss", loss_gen)
@@ -201,16 +213,22 @@ class WGAN(BaseGAN):
             F.clamp_(p, -clip, clip)
 
         real, _ = batch
-        fake = self.generator(self.sample_noise(len(real)))
+        noise = self.sample_noise(len(real))
 
         if optimizer_idx == 0:
-            disc_real = self.discriminator(real).reshape(-1)
+            if self.real_first:
+                disc_real = self.discriminator(real).reshape(-1)
+                fake = self.generator(noise)
+            else:
+                fake = self.generator(noise)
+                disc_real = self.discriminator(real).reshape(-1)
             disc_fake = self.discriminator(fake.detach()).reshape(-1)
             loss_disc = -(torch.mean(disc_real) - torch.mean(disc_fake))
             self.log("train/d_loss", loss_disc)
             return loss_disc
 
         if optimizer_idx == 1:
+            fake = self.generator(noise)
             gen_fake = self.discriminator(fake).reshape(-1)
             loss_gen = -torch.mean(gen_fake)
             self.log("train/g_loss", loss_gen)
@@ -222,10 +240,15 @@ class WGANGP(BaseGAN):
 
     def training_step(self, batch, batch_idx, optimizer_idx):
         real, _ = batch
-        fake = self.generator(self.sample_noise(len(real)))
+        noise = self.sample_noise(len(real))
 
         if optimizer_idx == 0:
-            disc_real = self.discriminator(real).reshape(-1)
+            if self.real_first:
+                disc_real = self.discriminator(real).reshape(-1)
+                fake = self.generator(noise)
+            else:
+                fake = self.generator(noise)
+                disc_real = self.discriminator(real).reshape(-1)
             disc_fake = self.discriminator(fake.detach()).reshape(-1)
             # `fake` is NOT detached here, as in the reference (:195-196)
             gp = gradient_penalty(self.discriminator, real, fake, device=self.device, alpha=self.gp_alpha)
@@ -234,6 +257,7 @@ class WGANGP(BaseGAN):
             return loss_disc
 
         if optimizer_idx == 1:
+            fake = self.generator(noise)
             gen_fake = self.discriminator(fake).reshape(-1)
             loss_gen = -torch.mean(gen_fake)
             self.log("train/g_loss", loss_gen)
@@ -246,10 +270,16 @@ class HOLOGAN(BaseGAN):
     def training_step(self, batch, batch_idx, optimizer_idx):
         real, _ = batch
         z = self.sample_noise(len(real))
-        fake = self.generator(z)
 
         if optimizer_idx == 0:
-            disc_real, _ = self.discriminator(real)
+            # (the generator draws its views from numpy's generator inside forward(): no other numpy draw happens in
+            # this step, so running D(real) first leaves that stream untouched)
+            if self.real_first:
+                disc_real, _ = self.discriminator(real)
+                fake = self.generator(z)
+            else:
+                fake = self.generator(z)
+                disc_real, _ = self.discriminator(real)
             loss_disc_real = self.criterion_const(disc_real, 1.0)
             disc_fake, d_z_pred = self.discriminator(fake.detach())
             loss_disc_fake = self.criterion_const(disc_fake, 0.0)
@@ -260,6 +290,7 @@ class HOLOGAN(BaseGAN):
             return loss_disc + q_loss
 
         if optimizer_idx == 1:
+            fake = self.generator(z)
             output, d_z_pred = self.discriminator(fake)
             loss_gen = self.criterion_const(output, 1.0)
             q_loss = F.mse_mean(d_z_pred, z)

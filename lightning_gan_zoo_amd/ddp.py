@@ -82,6 +82,11 @@ class GradSync:
         self.works = [[], []]
         self.issued = [set(), set()]
         self.stats = {"buckets_from_hooks": 0, "buckets_after_backward": 0}
+        # GZ_DDP_MEASURE=1 (bench.py --gpus N sets it): bracket every wait for a bucket with events on the compute
+        # stream (host clock on CPU tensors), so that a multi-GPU run reports how much of the exchange was EXPOSED --
+        # the time the compute stream sat behind a collective that had not finished
+        self.measure = bool(os.environ.get("GZ_DDP_MEASURE"))
+        self._waits = []              # (optimizer_idx, start event, end event) or (optimizer_idx, seconds)
         self.hooks = [n.register_forward_pre_hook(self._make_hook(i)) for i, n in enumerate(self.nets)]
         for idx, fg in enumerate(self.flats):
             for p in fg.params:
@@ -150,8 +155,11 @@ class GradSync:
         works, optimizer = item
         fg = self.flats[idx]
         scale = 1.0
-        for work in works:
-            work.wait()
+        if works and self.measure:
+            self._timed_wait(idx, works, fg.flat)
+        else:
+            for work in works:
+                work.wait()
         if works:
             scale = 1.0 / self.world
         if scale != 1.0 and getattr(optimizer, "accepts_grad_scale", False):
@@ -161,6 +169,33 @@ class GradSync:
                 fg.flat.mul_(scale)
             optimizer.step()
         fg.flat.zero_()          # == optimizer.zero_grad(set_to_none=False), one memset
+
+    def _timed_wait(self, idx, works, flat):
+        if flat.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for work in works:
+                work.wait()              # NCCL / RCCL: makes the current stream wait, the host does not block
+            e1.record()
+            self._waits.append((idx, e0, e1))
+        else:
+            import time
+            t0 = time.perf_counter()
+            for work in works:
+                work.wait()
+            self._waits.append((idx, time.perf_counter() - t0))
+
+    def exposed_wait_ms(self):
+        """{'discriminator': ms, 'generator': ms, 'waits': n}: total time the compute stream (or the host, for CPU
+        tensors) spent waiting for gradient buckets since the last call.  Synchronises the device."""
+        out = {"discriminator": 0.0, "generator": 0.0, "waits": len(self._waits)}
+        if any(len(w) == 3 for w in self._waits):
+            torch.cuda.synchronize()
+        for w in self._waits:
+            ms = w[1].elapsed_time(w[2]) if len(w) == 3 else w[1] * 1e3
+            out["discriminator" if w[0] == 0 else "generator"] += ms
+        self._waits = []
+        return out
 
     def flush(self):
         for i in range(len(self.nets)):

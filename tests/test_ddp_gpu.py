@@ -79,6 +79,10 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     assert out["config"]["global_batch"] == 64 and out["scaling"] == "weak" and "rehearsal" in out
     ex = out["grad_exchange"]
     assert ex["buckets_from_hooks"] > 0 and ex["buckets_after_backward"] == 0
+    # the overlap report of the first real multi-GPU run: exposed wait per optimizer cycle and network
+    ov = ex["overlap"]
+    assert set(ov["exposed_wait_ms_per_step"]) == {"discriminator", "generator"} and ov["waits_per_step"] >= 2
+    assert all(v >= 0.0 for v in ov["exposed_wait_ms_per_step"].values())
 
 
 def test_two_rank_training_run_rehearsal_on_one_gpu(tmp_path):
