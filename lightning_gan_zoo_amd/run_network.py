@@ -147,13 +147,22 @@ def seed_everything(seed):
 # ---------------------------------------------------------------------------------------------------------
 # data
 # ---------------------------------------------------------------------------------------------------------
-def shard_indices(n, rank, world):
-    """torch.utils.data.DistributedSampler(shuffle=False, drop_last=False): pad to a multiple of ``world`` by
-    wrapping around, then every ``world``-th index from ``rank`` (what Lightning's DDP inserts)."""
+def shard_indices(n, rank, world, epoch=None, seed=0):
+    """torch.utils.data.DistributedSampler(drop_last=False): pad to a multiple of ``world`` by wrapping around, then
+    every ``world``-th index from ``rank``.  Under ``accelerator="ddp"`` (reference run_network.py:66) Lightning puts a
+    DistributedSampler with shuffle=True in front of the train loader and calls ``set_epoch`` every epoch, so each
+    epoch is a fresh permutation ``randperm(n, generator=manual_seed(seed + epoch))`` shared by all ranks (seed 0,
+    the sampler's default): pass ``epoch`` to get that order; ``epoch=None`` is the unshuffled order (one process:
+    the reference's loader has no shuffle, core/lightning_module.py:89-92)."""
     if world <= 1:
         return list(range(n))
+    if epoch is None:
+        idx = list(range(n))
+    else:
+        g = torch.Generator()
+        g.manual_seed(seed + epoch)
+        idx = torch.randperm(n, generator=g).tolist()
     total = int(math.ceil(n / world)) * world
-    idx = list(range(n))
     idx += idx[:total - n]
     return idx[rank:total:world]
 
@@ -225,7 +234,8 @@ class ImageFolderImages:
         self.samples, self.classes = image_folder_samples(root)
         if not self.samples:
             raise FileNotFoundError("no images under %r" % root)
-        self.order = shard_indices(len(self.samples), rank, world)
+        self.rank, self.world = rank, world
+        self.order = shard_indices(len(self.samples), rank, world)          # (length / unshuffled view; see host_batches)
         self.batch, self.size, self.channels = batch, img_size, channels
         self.mean, self.std, self.device, self.prefetch = mean, std, torch.device(device), prefetch
 
@@ -241,10 +251,14 @@ class ImageFolderImages:
         return a if a.ndim == 3 else a[:, :, None]
 
     def host_batches(self):
-        """uint8 [b, S, S, C] arrays and int64 labels, epoch after epoch, in (sharded) dataset order."""
+        """uint8 [b, S, S, C] arrays and int64 labels, epoch after epoch: dataset order in one process, a fresh
+        DistributedSampler(shuffle=True) permutation per epoch under data parallelism (shard_indices)."""
+        epoch = 0
         while True:
-            for i in range(0, len(self.order), self.batch):
-                chunk = [self.samples[j] for j in self.order[i:i + self.batch]]
+            order = self.order if self.world <= 1 else shard_indices(len(self.samples), self.rank, self.world, epoch)
+            epoch += 1
+            for i in range(0, len(order), self.batch):
+                chunk = [self.samples[j] for j in order[i:i + self.batch]]
                 yield (np.stack([self.decode(p) for p, _ in chunk]), np.array([c for _, c in chunk], dtype=np.int64))
 
     def __iter__(self):
@@ -364,6 +378,10 @@ class CheckpointKeeper:
     def update(self, metrics, step, save_fn):
         """``save_fn(path)`` writes the checkpoint; returns the path written or None."""
         score = metrics.get(self.monitor) if metrics else None
+        if score is None and self.best_score is not None and self.best_path and os.path.exists(self.best_path):
+            # a state without a metric (a run cut short mid-epoch) never displaces the monitored best:
+            # ModelCheckpoint(save_top_k=1) keeps its best file until something better arrives
+            return None
         if score is not None:
             score = float(score)
             if self.best_score is not None and not score < self.best_score:
@@ -445,6 +463,61 @@ def fit(module, cfg, data, run, sync=None, rank=0, world=1, evaluate=None):
     return module, trainer, step
 
 
+FID_IMAGE_EXTENSIONS = ("bmp", "jpg", "jpeg", "pgm", "png", "ppm", "tif", "tiff", "webp")
+
+
+def real_image_files(root):
+    """The files ``compute_activations_of_path`` feeds to pytorch_fid (core/callback_inception_metrics.py:141-147):
+    every image under ``root``, recursively, sorted."""
+    out = []
+    for d, _, names in os.walk(root):
+        out += [os.path.join(d, f) for f in names if f.lower().endswith(FID_IMAGE_EXTENSIONS)]
+    return sorted(out)
+
+
+def real_activations(root, features, batch_size=16):
+    """Inception activations of the real images as the reference's callback obtains them (:159-163, :211-221): the
+    first ``*.npz`` in ``root`` if there is one (keys mu / sigma / act), else every image at its NATIVE resolution --
+    pytorch_fid's loader applies ToTensor only, the one resize is InceptionV3's own to 299x299 -- in batches of
+    ``batch_size`` consecutive files of equal size, and the result written to ``<root>/inception_cache.npz`` for the
+    next launch / resume.  Returns the activations [n, 2048]."""
+    cached = sorted(f for f in os.listdir(root) if ".npz" in f)
+    if cached:
+        with np.load(os.path.join(root, cached[0])) as data:
+            return np.asarray(data["act"])
+    from PIL import Image
+    from . import eval as E
+    acts, batch = [], []
+
+    def flush():
+        if batch:
+            acts.append(features(np.stack(batch)))
+            del batch[:]
+
+    for path in real_image_files(root):
+        with open(path, "rb") as f:
+            img = np.asarray(Image.open(f).convert("RGB"), dtype=np.uint8)
+        if batch and (img.shape != batch[0].shape or len(batch) == batch_size):
+            flush()
+        batch.append(img)
+    flush()
+    if not acts:
+        raise FileNotFoundError("no images under %r" % root)
+    act = np.concatenate(acts, axis=0)
+    mu, sigma = E.activation_statistics(act)
+    try:
+        np.savez(os.path.join(root, "inception_cache.npz"), mu=mu, sigma=sigma, act=act)
+    except OSError as e:            # read-only data set directory: recomputed on the next launch
+        print("could not write %s/inception_cache.npz (%s)" % (root, e))
+    return act
+
+
+def wants_fid(cfg, run):
+    node = cfg.get("dataset") or {}
+    return bool(cfg.get("calc_fid", True) and run.get("inception_weights") and (node.get("val") or {}).get("root")
+                and str(node.get("_target_", "")).endswith("ImageFolder"))
+
+
 def make_fid_evaluator(cfg, run, module, device):
     """The reference's InceptionMetrics callback (run_network.py:51-56, core/callback_inception_metrics.py:136-246) as
     the ``evaluate`` hook of fit(): FID / KID of ``val.fid_n_samples`` generated images against the validation images,
@@ -463,25 +536,13 @@ def make_fid_evaluator(cfg, run, module, device):
     features = InceptionFeatures(load_fid_weights(run["inception_weights"], device))
     n = int((cfg.get("val") or {}).get("fid_n_samples", 5000))
     dump = E.SampleDump(module, n_samples=n, batch_size=16)          # host RNG draw, right after the module is built
-    t = cfg.train
-    cache = {}
-
-    def real_activations():
-        if "act" not in cache:          # the callback caches them too (real_inception_cache)
-            folder = ImageFolderImages(val_root, 16, t.img_size, t.channels_img, t.data_mean, t.data_std, "cpu")
-            acts, seen = [], 0
-            for imgs, _ in folder.host_batches():
-                if imgs.shape[-1] == 1:
-                    imgs = np.repeat(imgs, 3, axis=-1)
-                acts.append(features(imgs))
-                seen += len(imgs)
-                if seen >= len(folder):
-                    break
-            cache["act"] = np.concatenate(acts, axis=0)
-        return cache["act"]
+    # before training starts, persisted next to the images: a resume or the next launch loads it, and under data
+    # parallelism the other ranks wait for it ONCE, at start-up (main() gives the process group a long timeout), not
+    # inside a collective in the middle of the run
+    real_act = real_activations(val_root, features)
 
     def evaluate(mod, epoch):
-        m = E.evaluate(mod, dump, features, real_activations())
+        m = E.evaluate(mod, dump, features, real_act)
         print("epoch %d FID: %.4f KID mean: %.6f KID stddev: %.6f" % (epoch, m["fid"], m["kid"], m["kid_std"]))
         return m
 
@@ -509,15 +570,22 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # with the FID evaluator on, rank 0 alone generates val.fid_n_samples images and runs InceptionV3 over them at
+        # every epoch end while the other ranks wait in the checkpoint's collectives: far longer than the 10 minutes
+        # after which the default watchdog aborts the job
+        import datetime
+        kw = {"timeout": datetime.timedelta(hours=6)} if wants_fid(cfg, run) else {}
         if rehearsal:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", **kw)
         else:
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, **kw)
     module = locate(cfg.model.lm["_target_"])(cfg, logging_dir="output").to(device)
     if world > 1:
         from .ddp import GradSync
         sync = GradSync(module)
     evaluate = make_fid_evaluator(cfg, run, module, device) if rank == 0 else None
+    if world > 1 and wants_fid(cfg, run):
+        torch.distributed.barrier()            # rank 0 has the real activations (computed or loaded) before step 0
     data = build_data(cfg, run, device, rank, world)
     out = fit(module, cfg, data, run, sync=sync, rank=rank, world=world, evaluate=evaluate)
     if world > 1:

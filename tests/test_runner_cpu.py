@@ -107,11 +107,75 @@ def test_best_score_bookkeeping_follows_model_checkpoint(tmp_path):
 
 
 def test_shard_indices_match_distributed_sampler():
+    """Unshuffled and -- what Lightning's DDP actually runs: ``auto_add_sampler(shuffle=True)`` + ``set_epoch`` --
+    reshuffled per epoch, against torch's own sampler."""
     from torch.utils.data.distributed import DistributedSampler
     for n, world in ((10, 4), (7, 2), (8, 8), (3, 4), (5, 1)):
         for rank in range(world):
             ref = list(DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=False))
             assert R.shard_indices(n, rank, world) == ref, (n, world, rank)
+            if world > 1:
+                sampler = DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=True, seed=0)
+                for epoch in range(3):
+                    sampler.set_epoch(epoch)
+                    assert R.shard_indices(n, rank, world, epoch) == list(sampler), (n, world, rank, epoch)
+
+
+def test_image_folder_reshuffles_per_epoch_under_data_parallelism(tmp_path):
+    from test_input_step import make_folder
+    from lightning_gan_zoo_amd.run_network import ImageFolderImages
+    root = str(tmp_path / "imgs")
+    make_folder(root)                                   # 6 images
+    labels = {}
+    for rank in range(2):
+        it = ImageFolderImages(root, 3, 8, 3, 0.5, 0.5, "cpu", rank=rank, world=2).host_batches()
+        labels[rank] = [next(it)[1].tolist() for _ in range(3)]         # three epochs of one batch each
+    full = sorted(c for _, c in R.image_folder_samples(root)[0])
+    for epoch in range(3):
+        assert sorted(labels[0][epoch] + labels[1][epoch]) == full      # the two ranks partition every epoch
+    assert len({tuple(labels[0][e]) for e in range(3)}) > 1             # ... in a different order each time
+    one = ImageFolderImages(root, 6, 8, 3, 0.5, 0.5, "cpu").host_batches()
+    assert next(one)[1].tolist() == next(one)[1].tolist() == [c for _, c in R.image_folder_samples(root)[0]]
+
+
+def test_a_run_cut_short_keeps_the_best_checkpoint(tmp_path):
+    """advisor finding (round 2): ``+max_steps`` ending mid-epoch wrote step=N.ckpt and swept model_best-fid=X.ckpt
+    away.  ModelCheckpoint(save_top_k=1) never removes its best file for a state without a better metric."""
+    ck = str(tmp_path / "ck")
+    torch.set_num_threads(2)
+    run_on_cpu("dc_gan", SMALL + ["train.batch_size=2", "train.ckpt_dir=" + ck, "steps_per_epoch=2", "max_steps=3"],
+               evaluate=lambda module, epoch: {"fid": 20.0})
+    assert os.listdir(ck) == ["model_best-fid=20.00.ckpt"]              # the tail save at step 3 did not replace it
+    blob = torch.load(os.path.join(ck, "model_best-fid=20.00.ckpt"), weights_only=False)
+    assert blob["global_step"] == 2 and blob["callbacks"]["ModelCheckpoint"]["best_model_score"] == 20.0
+
+
+def test_real_activations_native_resolution_and_cache(tmp_path):
+    """advisor finding (round 2): the callback's real statistics come from the val images at their NATIVE size
+    (pytorch_fid: ToTensor only) in batches of 16 equal-sized files, are cached as <val_root>/inception_cache.npz
+    (mu / sigma / act) and an existing *.npz is used instead of recomputing."""
+    import numpy as np
+    from PIL import Image
+    root = str(tmp_path / "val")
+    os.makedirs(os.path.join(root, "a"))
+    rng = np.random.RandomState(0)
+    sizes = [(20, 30)] * 18 + [(24, 24)] * 3 + [(20, 30)]                 # 18 equal (-> 16 + 2), 3 of another size, 1
+    for i, (h, w) in enumerate(sizes):
+        Image.fromarray(rng.randint(0, 256, size=(h, w, 3), dtype=np.uint8)).save(os.path.join(root, "a", "%03d.png" % i))
+    open(os.path.join(root, "a", "notes.txt"), "w").write("x")
+    seen = []
+
+    def features(u8):
+        seen.append(u8.shape)
+        return u8.reshape(len(u8), -1).astype(np.float64)[:, :5]
+
+    act = R.real_activations(root, features)
+    assert seen == [(16, 20, 30, 3), (2, 20, 30, 3), (3, 24, 24, 3), (1, 20, 30, 3)] and act.shape == (22, 5)
+    with np.load(os.path.join(root, "inception_cache.npz")) as d:
+        assert set(d.files) == {"mu", "sigma", "act"} and np.array_equal(d["act"], act) and d["sigma"].shape == (5, 5)
+    seen.clear()
+    again = R.real_activations(root, features)                            # second launch / resume: from the cache
+    assert not seen and np.array_equal(again, act)
 
 
 def test_runner_trains_from_an_image_folder(tmp_path):
