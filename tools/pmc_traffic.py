@@ -19,9 +19,15 @@ import sys
 def label_of(name):
     m = re.search(r"igemm_kernel<gz::TileCfg<(\d+), (\d+), (\d+), (\d+)>, gz::(\w+)<", name)
     if not m:
-        return None
-    wm, wn, tm, tn = (int(m.group(i)) for i in range(1, 5))
-    loader = m.group(5)
+        # round 3: igemm2_kernel / igemm2r_kernel<gz::TileCfg2<WM, WN, TN, OCC>, loader...> (TM = 4)
+        m2 = re.search(r"igemm2r?_kernel<gz::TileCfg2<(\d+), (\d+), (\d+), (\d+)>, gz::(\w+)<", name)
+        if not m2:
+            return None
+        wm, wn, tn = (int(m2.group(i)) for i in range(1, 4))
+        tm, loader = 4, m2.group(5)
+    else:
+        wm, wn, tm, tn = (int(m.group(i)) for i in range(1, 5))
+        loader = m.group(5)
     if loader.startswith("ConvFwd"):
         op = "F"
     elif loader.startswith("ConvDg"):
