@@ -1779,6 +1779,7 @@ struct GridMap {
     int phase_nz[8];
     int phase_slab0[8];
     int no_swizzle;            // experiment (GZ_NO_XCD_SWIZZLE): plain blockIdx order
+    int stagger;               // igemm2: shader cycles by which the first-round workgroups in odd CU slots start late
 };
 
 // SWAP (transposed accumulators, lanes along m): the slab is kept [n][m] so that its stores and the finish
@@ -2128,6 +2129,7 @@ inline int launch_igemm(const typename AL::Params& pa, const typename BL::Params
     GridMap gm;
     static int no_swz = getenv("GZ_NO_XCD_SWIZZLE") ? 1 : 0;
     gm.no_swizzle = no_swz;
+    gm.stagger = 0;
     gm.var_chunks = 0;
     if (phase_chunks && ny <= 8) {
         gm.var_chunks = 1;
@@ -2463,6 +2465,16 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
     const int tid = threadIdx.x;
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
+    // (experiment, off by default -- see launch_igemm2)  The first-round workgroup in the CU's odd thread-group slot
+    // starts a fraction of a tile late; the offset persists, because every later workgroup starts when its predecessor
+    // in that slot ends.
+    if (gm.stagger > 0 && bid < 512 && blockIdx.z == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (16 << 6) | 4);      // HW_ID.TG_ID
+        if (hw & 1u) {
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime() + (unsigned long long)gm.stagger;
+            while (__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(64);
+        }
+    }
     if (!gm.no_swizzle) {
         const int q = nwg >> 3, rr = nwg & 7, x = bid & 7, i = bid >> 3;
         bid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + i;
@@ -2818,6 +2830,7 @@ inline int launch_igemm2r(const typename AL::Params& pa, const typename BL::Para
     int nz = (gm.chunks + gm.chunks_per_split - 1) / gm.chunks_per_split;
     if (nz < 1) nz = 1;
     gm.ny = 1;
+    gm.stagger = 0;
     for (int i = 0; i < 8; ++i) gm.phase_nz[i] = gm.phase_slab0[i] = 0;
     dim3 grid(gm.tiles_m * gm.tiles_n, 1, nz);
     constexpr size_t lds = (size_t)2 * BK * (AL::LD + BL::LD) * 4;
@@ -2858,6 +2871,14 @@ inline int launch_igemm2(const typename AL::Params& pa, const typename BL::Param
     if (nz < 1) nz = 1;
     gm.ny = ny;
     dim3 grid(gm.tiles_m * gm.tiles_n * ny, 1, nz);
+    // stagger (see the kernel), an experiment that stays OFF: GZ_IGEMM2_STAGGER=<percent of a tile>.  Measured (in-kernel
+    // stamps): co-resident workgroups drift apart by themselves -- the average workgroup's loop takes 469 k cycles where
+    // two in lockstep would take 524 k -- and a forced half-tile offset changes neither the layer (143.3 -> 142.8
+    // TFLOP/s) nor the step (21.43 vs 21.40 ms).  What a launch does lose is its ramp: ~19 us until the first
+    // round's prologues are through plus the last round's tail, ~6 % of a 1 ms launch.
+    static const int stagger_pct = getenv("GZ_IGEMM2_STAGGER") ? atoi(getenv("GZ_IGEMM2_STAGGER")) : 0;
+    gm.stagger = (Cfg::OCC == 2 && nz == 1 && grid.x >= 1536)
+                     ? (int)((long long)gm.chunks * 8 * Cfg::TM * Cfg::TN * 64 * 2 * stagger_pct / 100) : 0;
     if (slab && nz > 1) gm.slab = slab;
     SlabMap sm;
     sm.var = 0;

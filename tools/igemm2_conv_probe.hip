@@ -32,6 +32,7 @@ static void run(int N, int K, int OH, int C, size_t lds_extra) {
     GridMap gm{};
     gm.tiles_m = (int)((M + Cfg::BM - 1) / Cfg::BM); gm.tiles_n = (C + Cfg::BN - 1) / Cfg::BN; gm.ny = 4;
     gm.chunks = Kg / BK; gm.chunks_per_split = gm.chunks; gm.slab = nullptr; gm.slab_m = (int)M; gm.slab_n = C;
+    gm.stagger = getenv("STAGGER") ? (int)((long long)gm.chunks * 8 * Cfg::TM * Cfg::TN * 64 * 2 * atoi(getenv("STAGGER")) / 100) : 0;
     dim3 grid(gm.tiles_m * gm.tiles_n * 4);
     size_t lds = igemm2_lds_bytes<Cfg, AL, BL>() + lds_extra;
     auto kern = igemm2_kernel<Cfg, AL, BL, Epi>;
