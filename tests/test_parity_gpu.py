@@ -128,6 +128,7 @@ def test_hologan_step_gradients_with_pinned_masks(init, img, bs):
         torch.manual_seed(1234)
         steps[name] = locate(cfg.model.lm["_target_"])(cfg, None)
     hip, cpu = steps["hip"], steps["cpu"]
+    hip.real_first = False        # the tape is replayed in call order: keep the reference's (G(z), D(real), D(fake))
     if init != "default_init":
         scenario._prepare(hip, init == "stable")
     for net in ("generator", "discriminator"):
@@ -419,9 +420,10 @@ def test_product_with_reference_mask_decisions_every_gradient_at_1e3(expt):
         cpu = scenario.run_scenario(build_oracle_step(expt, "full"), inputs, "cpu", full=True, set_alpha=set_alpha,
                                     **PINNED_KW)
     assert tape.cursor == len(tape.masks)
+    product = build_product_step(expt, "full")
+    product.real_first = False    # the reference's decisions are taped in ITS call order (G(z), D(real), D(fake))
     with pinned_product_masks(tape.rewind()):
-        hip = scenario.run_scenario(build_product_step(expt, "full"), inputs, "cuda", full=True, set_alpha=set_alpha,
-                                    **PINNED_KW)
+        hip = scenario.run_scenario(product, inputs, "cuda", full=True, set_alpha=set_alpha, **PINNED_KW)
     assert tape.cursor == len(tape.masks), "product and reference took different numbers of mask decisions"
     total = sum(m.numel() for m in tape.masks)
     flips = sum(m[1] for m in tape.mismatches)
