@@ -24,8 +24,11 @@ using Cfg64x64 = TileCfg<2, 2, 1, 1>;
 // round 3 (gz_igemm.h, igemm2): one wavefront per SIMD, 128x128 / 128x64 accumulators per wavefront
 using Cfg256x256 = TileCfg2<2, 2, 4, 1>;
 using Cfg256x128 = TileCfg2<2, 2, 2, 2>;
+using Cfg512x64 = TileCfg2<4, 1, 2, 2>;       // 64 output channels in all (D.block1-size input gradients)
+using Cfg128x256 = TileCfg2<1, 4, 2, 2>;      // weight gradient with 128 output channels
 
-enum TileId { T128x128 = 0, T128x64 = 1, T128x32 = 2, T64x64 = 3, T256x256 = 4, T256x128 = 5 };
+enum TileId { T128x128 = 0, T128x64 = 1, T128x32 = 2, T64x64 = 3, T256x256 = 4, T256x128 = 5, T512x64 = 6, T128x256 = 7 };
+static bool is_tile2(TileId t) { return t >= T256x256; }
 
 // Which launches take the igemm2 skeleton: its workgroup is a whole CU's worth of matrix pipes (one wavefront per
 // SIMD), so 256 tiles already fill the chip and anything from there up runs at the loop's rate; fewer would leave
@@ -33,6 +36,10 @@ enum TileId { T128x128 = 0, T128x64 = 1, T128x32 = 2, T64x64 = 3, T256x256 = 4, 
 // epilogues overlap each other's main loops: preferred unless that halves a long reduction's operand reuse for nothing.
 static TileId pick_tile2(long long M, long long N, int ny, int kdim) {
     static const bool off = getenv("GZ_NO_IGEMM2") != nullptr;
+    if (!off && N > 32 && N <= 64 && kdim >= 256) {             // one 64-wide column of 512-pixel tiles
+        const long long t = ((M + 511) / 512) * ny;
+        return t >= 512 ? T512x64 : T64x64;
+    }
     if (off || N < 128 || kdim < 256) return T64x64;            // "not applicable"
     const long long t128 = ((M + 255) / 256) * ((N + 127) / 128) * ny;
     const long long t256 = ((M + 255) / 256) * ((N + 255) / 256) * ny;
@@ -117,6 +124,7 @@ struct SplitPlan {
 
 static long long tile_count(TileId t, long long M, long long N, int ny) {
     if (t == T256x256 || t == T256x128) return ((M + 255) / 256) * ((N + (t == T256x256 ? 255 : 127)) / (t == T256x256 ? 256 : 128)) * ny;
+    if (t == T512x64) return ((M + 511) / 512) * ((N + 63) / 64) * ny;
     const int bm = t == T64x64 ? 64 : 128;
     const int bn = t == T128x128 ? 128 : (t == T128x32 ? 32 : 64);
     return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * ny;
@@ -436,7 +444,7 @@ template <class G>
 static SplitPlan fwd2_plan(const ConvShape& s) {
     if (!fwd2_ok<G>(s)) return SplitPlan{T64x64, 1};
     const long long M = (long long)s.N * s.OH * s.OW;
-    TileId t = pick_tile2(M, s.K, 1, s.C * 16);
+    TileId t = s.K > 64 ? pick_tile2(M, s.K, 1, s.C * 16) : T64x64;
     if (t == T256x256 || t == T256x128) return SplitPlan{t, 1};
     static const bool off = getenv("GZ_NO_IGEMM2") != nullptr;
     if (off || s.K < 128) return SplitPlan{T64x64, 1};
@@ -808,6 +816,7 @@ static int run_dgrad2(const float* y, const float* wp, const float* bias, float*
 template <class G>
 static bool dgrad2_ok(const ConvShape& s) {
     // ConvDgA2: 16-byte pieces of whole pixel quads; a tile's first pixel starts an image row (256 % AW == 0)
+    // (the 512-pixel tile: 512 % AW == 0 follows)
     return G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1 && s.H == 2 * s.OH && s.W == 2 * s.OW && s.OW % 4 == 0 &&
            256 % s.OW == 0 && s.K % 4 == 0;
 }
@@ -825,7 +834,7 @@ static SplitPlan dgrad_plan(const ConvShape& s) {
     const int kk = dgrad_tap_major(s.K, G::kh, G::kw, G::s) ? round_bk(s.K) : s.K;
     if (dgrad2_ok<G>(s)) {
         const TileId t2 = pick_tile2(M, s.C, 4, s.K * 4);
-        if (t2 == T256x256 || t2 == T256x128) return SplitPlan{t2, 1};
+        if (is_tile2(t2)) return SplitPlan{t2, 1};
     }
     return plan_split(M, s.C, kk * TAPS, G::s * G::s, pick_tile(M, s.C, G::s * G::s, kk * TAPS));
 }
@@ -854,11 +863,12 @@ static int dispatch_dgrad(const float* y, const float* wp, const float* bias, fl
     SplitPlan sp = dgrad_plan<G>(s);
     if (sp.splits > 1 && (!ws || ws_bytes < dgrad_ws_bytes<G>(s))) sp = SplitPlan{pick_tile(M, s.C, G::s * G::s), 1};
     float* slab = sp.splits > 1 ? ws : nullptr;
-    if ((sp.tile == T256x256 || sp.tile == T256x128) && (((uintptr_t)y) & 15) != 0)
+    if (is_tile2(sp.tile) && (((uintptr_t)y) & 15) != 0)
         sp = SplitPlan{pick_tile(M, s.C, G::s * G::s), 1};        // unaligned tensor: the element-wise loaders
     switch (sp.tile) {
         case T256x256: return run_dgrad2<Cfg256x256>(y, wp, bias, x, s, act, slope, st);
         case T256x128: return run_dgrad2<Cfg256x128>(y, wp, bias, x, s, act, slope, st);
+        case T512x64: return run_dgrad2<Cfg512x64>(y, wp, bias, x, s, act, slope, st);
         case T128x128: return run_dgrad<G, Cfg128x128>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
         case T128x64: return run_dgrad<G, Cfg128x64>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
         case T128x32: return run_dgrad<G, Cfg128x32>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
@@ -1224,13 +1234,17 @@ static int launch_wgrad(const typename AL::Params& pa, const typename BL::Params
 // channels) x 128 ((c, ky, kx) columns); the reduction over the pixels is split so that >= 512 workgroups exist.
 using Cfg2Wg = TileCfg2<2, 2, 2, 2>;
 
+// K in [128, 256): the 128 x 256 tile (one row of wavefronts, all four along the columns)
+static bool wgrad2_narrow(const ConvShape& s) { return s.K < 256; }
+
 template <class G>
 static int wgrad2_splits(const ConvShape& s) {
     static const bool off = getenv("GZ_NO_IGEMM2") != nullptr || getenv("GZ_NO_IGEMM2_WG") != nullptr;
     WgRowGeom rg;
     const int NTOT = s.C * G::kh * G::kw;
-    if (off || s.K < 256 || s.K % 32 || NTOT < 128 || !wg_row_geom<G>(s, &rg)) return 0;
-    const long long tiles = (long long)((s.K + 255) / 256) * ((NTOT + 127) / 128);
+    if (off || s.K < 128 || s.K % 32 || NTOT < 256 - 128 * !wgrad2_narrow(s) || !wg_row_geom<G>(s, &rg)) return 0;
+    const long long tiles = wgrad2_narrow(s) ? (long long)((s.K + 127) / 128) * ((NTOT + 255) / 256)
+                                             : (long long)((s.K + 255) / 256) * ((NTOT + 127) / 128);
     const int chunks = (s.N * s.OH * s.OW + BK - 1) / BK;
     int splits = (int)((512 + tiles - 1) / tiles);
     if (splits < 1) splits = 1;
@@ -1238,10 +1252,9 @@ static int wgrad2_splits(const ConvShape& s) {
     return tiles * splits >= 256 ? splits : 0;
 }
 
-template <class G>
+template <class G, class Cfg>
 static int run_wgrad2(const float* x, const float* y, float* dw, float* ws, size_t ws_bytes, const ConvShape& s,
                       int splits, hipStream_t st) {
-    using Cfg = Cfg2Wg;
     using AL = WgALoaderRow<Cfg::BM>;
     using BL = WgBLoaderRow<Cfg::BN, G::kh, G::kw, G::s, G::p>;
     const int KTOT = s.N * s.OH * s.OW;
@@ -1302,9 +1315,11 @@ template <class G>
 static int dispatch_wgrad(const float* x, const float* y, float* dw, float* ws, size_t ws_bytes,
                           const ConvShape& s, hipStream_t st) {
     TileId t = (TileId)gz_conv2d_tile(2, s.N, s.C, s.H, s.W, s.K, s.OH, s.OW, G::kh, G::kw, G::s);
-    if (t == T256x128) {
+    if (t == T256x128 || t == T128x256) {
         const int splits = wgrad2_splits<G>(s);
-        if (splits > 0) return run_wgrad2<G>(x, y, dw, ws, ws_bytes, s, splits, st);
+        if (splits > 0)
+            return wgrad2_narrow(s) ? run_wgrad2<G, Cfg128x256>(x, y, dw, ws, ws_bytes, s, splits, st)
+                                    : run_wgrad2<G, Cfg2Wg>(x, y, dw, ws, ws_bytes, s, splits, st);
         t = T128x128;
     }
     switch (t) {
@@ -1528,6 +1543,7 @@ int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* dbias, flo
 static int stats_wm(TileId t) { return t == T128x32 ? 4 : 2; }
 static int stats_tm_rows(TileId t, long long M) {       // partial rows per phase: tiles_m * WM
     if (t == T256x256 || t == T256x128) return (int)((M + 255) / 256) * 2;
+    if (t == T512x64) return (int)((M + 511) / 512) * 4;
     const int bm = t == T64x64 ? 64 : 128;
     return (int)((M + bm - 1) / bm) * stats_wm(t);
 }
@@ -1586,6 +1602,7 @@ int gz_conv2d_dgrad_stats(const float* y, const float* wpack, float* x, float* s
         switch (dgrad_plan<G>(s).tile) {                                                                               \
             case T256x256: return run_dgrad2<Cfg256x256>(y, wpack, nullptr, x, s, 0, 0.f, stream, stats);               \
             case T256x128: return run_dgrad2<Cfg256x128>(y, wpack, nullptr, x, s, 0, 0.f, stream, stats);               \
+            case T512x64: return run_dgrad2<Cfg512x64>(y, wpack, nullptr, x, s, 0, 0.f, stream, stats);                 \
             case T128x128: return run_dgrad<G, Cfg128x128>(y, wpack, nullptr, x, s, 0, 0.f, stream, 1, nullptr, stats); \
             case T128x64: return run_dgrad<G, Cfg128x64>(y, wpack, nullptr, x, s, 0, 0.f, stream, 1, nullptr, stats);   \
             case T128x32: return run_dgrad<G, Cfg128x32>(y, wpack, nullptr, x, s, 0, 0.f, stream, 1, nullptr, stats);   \
@@ -1668,7 +1685,7 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
     if (op == 1) {
         if (KH == 4 && KW == 4 && S == 2 && H == 2 * OH && W == 2 * OW && OW % 4 == 0 && 256 % OW == 0 && K % 4 == 0) {
             const TileId t2 = pick_tile2((long long)N * (H / S) * (W / S), C, 4, K * 4);
-            if (t2 == T256x256 || t2 == T256x128) return t2;
+            if (is_tile2(t2)) return t2;
         }
         return pick_tile((long long)N * (H / S) * (W / S), C, S * S, K * ((KH + S - 1) / S) * ((KW + S - 1) / S));
     }
@@ -1676,7 +1693,7 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
     int t;
     if (KH == 4 && KW == 4 && S == 2 && forced_tile() < 0) {
         ConvShape s{N, C, H, W, K, OH, OW};
-        if (wgrad2_splits<G4421>(s) > 0) return T256x128;
+        if (wgrad2_splits<G4421>(s) > 0) return wgrad2_narrow(s) ? T128x256 : T256x128;
     }
     if (NTOT <= 32) t = T128x32;
     else if (NTOT <= 64 || K <= 64) t = (K <= 64 ? T64x64 : T128x64);

@@ -2227,10 +2227,10 @@ struct TileCfg2 {
 // [BK][BN] image = one k row (BN = 256) or two (BN = 128).  Rows past K are out of the descriptor's range (zeros).
 template <int BN>
 struct MContigB2 {
-    static_assert(BN == 128 || BN == 256, "piece mapping");
+    static_assert(BN == 64 || BN == 128 || BN == 256, "piece mapping");
     using Params = typename MContigLoader<BN>::Params;
     static constexpr int LD = BN, ROWS = BK;
-    static constexpr int PIECES = BK * BN / 256 / 4;
+    static constexpr int PIECES = BK * BN / 256 / 4;      // per wavefront: 4 (BN 256), 2 (128), 1 (64: four k rows each)
     static constexpr int RPP = 256 / BN;                  // k rows per piece
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff, ldb;
@@ -2256,17 +2256,18 @@ struct MContigB2 {
 // LDS row of 256 pixels; wavefront w stages channel w of the chunk, its two vertical taps.
 template <int BM>
 struct ConvDgA2 {
-    static_assert(BM == 256, "one piece per LDS row");
+    static_assert(BM == 256 || BM == 512, "whole 256-pixel pieces per LDS row");
     using Params = typename ConvDgALoader<BM, 4, 4, 2, 1>::Params;
     // LDS rows carry 4 pad floats that are zeroed once and never written again: a lane whose shifted read would take
     // its value from the neighbouring image row reads that column instead (no v_cndmask in the loop -- an f32 MFMA
     // holds the SIMD's vector issue for its whole duration, so every VALU instruction between MFMAs costs its full
     // issue time)
-    static constexpr int LD = BM + 4, ROWS = BK / 2, PIECES = 2;
+    static constexpr int PPR = BM / 256;                   // pieces per LDS row
+    static constexpr int LD = BM + 4, ROWS = BK / 2, PIECES = 2 * PPR;
     static constexpr int ZERO_COL = BM;
     static constexpr bool ROWSHARE = true;
     __amdgpu_buffer_rsrc_t rsrc;
-    uint32_t voff[2];
+    uint32_t voff[2 * PPR];       // [vertical tap][256-pixel block]
     int wave, K, OHW, shift_half1;
     __device__ __forceinline__ void init(const Params& p, int tile, int phase, int tid) {
         const ConvShape& s = p.s;
@@ -2276,23 +2277,26 @@ struct ConvDgA2 {
         K = s.K; OHW = s.OH * s.OW;
         const int py = phase / 2, px = phase % 2;
         shift_half1 = (px + 1) / 2 - 1;
-        const uint32_t m = (uint32_t)tile * BM + lane * 4;
-        const bool m_ok = m < (uint32_t)s.N * p.AH * p.AW;
-        const uint32_t n = fdiv(m, p.div_ahw);
-        const uint32_t pix = m - n * (uint32_t)(p.AH * p.AW);
-        const uint32_t a = fdiv(pix, p.div_aw);
-        const uint32_t b = pix - a * (uint32_t)p.AW;
 #pragma unroll
-        for (int ty = 0; ty < 2; ++ty) {
-            const int oy = (int)a + (py + 1) / 2 - ty;
-            const bool ok = m_ok && (unsigned)oy < (unsigned)s.OH;
-            voff[ty] = ok ? (n * (uint32_t)(s.K * OHW) + (uint32_t)(oy * s.OW) + b) * 4u : OOB;
+        for (int hb = 0; hb < PPR; ++hb) {
+            const uint32_t m = (uint32_t)tile * BM + hb * 256 + lane * 4;
+            const bool m_ok = m < (uint32_t)s.N * p.AH * p.AW;
+            const uint32_t n = fdiv(m, p.div_ahw);
+            const uint32_t pix = m - n * (uint32_t)(p.AH * p.AW);
+            const uint32_t a = fdiv(pix, p.div_aw);
+            const uint32_t b = pix - a * (uint32_t)p.AW;
+#pragma unroll
+            for (int ty = 0; ty < 2; ++ty) {
+                const int oy = (int)a + (py + 1) / 2 - ty;
+                const bool ok = m_ok && (unsigned)oy < (unsigned)s.OH;
+                voff[ty * PPR + hb] = ok ? (n * (uint32_t)(s.K * OHW) + (uint32_t)(oy * s.OW) + b) * 4u : OOB;
+            }
         }
     }
     __device__ __forceinline__ int frag_shift(int half) const { return half ? shift_half1 : shift_half1 + 1; }
-    __device__ __forceinline__ void issue_piece(int kc, float* stage, int p, bool live) {
+    __device__ __forceinline__ void issue_piece(int kc, float* stage, int p, bool live) {     // p = ty * PPR + block
         const int kol = kc * (BK / 4) + wave;
-        bload_lds16(rsrc, stage + (wave * 2 + p) * LD, voff[p],
+        bload_lds16(rsrc, stage + (wave * 2 + p / PPR) * LD + (p % PPR) * 256, voff[p],
                     (live && kol < K) ? (uint32_t)kol * (uint32_t)OHW * 4u : SOFF_OOB);
     }
 };

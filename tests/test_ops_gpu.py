@@ -863,7 +863,9 @@ IGEMM2_DG_CASES = [
     (128, 72, 8, 384, "256x256"),        # 10 chunks; 256 tiles of 256x256 (384 tiles of 256x128 would not fill two per CU)
     (512, 72, 4, 512, "256x128"),        # 4x4 feature maps: 64 image rows per tile; 18 chunks
     (52, 64, 16, 384, "256x128"),        # ragged pixel tail (13312 = 52 * 256) and 3 N tiles
-    (67, 68, 16, 160, "256x128"),        # pixel tail inside a tile (67 * 256 = 17152 = 67 tiles), channel tail 160 = 128 + 32
+    (67, 68, 16, 160, "256x128"),
+    (64, 64, 32, 64, "512x64"),          # D.block1-size: 64 output channels, 512-pixel tiles (two 256-pixel pieces per row)
+    (272, 68, 16, 48, "512x64"),         # 48 channels: the general epilogue; 17 chunks        # pixel tail inside a tile (67 * 256 = 17152 = 67 tiles), channel tail 160 = 128 + 32
 ]
 
 
@@ -945,6 +947,8 @@ IGEMM2_WG_CASES = [
     (512, 64, 16, 512),         # OW = 8: two rows per chunk; 2 x 8 tiles, 32-way split
     (1024, 128, 8, 256),        # OW = 4: four rows per chunk (a whole 4x4 map); 1 x 16 tiles, 16-way split
     (400, 24, 32, 288),         # ragged: 288 = 256 + 32 output channels, 384 columns, 6400 chunks
+    (512, 32, 32, 128),         # 128 output channels: the 128 x 256 tile
+    (512, 64, 16, 160),         # 160 = 128 + 32 output channels on that tile
 ]
 
 
@@ -957,7 +961,7 @@ def test_igemm2_weight_gradient_matches_torch(case):
     N, C, H, K = case
     OH = H // 2
     tile = lib.gz_conv2d_tile(2, N, C, H, H, K, OH, OH, 4, 4, 2)
-    assert F._TILES[tile] == "256x128", F._TILES[tile]
+    assert F._TILES[tile] == ("256x128" if K >= 256 else "128x256"), F._TILES[tile]
     x = rnd(N, C, H, H, seed=31)
     gy = rnd(N, K, OH, OH, seed=32)
     torch.set_num_threads(min(16, torch.get_num_threads()))
