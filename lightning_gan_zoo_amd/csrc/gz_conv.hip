@@ -362,14 +362,14 @@ static int run_fwd(const float* x, const float* wp, const float* bias, float* y,
     using BL = MContigLoader4<Cfg::BN>;
     typename AL::Params pa{x, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW)};
     int M = s.N * s.OH * s.OW;
-    EpiNCHW::Params pe{y, M, s.K, s.OH * s.OW, make_fastdiv(s.OH * s.OW), bias, act, slope,
+    EpiNCHWB::Params pe{y, M, s.K, s.OH * s.OW, make_fastdiv(s.OH * s.OW), bias, act, slope,
                        reinterpret_cast<f32x2*>(stats)};
     if constexpr (BK % (G::kh * G::kw) != 0) {
         if (fwd_tap_major(s.C, G::kh, G::kw)) {
             using ALT = ConvFwdALoaderTap<Cfg::BM, G::kh, G::kw, G::s, G::p>;
             int Kt = G::kh * G::kw * round_bk(s.C);
             typename BL::Params pbt{wp, Kt, round4(s.K), round4(s.K), 0};
-            return launch_igemm<Cfg, ALT, BL, EpiNCHW>(pa, pbt, pe, M, s.K, Kt, 1, splits, st, slab);
+            return launch_igemm<Cfg, ALT, BL, EpiNCHWB>(pa, pbt, pe, M, s.K, Kt, 1, splits, st, slab);
         }
     }
     int Kg = s.C * G::kh * G::kw;
@@ -382,10 +382,10 @@ static int run_fwd(const float* x, const float* wp, const float* bias, float* y,
         if (!no_row4 && s.W == 2 * s.OW && s.H == 2 * s.OH && s.OW >= 16 && s.OW <= Cfg::BM && Cfg::BM % s.OW == 0 &&
             (((uintptr_t)x) & 15) == 0) {
             using AR = ConvFwdALoaderRow4<Cfg::BM>;
-            return launch_igemm<Cfg, AR, BL, EpiNCHW>(pa, pb, pe, M, s.K, Kg, 1, splits, st, slab);
+            return launch_igemm<Cfg, AR, BL, EpiNCHWB>(pa, pb, pe, M, s.K, Kg, 1, splits, st, slab);
         }
     }
-    return launch_igemm<Cfg, AL, BL, EpiNCHW>(pa, pb, pe, M, s.K, Kg, 1, splits, st, slab);
+    return launch_igemm<Cfg, AL, BL, EpiNCHWB>(pa, pb, pe, M, s.K, Kg, 1, splits, st, slab);
 }
 
 // k4 s2 p1 forward convolution on the igemm2 skeleton (raw input rows by LDS-DMA, taps on the fragment read)
@@ -756,7 +756,7 @@ static int run_dgrad(const float* y, const float* wp, const float* bias, float* 
                      float slope, hipStream_t st, int splits = 1, float* slab = nullptr, float* stats = nullptr) {
     using AL = ConvDgALoader<Cfg::BM, G::kh, G::kw, G::s, G::p>;
     using BL = MContigLoader4<Cfg::BN>;
-    using Epi = EpiPhase<G::s>;
+    using Epi = EpiPhaseB<G::s>;
     const int AH = s.H / G::s, AW = s.W / G::s;
     typename AL::Params pa{y, s, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW)};
     int Kg = s.K * AL::TAPS;
@@ -1215,8 +1215,8 @@ static int launch_wgrad(const typename AL::Params& pa, const typename BL::Params
     int cps = (chunks + splits - 1) / splits;
     int nz = (chunks + cps - 1) / cps;
     float* out = nz > 1 ? ws : dw;
-    EpiRowMajor::Params pe{out, s.K, NTOT, NTOT, count, nullptr, ACT_NONE, 0.f};
-    int rc = launch_igemm<Cfg, AL, BL, EpiRowMajor>(pa, pb, pe, s.K, NTOT, KTOT, 1, splits, st);
+    EpiRowMajorB::Params pe{out, s.K, NTOT, NTOT, count, nullptr, ACT_NONE, 0.f};
+    int rc = launch_igemm<Cfg, AL, BL, EpiRowMajorB>(pa, pb, pe, s.K, NTOT, KTOT, 1, splits, st);
     if (rc != GZ_OK) return rc;
     if (nz > 1) {
         if (nz <= 8)
@@ -1564,6 +1564,7 @@ int gz_conv2d_fwd_stats(const float* x, const float* wpack, float* y, float* sta
     ConvShape s{N, C, H, W, K, OH, OW};
     if (!shape_ok(s, KH, KW, S, P) || !stats) return GZ_ERR_BAD_SHAPE;
     if (gz_conv2d_fwd_stats_rows(N, C, H, W, K, OH, OW, KH, KW, S, P) <= 0) return GZ_ERR_UNSUPPORTED;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15) != 0) return GZ_ERR_BAD_SHAPE;      // 16-byte LDS-DMA pieces / row stores
     if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
 #define CALL(G)                                                                                                      \
     [&]() -> int {                                                                                                   \
@@ -1596,6 +1597,7 @@ int gz_conv2d_dgrad_stats(const float* y, const float* wpack, float* x, float* s
     ConvShape s{N, C, H, W, K, OH, OW};
     if (!shape_ok(s, KH, KW, S, P) || !stats) return GZ_ERR_BAD_SHAPE;
     if (gz_conv2d_dgrad_stats_rows(N, C, H, W, K, OH, OW, KH, KW, S, P) <= 0) return GZ_ERR_UNSUPPORTED;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15) != 0) return GZ_ERR_BAD_SHAPE;      // 16-byte LDS-DMA pieces / row stores
     if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
 #define CALL(G)                                                                                                        \
     [&]() -> int {                                                                                                     \

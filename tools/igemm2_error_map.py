@@ -1,3 +1,9 @@
+"""Where does a transposed-convolution result differ from torch's?  Error fractions by phase / image / channel /
+row / column and the reference channel a wrong channel actually holds -- how the two igemm2 bugs of round 3 were found
+(a VALU -> asm-MFMA hazard hit accumulator blocks (i in {0, 2}, j = 0); a bit_cast of a vector element stored element 0).
+
+    python tools/igemm2_error_map.py        # on the GPU box
+"""
 import sys, torch
 sys.path.insert(0, '/root/repo'); sys.path.insert(0,'.')
 from lightning_gan_zoo_amd import functional as F
