@@ -798,7 +798,7 @@ static int run_dgrad(const float* y, const float* wp, const float* bias, float* 
 // k4 s2 p1 transposed convolution on the igemm2 skeleton (row-shared A rows by LDS-DMA, packed per-phase weights)
 template <class Cfg>
 static int run_dgrad2(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s, int act,
-                      float slope, hipStream_t st, float* stats = nullptr) {
+                      float slope, hipStream_t st, float* stats = nullptr, int splits = 1, float* slab = nullptr) {
     using AL = ConvDgA2<Cfg::BM>;
     using BL = MContigB2<Cfg::BN>;
     using Epi = EpiPhaseB<2>;
@@ -810,7 +810,7 @@ static int run_dgrad2(const float* y, const float* wp, const float* bias, float*
     const int M = s.N * AH * AW;
     typename Epi::Params pe{x, M, s.C, s.H, s.W, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW), bias, act, slope,
                             reinterpret_cast<f32x2*>(stats), ((M + Cfg::BM - 1) / Cfg::BM) * Cfg::WM};
-    return launch_igemm2<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kg, 4, 1, st);
+    return launch_igemm2<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kg, 4, splits, st, slab);
 }
 
 template <class G>
@@ -835,6 +835,16 @@ static SplitPlan dgrad_plan(const ConvShape& s) {
     if (dgrad2_ok<G>(s)) {
         const TileId t2 = pick_tile2(M, s.C, 4, s.K * 4);
         if (is_tile2(t2)) return SplitPlan{t2, 1};
+        // 64-255 tiles of 256x128 (small batches, deep layers): cut the reduction so that >= 256 workgroups exist,
+        // each with >= 32 chunks (as the forward convolution does)
+        static const bool off = getenv("GZ_NO_IGEMM2") != nullptr;
+        const long long tiles = ((M + 255) / 256) * ((s.C + 127) / 128) * 4;
+        const int chunks = s.K / 4;
+        if (!off && s.C >= 128 && tiles >= 64 && tiles < 256 && chunks >= 64) {
+            int splits = (int)((256 + tiles - 1) / tiles);
+            while (splits > 1 && chunks / splits < 32) --splits;
+            if (splits > 1 && tiles * splits >= 256) return SplitPlan{T256x128, splits};
+        }
     }
     return plan_split(M, s.C, kk * TAPS, G::s * G::s, pick_tile(M, s.C, G::s * G::s, kk * TAPS));
 }
@@ -867,7 +877,7 @@ static int dispatch_dgrad(const float* y, const float* wp, const float* bias, fl
         sp = SplitPlan{pick_tile(M, s.C, G::s * G::s), 1};        // unaligned tensor: the element-wise loaders
     switch (sp.tile) {
         case T256x256: return run_dgrad2<Cfg256x256>(y, wp, bias, x, s, act, slope, st);
-        case T256x128: return run_dgrad2<Cfg256x128>(y, wp, bias, x, s, act, slope, st);
+        case T256x128: return run_dgrad2<Cfg256x128>(y, wp, bias, x, s, act, slope, st, nullptr, sp.splits, slab);
         case T512x64: return run_dgrad2<Cfg512x64>(y, wp, bias, x, s, act, slope, st);
         case T128x128: return run_dgrad<G, Cfg128x128>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
         case T128x64: return run_dgrad<G, Cfg128x64>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
@@ -1685,9 +1695,12 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
         return pick_tile_fwd((long long)N * OH * OW, K, OW, KH, KW, S, C * KH * KW);
     }
     if (op == 1) {
-        if (KH == 4 && KW == 4 && S == 2 && H == 2 * OH && W == 2 * OW && OW % 4 == 0 && 256 % OW == 0 && K % 4 == 0) {
-            const TileId t2 = pick_tile2((long long)N * (H / S) * (W / S), C, 4, K * 4);
-            if (is_tile2(t2)) return t2;
+        if (KH == 4 && KW == 4 && S == 2) {
+            ConvShape s{N, C, H, W, K, OH, OW};
+            if (dgrad2_ok<G4421>(s) && !dgrad_direct<G4421>(nullptr, s)) {
+                const SplitPlan sp = dgrad_plan<G4421>(s);
+                if (is_tile2(sp.tile)) return sp.tile;
+            }
         }
         return pick_tile((long long)N * (H / S) * (W / S), C, S * S, K * ((KH + S - 1) / S) * ((KW + S - 1) / S));
     }
