@@ -865,6 +865,7 @@ IGEMM2_DG_CASES = [
     (52, 64, 16, 384, "256x128"),        # ragged pixel tail (13312 = 52 * 256) and 3 N tiles
     (67, 68, 16, 160, "256x128"),
     (64, 256, 8, 256, "256x128"),        # 128 tiles: the reduction (64 chunks) is split in two, slabs + finish kernel
+    (8, 64, 64, 128, "256x128"),         # 64-pixel feature rows: four image rows per tile
     (64, 64, 32, 64, "512x64"),          # D.block1-size: 64 output channels, 512-pixel tiles (two 256-pixel pieces per row)
     (272, 68, 16, 48, "512x64"),         # 48 channels: the general epilogue; 17 chunks        # pixel tail inside a tile (67 * 256 = 17152 = 67 tiles), channel tail 160 = 128 + 32
 ]
@@ -909,6 +910,7 @@ IGEMM2_F_CASES = [
     (512, 64, 8, 512, "256x128"),        # OW = 4 (64 output rows per tile)
     (100, 68, 32, 384, "256x128"),       # ragged pixel tail (25600 = 100 tiles), 3 column tiles
     (512, 256, 8, 512, "256x128"),       # 32 row tiles x 4 column tiles = 128 tiles: reduction split in two
+    (32, 64, 128, 128, "256x128"),       # OW = 64: four output rows per tile
 ]
 
 
