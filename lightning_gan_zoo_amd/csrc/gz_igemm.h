@@ -2211,9 +2211,6 @@ inline int launch_igemm(const typename AL::Params& pa, const typename BL::Params
 //   void issue_piece(int kc, float* stage_base, int p, bool live);   // p in [0, PIECES), wave-uniform control flow
 // =====================================================================================================================
 constexpr int STAGES2 = 3;
-#ifndef GZ2_RD2
-#define GZ2_RD2 1
-#endif
 constexpr uint32_t SOFF_OOB = 0x80000000u;      // scalar offset that puts every lane of a buffer access out of range
 
 template <int WM_, int WN_, int TN_, int OCC_>
@@ -2381,15 +2378,6 @@ __device__ __forceinline__ float lds_rd(uint32_t byte_addr) {
     float v;
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF) : "memory");
     return v;
-}
-// two dwords at byte_addr + 4 * {D0, D1} (one LDS instruction: a single wavefront per SIMD issues ds_read_b32 at only a
-// fraction of the LDS rate -- MI355X_MICROARCH.md, LDS -- so the number of LDS instructions per k-step matters)
-template <int D0, int D1>
-__device__ __forceinline__ void lds_rd2(uint32_t byte_addr, float& x, float& y) {
-    f32x2 v;
-    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(byte_addr), "n"(D0), "n"(D1) : "memory");
-    x = v.x;
-    y = v.y;
 }
 __device__ __forceinline__ void mfma_row(f32x16 (&c)[4], float a, const float (&b)[4]) {
     // s_nop 1: a VALU write (the zeroing v_cndmask) needs two wait states before an MFMA reads the register, and the
