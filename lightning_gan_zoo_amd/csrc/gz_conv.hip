@@ -1298,6 +1298,59 @@ static int run_wgrad2(const float* x, const float* y, float* dw, float* ws, size
     return rc;
 }
 
+// ... and with both operands by LDS-DMA (igemm2w_kernel: k4 s2 p1 only, pixel rows of 4, 8 or a multiple of 16)
+template <class G>
+static int wgrad2w_cw(const float* x, const float* y, const ConvShape& s) {
+    static const bool off = getenv("GZ_NO_IGEMM2W") != nullptr;
+    if (off || G::kh != 4 || G::kw != 4 || G::s != 2 || G::p != 1) return 0;
+    if (s.H != 2 * s.OH || s.W != 2 * s.OW) return 0;
+    if ((((uintptr_t)x) | ((uintptr_t)y)) & 15) return 0;
+    const int cw = s.OW == 4 ? 4 : s.OW == 8 ? 8 : (s.OW % 16 == 0 ? 16 : 0);
+    if (!cw || s.OH % (16 / cw)) return 0;
+    return cw;
+}
+
+template <class Cfg, int CW>
+static int run_wgrad2w(const float* x, const float* y, float* dw, float* ws, size_t ws_bytes, const ConvShape& s,
+                       int splits, hipStream_t st) {
+    const int KTOT = s.N * s.OH * s.OW;
+    const int NTOT = s.C * 16;
+    Wg2Params p{x, y, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW)};
+    const long long count = (long long)s.K * NTOT;
+    if (splits > 1) {
+        long long max_splits = (long long)(ws_bytes / 4) / count;
+        if (max_splits < 2) splits = 1;
+        else if (splits > max_splits) splits = (int)max_splits;
+    }
+    const int chunks = (KTOT + BK - 1) / BK;
+    const int cps = (chunks + splits - 1) / splits;
+    const int nz = (chunks + cps - 1) / cps;
+    float* out = nz > 1 ? ws : dw;
+    EpiRowMajorB::Params pe{out, s.K, NTOT, NTOT, count, nullptr, ACT_NONE, 0.f};
+    int rc = launch_igemm2w<Cfg, CW, EpiRowMajorB>(p, pe, s.K, NTOT, KTOT, splits, st);
+    if (rc != GZ_OK) return rc;
+    if (nz > 1) {
+        if (nz <= 8)
+            hipLaunchKernelGGL(reduce_few_slabs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws, dw,
+                               nz, count);
+        else
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64 * RS_WAVES), 0, st, ws,
+                               dw, nz, count, count, (float*)nullptr, 0ll);
+        rc = launch_status();
+    }
+    return rc;
+}
+
+template <class Cfg>
+static int run_wgrad2w_cw(int cw, const float* x, const float* y, float* dw, float* ws, size_t ws_bytes,
+                          const ConvShape& s, int splits, hipStream_t st) {
+    switch (cw) {
+        case 4: return run_wgrad2w<Cfg, 4>(x, y, dw, ws, ws_bytes, s, splits, st);
+        case 8: return run_wgrad2w<Cfg, 8>(x, y, dw, ws, ws_bytes, s, splits, st);
+        default: return run_wgrad2w<Cfg, 16>(x, y, dw, ws, ws_bytes, s, splits, st);
+    }
+}
+
 template <class G, class Cfg>
 static int run_wgrad(const float* x, const float* y, float* dw, float* ws, size_t ws_bytes, const ConvShape& s,
                      hipStream_t st) {
@@ -1327,9 +1380,14 @@ static int dispatch_wgrad(const float* x, const float* y, float* dw, float* ws, 
     TileId t = (TileId)gz_conv2d_tile(2, s.N, s.C, s.H, s.W, s.K, s.OH, s.OW, G::kh, G::kw, G::s);
     if (t == T256x128 || t == T128x256) {
         const int splits = wgrad2_splits<G>(s);
-        if (splits > 0)
+        if (splits > 0) {
+            const int cw = wgrad2w_cw<G>(x, y, s);
+            if (cw)
+                return wgrad2_narrow(s) ? run_wgrad2w_cw<Cfg128x256>(cw, x, y, dw, ws, ws_bytes, s, splits, st)
+                                        : run_wgrad2w_cw<Cfg2Wg>(cw, x, y, dw, ws, ws_bytes, s, splits, st);
             return wgrad2_narrow(s) ? run_wgrad2<G, Cfg128x256>(x, y, dw, ws, ws_bytes, s, splits, st)
                                     : run_wgrad2<G, Cfg2Wg>(x, y, dw, ws, ws_bytes, s, splits, st);
+        }
         t = T128x128;
     }
     switch (t) {

@@ -2803,6 +2803,296 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2r_kernel(typename AL::Para
     Epi::template store<TM, TN>(pe, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32, lane, y, z);
 }
 
+// ---- weight gradient of the k4 s2 p1 convolution with BOTH operands arriving by LDS-DMA (igemm2w) -----------------------
+// dW[ko][(c, ky, kx)] = sum over pixels (n, oy, ox) of  dy[n][ko][oy][ox] * x[n][c][2*oy - 1 + ky][2*ox - 1 + kx].
+// Both operands are reduction-contiguous in memory, which is why igemm2r_kernel transposes them through registers
+// (16 + 8 dword loads, 12 ds_writes and their address / mask VALU per wavefront and chunk, all paid in MFMA issue
+// slots).  Here nothing is transposed on the way in:
+//   A  the chunk's 16 consecutive pixels of a dy channel are 64 contiguous bytes: the LDS image is [m][16 k] (four
+//      16-byte quads per row, the quad order XOR-swizzled with (m >> 2) & 3 so that the 16 lanes of a ds_read_b128
+//      group hit 16 different slots), and the lane (m, half) takes its operands with ONE ds_read_b128 per four
+//      k-steps.  The reduction index inside a chunk is enumerated so that this works: k-step s = 4*g + t of
+//      half-wave h multiplies pixel k = 8*g + 4*h + t (the order of a sum's terms is free as long as A and B agree);
+//   B  the raw input rows the chunk's pixels touch -- per input channel 2*R + 2 rows of 2*CW + 8 columns (R x CW =
+//      the chunk's pixel rectangle: 1 x 16, 2 x 8 or 4 x 4; four columns either side so that every 16-byte quad is
+//      entirely inside or entirely outside the image, outside = out-of-range lanes = zeros) -- land as they are, and
+//      the lane (c, ky, kx) reads  image[c][2*r + ky][2*x + kx + 3]  with r, x from k: row / channel pitches are chosen
+//      so that the 32 (c, ky, kx) lanes of a half-wave fall on 32 different banks, and every k-step's offset is an
+//      immediate.
+// No VALU and no ds_write in the loop; 24 LDS reads per chunk and wavefront instead of 48.  Ring, counted vmcnt,
+// barrier placement and the epilogue (D[m][n], lanes along n, split-K slabs through the epilogue) as above.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_rd4(uint32_t byte_addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lgkm_done(float (&b)[2]) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b[0]), "+v"(b[1])); }
+__device__ __forceinline__ void lgkm_done(f32x4 (&a)[4], float (&b)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]));
+}
+
+struct Wg2Params {
+    const float* x;          // image side  [N, C, H, W], H = 2*OH, W = 2*OW
+    const float* y;          // feature side [N, K, OH, OW]
+    ConvShape s;
+    FastDiv div_ohw, div_ow;
+};
+
+template <int BM>
+struct WgDyA2 {
+    static constexpr int PIECES = BM / 64;                 // per wavefront and chunk (BM rows x 4 quads / 64 lanes / 4)
+    static constexpr int ELEMS = BM * BK;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[PIECES];
+    int wave;
+    __device__ __forceinline__ void init(const Wg2Params& p, int tile, int tid) {
+        const ConvShape& s = p.s;
+        rsrc = make_rsrc(p.y, (uint32_t)s.N * s.K * s.OH * s.OW * 4u);
+        const int lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+            const int gq = (wave * PIECES + j) * 64 + lane;       // LDS quad
+            const int ml = gq >> 2, qk = (gq & 3) ^ ((ml >> 2) & 3);
+            const int m = tile * BM + ml;
+            voff[j] = m < s.K ? (uint32_t)(m * s.OH * s.OW + 4 * qk) * 4u : OOB;
+        }
+    }
+    __device__ __forceinline__ void issue_piece(float* stage, int j, uint32_t soff) {
+        bload_lds16(rsrc, stage + (wave * PIECES + j) * 256, voff[j], soff);
+    }
+};
+
+template <int BN, int CW>
+struct WgImgB2 {
+    static_assert(CW == 4 || CW == 8 || CW == 16, "chunk rectangles 4 x 4, 2 x 8, 1 x 16");
+    static constexpr int R = 16 / CW, IMG_ROWS = 2 * R + 2;
+    static constexpr int RQ = CW == 4 ? 5 : (2 * CW + 8) / 4;              // quads per image row (CW 4: one pad quad)
+    static constexpr int CHQ = CW == 16 ? 41 : CW == 8 ? 37 : 52;           // quads per channel (pad quads at its end)
+    static constexpr int RP = RQ * 4, CHP = CHQ * 4;                        // pitches in floats: (8*ky + 4*c + kx) mod 32,
+                                                                            // (24*ky + 20*c + kx), (20*ky + 16*c + kx)
+                                                                            // are 32 different banks
+    static constexpr int NCH = BN / 16;
+    static constexpr int PIECES = (NCH * CHQ + 255) / 256;                  // per wavefront and chunk
+    static constexpr int ELEMS = PIECES * 4 * 256;
+    // float offsets of the fragment read of k-step s = 4*g + t, half-wave h: pixel k = 8*g + 4*h + t = (r, x)
+    static constexpr int HOFF = CW == 4 ? 2 * RP : 8, GOFF = CW == 16 ? 16 : CW == 8 ? 2 * RP : 4 * RP;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[PIECES], flags[PIECES];
+    int wave;
+    __device__ __forceinline__ void init(const Wg2Params& p, int tile, int tid) {
+        const ConvShape& s = p.s;
+        // per-lane offsets are relative to the chunk's first input pixel (2*oy0, 2*ox0) and reach one row up and four
+        // columns left: the descriptor's base is moved back by that much (never dereferenced there: flagged lanes)
+        const int shift = s.W + 4;
+        rsrc = make_rsrc(p.x - shift, (uint32_t)(s.N * s.C * s.H * s.W + shift) * 4u);
+        const int lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+            const int gq = (wave * PIECES + j) * 64 + lane;
+            const int cl = gq / CHQ, rem = gq - cl * CHQ;
+            const int row = rem / RQ, q = rem - row * RQ;
+            const int c = tile * NCH + cl;
+            const int col0 = 4 * q - 4;
+            const bool inside = cl < NCH && c < s.C && row < IMG_ROWS && col0 <= 2 * CW;
+            voff[j] = inside ? (uint32_t)((c * s.H + row - 1) * s.W + col0 + shift) * 4u : OOB;
+            flags[j] = (row == 0 ? 1u : 0u) | (row == IMG_ROWS - 1 ? 2u : 0u) | (col0 < 0 ? 4u : 0u) |
+                       (col0 >= 2 * CW ? 8u : 0u);
+        }
+    }
+    __device__ __forceinline__ void issue_piece(float* stage, int j, uint32_t soff, uint32_t cond) {
+        bload_lds16(rsrc, stage + (wave * PIECES + j) * 256, (flags[j] & cond) ? OOB : voff[j], soff);
+    }
+};
+
+template <class Cfg, int CW, class Epi>
+__global__ __launch_bounds__(NT, Cfg::OCC) void igemm2w_kernel(Wg2Params p, typename Epi::Params pe, GridMap gm) {
+    using AL = WgDyA2<Cfg::BM>;
+    using BL = WgImgB2<Cfg::BN, CW>;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN;
+    static_assert(TM == 4 && TN == 2 && !Epi::SWAP, "fragment registers of the hand-ordered k-step");
+    constexpr int A_ELEMS = AL::ELEMS, B_ELEMS = BL::ELEMS, STAGE = A_ELEMS + B_ELEMS;
+    extern __shared__ __attribute__((aligned(16))) float smem2[];
+    float* const ring = smem2;                           // stage i: [B image][A image]
+
+    const int tid = threadIdx.x;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    if (!gm.no_swizzle) {
+        const int q = nwg >> 3, rr = nwg & 7, x = bid & 7, i = bid >> 3;
+        bid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + i;
+    }
+    const int tile_n = bid % gm.tiles_n;
+    const int tile_m = bid / gm.tiles_n;
+    const int z = blockIdx.z;
+    const int kc0 = z * gm.chunks_per_split;
+    const int kc1 = min(gm.chunks, kc0 + gm.chunks_per_split);
+
+    AL al;
+    BL bl;
+    al.init(p, tile_m, tid);
+    bl.init(p, tile_n, tid);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int half = lane >> 5, l32 = lane & 31;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)ring;
+    // A: row m = 16 floats, quad (2*g + half) ^ swizzle; the swizzle (m >> 2) & 3 only depends on the lane
+    const int swz = (l32 >> 2) & 3;
+    uint32_t a_addr[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+        a_addr[g] = lds0 + (uint32_t)(B_ELEMS + (wm * TM * 32 + l32) * BK + (((2 * g + half) ^ swz) << 2)) * 4u;
+    // B: lane (c, ky, kx) of the 32-column block j: channel wn*4 + 2*j + (l32 >> 4)
+    const uint32_t b_addr = lds0 + (uint32_t)((wn * 4 + (l32 >> 4)) * BL::CHP + ((l32 >> 2) & 3) * BL::RP + (l32 & 3) +
+                                              3 + half * BL::HOFF) * 4u;
+
+    constexpr int NPA = AL::PIECES, NPB = BL::PIECES, NP = NPA + NPB, STEPS = BK / 2;
+    static_assert(NP <= STEPS, "at most one LDS-DMA piece per k-step");
+    const ConvShape& s = p.s;
+    const int OHW = s.OH * s.OW;
+    uint32_t soff_a = 0, soff_b = 0, cond = 0;          // of the chunk being issued
+    auto locate = [&](int kc, bool live) {
+        const uint32_t p0 = (uint32_t)kc * BK;
+        const uint32_t n = fdiv(p0, p.div_ohw);
+        const uint32_t rem = p0 - n * (uint32_t)OHW;
+        const uint32_t oy0 = fdiv(rem, p.div_ow);
+        const uint32_t ox0 = rem - oy0 * (uint32_t)s.OW;
+        soff_a = live ? (n * (uint32_t)(s.K * OHW) + rem) * 4u : SOFF_OOB;
+        soff_b = live ? (n * (uint32_t)(s.C * s.H * s.W) + 2u * oy0 * (uint32_t)s.W + 2u * ox0) * 4u : SOFF_OOB;
+        cond = (oy0 == 0 ? 1u : 0u) | ((int)oy0 + BL::R == s.OH ? 2u : 0u) | (ox0 == 0 ? 4u : 0u) |
+               ((int)ox0 + CW == s.OW ? 8u : 0u);
+    };
+    auto issue_piece = [&](int st, int q) {
+        float* sb = ring + st * STAGE;
+        if (q < NPA) al.issue_piece(sb + B_ELEMS, q, soff_a);
+        else bl.issue_piece(sb, q - NPA, soff_b, cond);
+    };
+    auto fetch_a = [&](auto Gc, uint32_t so, f32x4 (&af)[TM]) {
+        constexpr int G = decltype(Gc)::value;
+        af[0] = lds_rd4<0>(a_addr[G] + so);
+        af[1] = lds_rd4<32 * BK * 4>(a_addr[G] + so);
+        af[2] = lds_rd4<64 * BK * 4>(a_addr[G] + so);
+        af[3] = lds_rd4<96 * BK * 4>(a_addr[G] + so);
+    };
+    auto fetch_b = [&](auto Sc, uint32_t so, float (&bf)[TN]) {
+        constexpr int S = decltype(Sc)::value;
+        constexpr int BO = ((S >> 2) * BL::GOFF + 2 * (S & 3)) * 4;
+        bf[0] = lds_rd<BO>(b_addr + so);
+        bf[1] = lds_rd<BO + 2 * BL::CHP * 4>(b_addr + so);
+    };
+
+    if (kc0 < kc1) {
+        locate(kc0, true);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) issue_piece(0, q);
+        locate(kc0 + 1, kc0 + 1 < kc1);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) issue_piece(1, q);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+        __builtin_amdgcn_s_barrier();
+        f32x4 af[2][TM];
+        float bf[2][TN];
+        fetch_a(std::integral_constant<int, 0>{}, 0u, af[0]);
+        fetch_b(std::integral_constant<int, 0>{}, 0u, bf[0]);
+        lgkm_done(af[0], bf[0]);
+        int stage = 0;
+        for (int kc = kc0; kc < kc1; ++kc) {
+            int s1 = stage + 1; if (s1 >= STAGES2) s1 -= STAGES2;
+            int s2 = s1 + 1; if (s2 >= STAGES2) s2 -= STAGES2;
+            const uint32_t so = (uint32_t)(stage * STAGE * 4), sno = (uint32_t)(s1 * STAGE * 4);
+            locate(kc + 2, kc + 2 < kc1);
+            auto kstep = [&](auto Sc) {
+                constexpr int S = decltype(Sc)::value;
+                constexpr int c = S & 1, n = c ^ 1, g = S >> 2, t = S & 3;
+                if constexpr (S + 1 < STEPS) {
+                    fetch_b(std::integral_constant<int, S + 1>{}, so, bf[n]);
+                    if constexpr (S == 0) fetch_a(std::integral_constant<int, 1>{}, so, af[1]);
+                    mfma_row_mn(acc[0], af[g][0][t], bf[c]);
+                    mfma_row_mn(acc[1], af[g][1][t], bf[c]);
+                    if constexpr (S < NP) issue_piece(s2, S);
+                    mfma_row_mn(acc[2], af[g][2][t], bf[c]);
+                    mfma_row_mn(acc[3], af[g][3][t], bf[c]);
+                    if constexpr (S == 0) lgkm_done(af[1], bf[n]);
+                    else lgkm_done(bf[n]);
+                } else {
+                    mfma_row_mn(acc[0], af[g][0][t], bf[c]);
+                    mfma_row_mn(acc[1], af[g][1][t], bf[c]);
+                    if constexpr (S < NP) issue_piece(s2, S);
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    fetch_b(std::integral_constant<int, 0>{}, sno, bf[n]);
+                    fetch_a(std::integral_constant<int, 0>{}, sno, af[0]);
+                    mfma_row_mn(acc[2], af[g][2][t], bf[c]);
+                    mfma_row_mn(acc[3], af[g][3][t], bf[c]);
+                    lgkm_done(af[0], bf[n]);
+                }
+            };
+            kstep(std::integral_constant<int, 0>{});
+            kstep(std::integral_constant<int, 1>{});
+            kstep(std::integral_constant<int, 2>{});
+            kstep(std::integral_constant<int, 3>{});
+            kstep(std::integral_constant<int, 4>{});
+            kstep(std::integral_constant<int, 5>{});
+            kstep(std::integral_constant<int, 6>{});
+            kstep(std::integral_constant<int, 7>{});
+            stage = s1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    }
+    Epi::template store<TM, TN>(pe, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32, lane, 0, z);
+}
+
+template <class Cfg, int CW>
+constexpr size_t igemm2w_lds_bytes() {
+    return (size_t)STAGES2 * (WgDyA2<Cfg::BM>::ELEMS + WgImgB2<Cfg::BN, CW>::ELEMS) * 4;
+}
+
+template <class Cfg, int CW, class Epi>
+inline int launch_igemm2w(const Wg2Params& p, const typename Epi::Params& pe, int M, int N, int K, int splits,
+                          hipStream_t stream) {
+    GridMap gm;
+    static int no_swz = getenv("GZ_NO_XCD_SWIZZLE") ? 1 : 0;
+    gm.no_swizzle = no_swz;
+    gm.var_chunks = 0;
+    gm.slab = nullptr;
+    gm.slab_m = M;
+    gm.slab_n = N;
+    gm.tiles_m = (M + Cfg::BM - 1) / Cfg::BM;
+    gm.tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
+    gm.chunks = (K + BK - 1) / BK;
+    if (splits < 1) splits = 1;
+    gm.chunks_per_split = (gm.chunks + splits - 1) / splits;
+    int nz = (gm.chunks + gm.chunks_per_split - 1) / gm.chunks_per_split;
+    if (nz < 1) nz = 1;
+    gm.ny = 1;
+    gm.stagger = 0;
+    for (int i = 0; i < 8; ++i) gm.phase_nz[i] = gm.phase_slab0[i] = 0;
+    dim3 grid(gm.tiles_m * gm.tiles_n, 1, nz);
+    constexpr size_t lds = igemm2w_lds_bytes<Cfg, CW>();
+    auto kern = igemm2w_kernel<Cfg, CW, Epi>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return launch_status();
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, p, pe, gm);
+    return launch_status();
+}
+
 // split-K through the epilogue's own slabs (pe.slab_stride), as launch_igemm does for the weight gradient
 template <class Cfg, class AL, class BL, class Epi>
 inline int launch_igemm2r(const typename AL::Params& pa, const typename BL::Params& pb, const typename Epi::Params& pe,
