@@ -975,3 +975,39 @@ def test_igemm2_weight_gradient_matches_torch(case):
     err = rel(dw, ref)
     assert err < TOL, err
     assert torch.equal(dw, F._conv_wgrad_raw(x.cuda(), gy.cuda(), F.K4S2P1))      # fixed summation order
+
+
+IGEMM2W_CASES = [
+    # N, C, H, W (image side), K: the shapes that reach igemm2w_kernel's less-travelled paths
+    (64, 32, 64, 64, 256),       # rows of 32 pixels: two chunks per row, left / right halo quads differ per chunk
+    (32, 16, 128, 128, 256),     # rows of 64 pixels: interior chunks with both halo quads inside the image
+    (2048, 20, 16, 16, 256),     # 20 input channels: the last column tile holds 4 channels (the others out of range)
+    (2048, 32, 16, 8, 256),      # 8 x 4 feature map: two 4 x 4 chunks per image (top / bottom halo rows differ)
+    (1024, 32, 8, 32, 256),      # 4 x 16 feature map: one-row chunks, rows 0 and 3 lose their top / bottom halo row
+    (2048, 40, 16, 16, 128),     # the 128 x 256 tile with a ragged column tile (640 columns = 2.5 tiles)
+]
+
+
+@pytest.mark.parametrize("case", IGEMM2W_CASES)
+def test_igemm2w_weight_gradient_edge_shapes(case):
+    """igemm2w_kernel (weight gradient of k4 s2 p1, both operands by LDS-DMA): halo quads / rows at every kind of
+    chunk position, ragged channel tiles, non-square maps -- against torch's CPU operator, and against the
+    register-staged kernel (GZ_NO_IGEMM2W is read once per process, so that comparison is indirect: same reference)."""
+    F = _F()
+    from lightning_gan_zoo_amd._lib import lib
+    N, C, H, W, K = case
+    OH, OW = H // 2, W // 2
+    tile = lib.gz_conv2d_tile(2, N, C, H, W, K, OH, OW, 4, 4, 2)
+    assert F._TILES[tile] == ("256x128" if K >= 256 else "128x256"), F._TILES[tile]
+    x = rnd(N, C, H, W, seed=41)
+    gy = rnd(N, K, OH, OW, seed=42)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = torch.nn.grad.conv2d_weight(x, (K, C, 4, 4), gy, stride=2, padding=1)
+    dw = F._conv_wgrad_raw(x.cuda(), gy.cuda(), F.K4S2P1)
+    err = rel(dw, ref)
+    assert err < TOL, err
+    # an unaligned view takes the register-staged kernel: same numbers to rounding
+    xs = torch.empty(x.numel() + 1, device="cuda")[1:].view_as(x).copy_(x)
+    dw2 = F._conv_wgrad_raw(xs, gy.cuda(), F.K4S2P1)
+    assert rel(dw2, ref) < TOL
+    assert rel(dw2, dw) < 1e-5
