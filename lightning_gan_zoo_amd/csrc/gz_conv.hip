@@ -403,6 +403,21 @@ static int run_fwd2(const float* x, const float* wp, const float* bias, float* y
     return launch_igemm2<Cfg, AL, BL, EpiNCHWB>(pa, pb, pe, M, s.K, Kg, 1, splits, st, slab);
 }
 
+// any other geometry whose reduction is tap-major (5x5 s2 p2, 3x3 s1 p1, 1x1 ...): gather loader, 4-byte LDS-DMA
+template <class G, class Cfg>
+static int run_fwdtap2(const float* x, const float* wp, const float* bias, float* y, const ConvShape& s, int act,
+                       float slope, hipStream_t st, int splits, float* slab, float* stats) {
+    using AL = ConvTapA2<Cfg::BM, G::kh, G::kw, G::s, G::p>;
+    using BL = MContigB2<Cfg::BN>;
+    typename AL::Params pa{x, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW)};
+    const int M = s.N * s.OH * s.OW;
+    EpiNCHWB::Params pe{y, M, s.K, s.OH * s.OW, make_fastdiv(s.OH * s.OW), bias, act, slope,
+                        reinterpret_cast<f32x2*>(stats)};
+    const int Kt = G::kh * G::kw * round_bk(s.C);
+    typename BL::Params pb{wp, Kt, round4(s.K), round4(s.K), 0};
+    return launch_igemm2<Cfg, AL, BL, EpiNCHWB>(pa, pb, pe, M, s.K, Kt, 1, splits, st, slab);
+}
+
 template <class Cfg>
 static int run_fwd2_ow(const float* x, const float* wp, const float* bias, float* y, const ConvShape& s, int act,
                        float slope, hipStream_t st, int splits = 1, float* slab = nullptr, float* stats = nullptr) {
@@ -440,9 +455,30 @@ static TileId pick_tile_fwd(long long M, int K, int OW, int kh, int kw, int stri
 
 // igemm2 plan of a forward launch: tile and reduction splits (few M tiles: the reduction is cut so that >= 256
 // workgroups exist, each with >= 32 chunks)
+// tap-major geometries on the igemm2 skeleton (ConvTapA2): >= 128 output channels, and enough tiles x reduction
+// splits to give every CU a workgroup, each with >= 32 chunks
+template <class G>
+static SplitPlan fwdtap2_plan(const ConvShape& s) {
+    static const bool off = getenv("GZ_NO_IGEMM2") != nullptr || getenv("GZ_NO_IGEMM2_TAP") != nullptr;
+    if constexpr (BK % (G::kh * G::kw) == 0) return SplitPlan{T64x64, 1};
+    if (off || !fwd_tap_major(s.C, G::kh, G::kw) || s.K < 128 || (s.K & 3)) return SplitPlan{T64x64, 1};
+    const long long M = (long long)s.N * s.OH * s.OW;
+    const long long tiles = ((M + 255) / 256) * ((s.K + 127) / 128);
+    const int chunks = G::kh * G::kw * round_bk(s.C) / BK;
+    if (tiles >= 224) return SplitPlan{T256x128, 1};
+    // split launches pay off from ~64 chunks per workgroup (HoloGAN EXT-128's blocks: 100 -> 115-118 TFLOP/s against
+    // 80-94 on the 64x64 tiles; the 64x64-image blocks would get 33 chunks each and lose 5 %)
+    if (tiles >= 8 && chunks >= 128) {
+        int splits = (int)((256 + tiles - 1) / tiles);
+        while (splits > 1 && chunks / splits < 64) --splits;
+        if (splits > 1 && tiles * splits >= 192) return SplitPlan{T256x128, splits};
+    }
+    return SplitPlan{T64x64, 1};
+}
+
 template <class G>
 static SplitPlan fwd2_plan(const ConvShape& s) {
-    if (!fwd2_ok<G>(s)) return SplitPlan{T64x64, 1};
+    if (!fwd2_ok<G>(s)) return fwdtap2_plan<G>(s);
     const long long M = (long long)s.N * s.OH * s.OW;
     TileId t = s.K > 64 ? pick_tile2(M, s.K, 1, s.C * 16) : T64x64;
     if (t == T256x256 || t == T256x128) return SplitPlan{t, 1};
@@ -481,13 +517,15 @@ static int dispatch_fwd(const float* x, const float* wp, const float* bias, floa
     if (sp.splits > 1 && (!ws || ws_bytes < fwd_ws_bytes<G>(s)))
         sp = SplitPlan{pick_tile_fwd(M, s.K, s.OW, G::kh, G::kw, G::s, 0), 1};
     float* slab = sp.splits > 1 ? ws : nullptr;
-    if ((sp.tile == T256x256 || sp.tile == T256x128) && (((uintptr_t)x) & 15) != 0) {
+    if ((sp.tile == T256x256 || sp.tile == T256x128) && fwd2_ok<G>(s) && (((uintptr_t)x) & 15) != 0) {
         sp = SplitPlan{pick_tile_fwd(M, s.K, s.OW, G::kh, G::kw, G::s, 0), 1};      // unaligned tensor
         slab = nullptr;
     }
     switch (sp.tile) {
         case T256x256: return run_fwd2_ow<Cfg256x256>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
-        case T256x128: return run_fwd2_ow<Cfg256x128>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
+        case T256x128:
+            if (!fwd2_ok<G>(s)) return run_fwdtap2<G, Cfg256x128>(x, wp, bias, y, s, act, slope, st, sp.splits, slab, nullptr);
+            return run_fwd2_ow<Cfg256x128>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
         case T128x128: return run_fwd<G, Cfg128x128>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
         case T128x64: return run_fwd<G, Cfg128x64>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
         case T128x32: return run_fwd<G, Cfg128x32>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
@@ -1638,7 +1676,9 @@ int gz_conv2d_fwd_stats(const float* x, const float* wpack, float* y, float* sta
     [&]() -> int {                                                                                                   \
         switch (fwd_plan<G>(s).tile) {                                                                               \
             case T256x256: return run_fwd2_ow<Cfg256x256>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats); \
-            case T256x128: return run_fwd2_ow<Cfg256x128>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats); \
+            case T256x128:                                                                                           \
+                if (!fwd2_ok<G>(s)) return run_fwdtap2<G, Cfg256x128>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats); \
+                return run_fwd2_ow<Cfg256x128>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats);          \
             case T128x128: return run_fwd<G, Cfg128x128>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats); \
             case T128x64: return run_fwd<G, Cfg128x64>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats);   \
             case T128x32: return run_fwd<G, Cfg128x32>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats);   \
@@ -1749,6 +1789,11 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
             ConvShape s{N, C, H, W, K, OH, OW};
             const SplitPlan p2 = fwd2_plan<G4421>(s);
             if (p2.tile == T256x256 || p2.tile == T256x128) return p2.tile;
+        }
+        if ((KH == 5 && KW == 5 && S == 2) || (KH == 3 && KW == 3 && S == 1)) {
+            ConvShape s{N, C, H, W, K, OH, OW};
+            const SplitPlan p2 = KH == 5 ? fwdtap2_plan<G5522>(s) : fwdtap2_plan<G3311>(s);
+            if (p2.tile == T256x128) return p2.tile;
         }
         return pick_tile_fwd((long long)N * OH * OW, K, OW, KH, KW, S, C * KH * KW);
     }

@@ -2350,6 +2350,75 @@ struct ConvFwdA2 {
     }
 };
 
+// A operand of a forward convolution of ANY geometry, tap-major reduction (k = (tap, channel), channels padded to a
+// chunk: the layout of ConvFwdALoaderTap and of pack_fwd_tap's weight rows): a chunk is 16 channels at ONE tap, its LDS
+// image [16 channels][BM pixels] a plain gather -- pixel m of channel c sits at x[n][c][S*oy - P + dy][S*ox - P + dx],
+// a fixed per-lane offset plus a per-(channel, tap) scalar.  The elements of a row are S floats apart in memory, so
+// the pieces are 4-BYTE LDS-DMA instructions (64 pixels of one channel each; 16 per wavefront and chunk at BM = 256,
+// three per k-step); taps that fall into the padding are out-of-range lanes (zeros), re-evaluated per lane only when
+// the tap changes (once every C/16 chunks).  Fragment reads are igemm_kernel's plain [k][m] ones: no VALU in the loop.
+template <int BM, int KH, int KW, int S, int P>
+struct ConvTapA2 {
+    using Params = typename ConvFwdALoader<BM, KH, KW, S, P>::Params;
+    static constexpr int LD = BM, ROWS = BK;
+    static constexpr int G = BM / 64;                      // 64-pixel groups per LDS row
+    static constexpr int PIECES = BK * G / 4;              // per wavefront and chunk: its 4 channel rows x G groups
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t vbase[G], veff[G];
+    int iy0[G], ix0[G];
+    int wave, C, H, W, HW, cblocks, last_tap, last_kc, cb;
+    uint32_t tap_soff;
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        const ConvShape& s = p.s;
+        const uint32_t shift = (uint32_t)(P * s.W + P) * 4u;
+        rsrc = make_rsrc(reinterpret_cast<const char*>(p.x) - shift, (uint32_t)s.N * s.C * s.H * s.W * 4u + shift);
+        const int lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        C = s.C; H = s.H; W = s.W; HW = s.H * s.W;
+        cblocks = round_bk(s.C) / BK;
+        last_tap = -1; last_kc = -1; cb = 0; tap_soff = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint32_t m = (uint32_t)tile * BM + g * 64 + lane;
+            const bool m_ok = m < (uint32_t)s.N * s.OH * s.OW;
+            const uint32_t n = fdiv(m, p.div_ohw);
+            const uint32_t pix = m - n * (uint32_t)(s.OH * s.OW);
+            const uint32_t oy = fdiv(pix, p.div_ow);
+            const uint32_t ox = pix - oy * (uint32_t)s.OW;
+            iy0[g] = m_ok ? (int)oy * S - P : -(1 << 20);      // rows past M: every tap out of range
+            ix0[g] = (int)ox * S - P;
+            vbase[g] = (n * (uint32_t)(s.C * HW) + (uint32_t)((iy0[g] + P) * W + (ix0[g] + P))) * 4u;   // shifted base
+            veff[g] = OOB;
+        }
+    }
+    __device__ __forceinline__ void issue_piece(int kc, float* stage, int p, bool live) {
+        if (p == 0) {        // (p is a literal at every call site) chunk -> (tap, channel block), wave-uniform;
+                             // chunks arrive in increasing order, so only the first one costs a division
+            int tap = last_tap;
+            if (kc == last_kc + 1 && last_kc >= 0) {
+                cb += BK;
+                if (cb >= cblocks * BK) { cb = 0; ++tap; }
+            } else {
+                tap = kc / cblocks;
+                cb = (kc - tap * cblocks) * BK;
+            }
+            last_kc = kc;
+            if (tap != last_tap) {
+                last_tap = tap;
+                const int dy = tap / KW, dx = tap - dy * KW;
+                tap_soff = (uint32_t)(dy * W + dx) * 4u;
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    veff[g] = ((unsigned)(iy0[g] + dy) < (unsigned)H && (unsigned)(ix0[g] + dx) < (unsigned)W) ? vbase[g] : OOB;
+            }
+        }
+        const int row = wave * 4 + p / G, g = p % G;
+        const int c = cb + row;
+        bload_lds4(rsrc, stage + row * LD + g * 64, veff[g],
+                   (live && c < C) ? (uint32_t)c * (uint32_t)HW * 4u + tap_soff : SOFF_OOB);
+    }
+};
+
 #ifdef GZ2_STAMPS       // diagnostic builds only (tools/igemm2_conv_probe.hip, tools/conv_bench2.py --stamps)
 __device__ unsigned long long gz2_stamps[8192 * 8];
 #define GZ2_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -2530,7 +2599,8 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
     const uint32_t b_addr = lds0 + (uint32_t)(half * LDB + wn * TN * 32 + l32) * 4u;
 
     constexpr int NPA = AL::PIECES, NPB = BL::PIECES, NP = NPA + NPB, STEPS = BK / 2;
-    static_assert(NP <= STEPS, "at most one LDS-DMA piece per k-step");
+    constexpr int PPS = (NP + STEPS - 1) / STEPS;          // LDS-DMA pieces per k-step (1 for the 16-byte loaders)
+    static_assert(PPS <= 4 && NP < 64, "pieces are spread over the k-step's four MFMA rows; vmcnt is 6 bits");
     auto issue_piece = [&](int kc, int st, int p, bool live) {
 #ifdef GZ2_EXP_NODMA       // timing experiments only (wrong results)
         if (kc >= kc0 + 2) return;
@@ -2599,22 +2669,35 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
             auto kstep = [&](auto Sc) {
                 constexpr int S = decltype(Sc)::value;
                 constexpr int c = S & 1, n = c ^ 1;
+                // chunk kc+2's pieces go out in the FIRST k-steps, PPS per step, one behind each MFMA row (the stage
+                // they overwrite was last read in chunk kc-1, behind its barrier), so that by the last k-step exactly
+                // NP are in flight
+                auto pieces = [&](auto Rowc) {        // behind MFMA row `Rowc` (a single piece per k-step: behind row 1)
+                    constexpr int row = decltype(Rowc)::value;
+                    constexpr int r = PPS == 1 ? (row == 1 ? 0 : -1) : row;
+                    constexpr int q = S * PPS + r;
+                    if constexpr (r >= 0 && r < PPS && q < NP) issue_piece(kc + 2, s2, q, more);
+                };
                 if constexpr (S + 1 < STEPS) {
                     fetch(std::integral_constant<int, S + 1>{}, so, af[n], bf[n]);
                     mfma_row(acc[0], af[c][0], bf[c]);
+                    pieces(std::integral_constant<int, 0>{});
                     mfma_row(acc[1], af[c][1], bf[c]);
-                    // chunk kc+2's pieces go out in the FIRST NP k-steps (the stage they overwrite was last read in
-                    // chunk kc-1, behind its barrier), so that by the last k-step exactly NP are in flight
-                    if constexpr (S < NP) issue_piece(kc + 2, s2, S, more);
+                    pieces(std::integral_constant<int, 1>{});
                     mfma_row(acc[2], af[c][2], bf[c]);
+                    pieces(std::integral_constant<int, 2>{});
                     mfma_row(acc[3], af[c][3], bf[c]);
+                    pieces(std::integral_constant<int, 3>{});
                 } else {
                     // last k-step: half of its MFMAs, then chunk kc+1 must have landed (all but the NP pieces of chunk
                     // kc+2) and every wavefront must be done with this stage's fragments; the first fragments of
                     // chunk kc+1 are fetched under the other half
                     mfma_row(acc[0], af[c][0], bf[c]);
+                    pieces(std::integral_constant<int, 0>{});
                     mfma_row(acc[1], af[c][1], bf[c]);
-                    if constexpr (S < NP) issue_piece(kc + 2, s2, S, more);
+                    pieces(std::integral_constant<int, 1>{});
+                    pieces(std::integral_constant<int, 2>{});
+                    pieces(std::integral_constant<int, 3>{});
 #ifndef GZ2_EXP_NOVMWAIT
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
 #endif

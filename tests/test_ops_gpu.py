@@ -86,6 +86,21 @@ def test_small_channel_transposed_conv(case):
                TF.conv_transpose2d(gy, w, None, 2, 1)) < TOL
 
 
+@pytest.mark.parametrize("case", [(512, 3, 64, 7), (128, 3, 128, 2), (512, 2, 64, 65), (520, 4, 64, 16), (512, 1, 64, 193)])
+def test_small_channel_transposed_conv_full_chip(case):
+    """The same layer at sizes that give every SIMD >= 2 wavefronts of lane positions (the unsplit channel loop: 256
+    lane positions per workgroup), odd channel counts and a batch that is not a multiple of the workgroup."""
+    F = _F()
+    N, C, H, K = case
+    gy = rnd(N, K, H // 2, H // 2, seed=17)
+    w = rnd(K, C, 4, 4, seed=18, scale=0.2)
+    b = rnd(C, seed=19)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = torch.tanh(TF.conv_transpose2d(gy, w, b, 2, 1))
+    out = F._conv_dgrad_raw(gy.cuda(), w.cuda(), b.cuda(), F.K4S2P1, (H, H), F.ACT_TANH, 0.0)
+    assert out.shape == ref.shape and rel(out, ref) < TOL
+
+
 @pytest.mark.parametrize("case", [(2, 3, 16, 5), (4, 8, 16, 16), (3, 20, 8, 40), (8, 64, 16, 128), (16, 32, 32, 96),
                                   (64, 16, 32, 256), (512, 64, 32, 128), (37, 24, 16, 72)])
 def test_conv_with_fused_batchnorm_statistics(case):
@@ -1011,3 +1026,38 @@ def test_igemm2w_weight_gradient_edge_shapes(case):
     dw2 = F._conv_wgrad_raw(xs, gy.cuda(), F.K4S2P1)
     assert rel(dw2, ref) < TOL
     assert rel(dw2, dw) < 1e-5
+
+
+IGEMM2_TAP_CASES = [
+    # N, C, H, K, k, stride, pad
+    (64, 64, 64, 128, 5, 2, 2),       # HoloGAN EXT-128 D.block1: 256 tiles, 100 chunks, no split
+    (64, 128, 32, 256, 5, 2, 2),      # D.block2: 128 tiles, 200 chunks -> 2 splits
+    (64, 256, 16, 512, 5, 2, 2),      # D.block3: 64 tiles, 400 chunks -> 4 splits
+    (64, 72, 32, 160, 3, 1, 1),       # 3x3 s1 p1, 72 channels (last chunk of a tap: 8 live rows), 160 = 128 + 32 columns
+    (67, 72, 32, 160, 3, 1, 1),       # the same with a ragged last pixel tile (68608 pixels = 268 tiles)
+    (70, 64, 64, 128, 5, 2, 2),       # 71680 pixels = 280 tiles: more than one workgroup per CU for some
+    (33, 128, 32, 256, 5, 2, 2),      # 8448 pixels = 33 x 2 tiles, 200 chunks -> 3 splits of 67, ragged batch
+]
+
+
+@pytest.mark.parametrize("case", IGEMM2_TAP_CASES)
+def test_igemm2_tap_major_forward_matches_torch(case):
+    """Forward convolutions whose reduction is tap-major (5x5 s2 p2, 3x3 ...) on the igemm2 skeleton: gather loader
+    with 4-byte LDS-DMA pieces (three per k-step), padding taps as out-of-range lanes; bias + LeakyReLU epilogue."""
+    F = _F()
+    from lightning_gan_zoo_amd._lib import lib
+    N, C, H, K, k, st, pd = case
+    geom = F.Geom(k, k, st, pd)
+    OH = (H + 2 * pd - k) // st + 1
+    tile = lib.gz_conv2d_tile(0, N, C, H, H, K, OH, OH, k, k, st)
+    x = rnd(N, C, H, H, seed=51)
+    w = rnd(K, C, k, k, seed=52, scale=0.05)
+    b = rnd(K, seed=53)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = TF.leaky_relu(TF.conv2d(x, w, b, st, pd), 0.2)
+    out = F._conv_fwd_raw(x.cuda(), w.cuda(), b.cuda(), geom, F.ACT_LRELU, 0.2)
+    assert out.shape == ref.shape
+    err = rel(out, ref)
+    assert err < TOL, (err, F._TILES[tile])
+    if case[:4] in ((64, 64, 64, 128), (64, 128, 32, 256), (64, 256, 16, 512), (70, 64, 64, 128)):
+        assert F._TILES[tile] == "256x128", F._TILES[tile]
