@@ -851,6 +851,56 @@ static int run_dgrad2(const float* y, const float* wp, const float* bias, float*
     return launch_igemm2<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kg, 4, splits, st, slab);
 }
 
+// transposed convolutions whose reduction is tap-major and whose phases differ in length (5x5 s2 p2: 9 / 6 / 6 / 4
+// taps): gather loader with 4-byte LDS-DMA; the reduction is cut into pieces of ~48 chunks so that the phases'
+// workgroups balance (unsplit, the 9-tap phase's workgroups would run 2.25x longer than the 4-tap phase's)
+template <class G, class Cfg>
+static int run_dgradtap2(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s, int act,
+                         float slope, hipStream_t st, int splits, float* slab) {
+    using AL = ConvDgTapA2<Cfg::BM, G::kh, G::kw, G::s, G::p>;
+    using BL = MContigB2<Cfg::BN>;
+    using Epi = EpiPhaseB<G::s>;
+    const int AH = s.H / G::s, AW = s.W / G::s;
+    typename AL::Params pa{y, s, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW)};
+    const int kpad = round_bk(s.K);
+    const int Kt = AL::TY * AL::TX * kpad;
+    const int ldc = round4(s.C);
+    typename BL::Params pb{wp, Kt, ldc, ldc, (long long)Kt * ldc};
+    const int M = s.N * AH * AW;
+    typename Epi::Params pe{x, M, s.C, s.H, s.W, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW), bias, act, slope,
+                            nullptr, 0};
+    int pc[8];
+    for (int ph = 0; ph < G::s * G::s; ++ph)
+        pc[ph] = dg_taps(G::kh, G::s, G::p, ph / G::s) * dg_taps(G::kw, G::s, G::p, ph % G::s) * (kpad / BK);
+    return launch_igemm2<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kt, G::s * G::s, splits, st, slab, pc);
+}
+
+template <class G>
+static SplitPlan dgradtap2_plan(const ConvShape& s) {
+    static const bool off = getenv("GZ_NO_IGEMM2") != nullptr || getenv("GZ_NO_IGEMM2_TAP") != nullptr;
+    constexpr int TY = (G::kh + G::s - 1) / G::s, TX = (G::kw + G::s - 1) / G::s;
+    if constexpr (G::s * G::s > 8 || (G::kh % G::s == 0 && G::kw % G::s == 0)) return SplitPlan{T64x64, 1};
+    if (off || !dgrad_tap_major(s.K, G::kh, G::kw, G::s) || s.C < 128 || (s.C & 3) || s.H % G::s || s.W % G::s)
+        return SplitPlan{T64x64, 1};
+    const long long M = (long long)s.N * (s.H / G::s) * (s.W / G::s);
+    const long long tiles = ((M + 255) / 256) * ((s.C + 127) / 128);
+    const int kblocks = round_bk(s.K) / BK;
+    long long total = 0;
+    for (int ph = 0; ph < G::s * G::s; ++ph)
+        total += (long long)dg_taps(G::kh, G::s, G::p, ph / G::s) * dg_taps(G::kw, G::s, G::p, ph % G::s) * kblocks;
+    const int maxchunks = TY * TX * kblocks;
+    if (tiles * total < 512LL * 32) return SplitPlan{T64x64, 1};       // too little work for the big tile
+    // ~384 workgroups of <= 96 chunks (measured on HoloGAN EXT-128's blocks, TFLOP/s of D.block2 / D.block3:
+    // 256 workgroups 84 / 67, 384: 99 / 99, 512: 99 / 89, 768: 90 / 86; the round-2 kernels: 89 / 74)
+    static const int wgs = getenv("GZ_TAP_WGS") ? atoi(getenv("GZ_TAP_WGS")) : 384;
+    static const int cps_max = getenv("GZ_TAP_CPS_MAX") ? atoi(getenv("GZ_TAP_CPS_MAX")) : 96;
+    long long cps = (tiles * total + wgs - 1) / wgs;
+    if (cps < 32) cps = 32;
+    if (cps > cps_max) cps = cps_max;
+    const int splits = (int)((maxchunks + cps - 1) / cps);
+    return SplitPlan{T256x128, splits < 1 ? 1 : splits};
+}
+
 template <class G>
 static bool dgrad2_ok(const ConvShape& s) {
     // ConvDgA2: 16-byte pieces of whole pixel quads; a tile's first pixel starts an image row (256 % AW == 0)
@@ -884,6 +934,10 @@ static SplitPlan dgrad_plan(const ConvShape& s) {
             if (splits > 1 && tiles * splits >= 256) return SplitPlan{T256x128, splits};
         }
     }
+    {
+        const SplitPlan pt = dgradtap2_plan<G>(s);
+        if (pt.tile == T256x128) return pt;
+    }
     return plan_split(M, s.C, kk * TAPS, G::s * G::s, pick_tile(M, s.C, G::s * G::s, kk * TAPS));
 }
 
@@ -911,11 +965,13 @@ static int dispatch_dgrad(const float* y, const float* wp, const float* bias, fl
     SplitPlan sp = dgrad_plan<G>(s);
     if (sp.splits > 1 && (!ws || ws_bytes < dgrad_ws_bytes<G>(s))) sp = SplitPlan{pick_tile(M, s.C, G::s * G::s), 1};
     float* slab = sp.splits > 1 ? ws : nullptr;
-    if (is_tile2(sp.tile) && (((uintptr_t)y) & 15) != 0)
+    if (is_tile2(sp.tile) && dgrad2_ok<G>(s) && (((uintptr_t)y) & 15) != 0)
         sp = SplitPlan{pick_tile(M, s.C, G::s * G::s), 1};        // unaligned tensor: the element-wise loaders
     switch (sp.tile) {
         case T256x256: return run_dgrad2<Cfg256x256>(y, wp, bias, x, s, act, slope, st);
-        case T256x128: return run_dgrad2<Cfg256x128>(y, wp, bias, x, s, act, slope, st, nullptr, sp.splits, slab);
+        case T256x128:
+            if (!dgrad2_ok<G>(s)) return run_dgradtap2<G, Cfg256x128>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
+            return run_dgrad2<Cfg256x128>(y, wp, bias, x, s, act, slope, st, nullptr, sp.splits, slab);
         case T512x64: return run_dgrad2<Cfg512x64>(y, wp, bias, x, s, act, slope, st);
         case T128x128: return run_dgrad<G, Cfg128x128>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
         case T128x64: return run_dgrad<G, Cfg128x64>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
@@ -1661,7 +1717,7 @@ int gz_conv2d_fwd_stats_rows(int N, int C, int H, int W, int K, int OH, int OW, 
     SplitPlan sp = [&]() -> SplitPlan { GZ_GEOM_DISPATCH_OR(CALL, (SplitPlan{T64x64, 2})) }();
 #undef CALL
     if (sp.splits > 1) return 0;              // split-K launches finish in another kernel: not fused
-    return stats_tm_rows(sp.tile, (long long)N * OH * OW);
+    return stats_tm_rows(sp.tile, (long long)N * OH * OW);      // (the tap-major gather launches do carry them)
 }
 
 int gz_conv2d_fwd_stats(const float* x, const float* wpack, float* y, float* stats, int N, int C, int H, int W, int K,
@@ -1696,6 +1752,7 @@ int gz_conv2d_dgrad_stats_rows(int N, int C, int H, int W, int K, int OH, int OW
     SplitPlan sp = [&]() -> SplitPlan { GZ_GEOM_DISPATCH_OR(CALL, (SplitPlan{T64x64, 2})) }();
 #undef CALL
     if (sp.splits > 1) return 0;
+    if (is_tile2(sp.tile) && !(KH == 4 && KW == 4 && S == 2 && P == 1)) return 0;      // gather-loader launches: not fused
     return S * S * stats_tm_rows(sp.tile, (long long)N * (H / S) * (W / S));
 }
 
@@ -1804,6 +1861,10 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
                 const SplitPlan sp = dgrad_plan<G4421>(s);
                 if (is_tile2(sp.tile)) return sp.tile;
             }
+        }
+        if (KH == 5 && KW == 5 && S == 2) {
+            ConvShape s{N, C, H, W, K, OH, OW};
+            if (dgradtap2_plan<G5522>(s).tile == T256x128) return T256x128;
         }
         return pick_tile((long long)N * (H / S) * (W / S), C, S * S, K * ((KH + S - 1) / S) * ((KW + S - 1) / S));
     }

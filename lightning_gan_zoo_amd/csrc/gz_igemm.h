@@ -2419,6 +2419,74 @@ struct ConvTapA2 {
     }
 };
 
+// The same gather for the TRANSPOSED convolution, phase (py, px), tap-major (ConvDgALoaderTap's reduction order and
+// pack_dgrad_tap's weight rows): chunk = 16 feature channels at one of the phase's ny x nx taps,
+// A[k = (tap, ko)][m = (n, a, b)] = y[n][ko][oy0 - ty][ox0 - tx].  Phases have their own chunk counts.
+template <int BM, int KH, int KW, int S, int P>
+struct ConvDgTapA2 {
+    static constexpr int TY = (KH + S - 1) / S, TX = (KW + S - 1) / S;
+    using Params = typename ConvDgALoaderTap<BM, KH, KW, S, P>::Params;
+    static constexpr int LD = BM, ROWS = BK;
+    static constexpr int G = BM / 64;
+    static constexpr int PIECES = BK * G / 4;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t vbase[G], veff[G];
+    int oy0[G], ox0[G];
+    int wave, K, OH, OW, OHW, kblocks, nx_p, last_tap, last_kc, kob;
+    uint32_t tap_soff;
+    __device__ __forceinline__ void init(const Params& p, int tile, int phase, int tid) {
+        const ConvShape& s = p.s;
+        const uint32_t shift = (uint32_t)((TY - 1) * s.OW + (TX - 1)) * 4u;
+        rsrc = make_rsrc(reinterpret_cast<const char*>(p.y) - shift, (uint32_t)s.N * s.K * s.OH * s.OW * 4u + shift);
+        const int lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int py = phase / S, px = phase % S;
+        nx_p = dg_taps(KW, S, P, px);
+        K = s.K; OH = s.OH; OW = s.OW; OHW = s.OH * s.OW;
+        kblocks = round_bk(s.K) / BK;
+        last_tap = -1; last_kc = -1; kob = 0; tap_soff = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint32_t m = (uint32_t)tile * BM + g * 64 + lane;
+            const bool m_ok = m < (uint32_t)s.N * p.AH * p.AW;
+            const uint32_t n = fdiv(m, p.div_ahw);
+            const uint32_t pix = m - n * (uint32_t)(p.AH * p.AW);
+            const uint32_t a = fdiv(pix, p.div_aw);
+            const uint32_t b = pix - a * (uint32_t)p.AW;
+            oy0[g] = m_ok ? (int)a + (py + P) / S : -(1 << 20);
+            ox0[g] = (int)b + (px + P) / S;
+            // addresses (oy0 - (TY-1), ox0 - (TX-1)) through the shifted base; the tap's scalar offset walks forward
+            vbase[g] = (n * (uint32_t)(s.K * OHW) + (uint32_t)(((int)a + (py + P) / S) * OW + ox0[g])) * 4u;
+            veff[g] = OOB;
+        }
+    }
+    __device__ __forceinline__ void issue_piece(int kc, float* stage, int p, bool live) {
+        if (p == 0) {
+            int tap = last_tap;
+            if (kc == last_kc + 1 && last_kc >= 0) {
+                kob += BK;
+                if (kob >= kblocks * BK) { kob = 0; ++tap; }
+            } else {
+                tap = kc / kblocks;
+                kob = (kc - tap * kblocks) * BK;
+            }
+            last_kc = kc;
+            if (tap != last_tap) {
+                last_tap = tap;
+                const int ty = tap / nx_p, tx = tap - ty * nx_p;
+                tap_soff = (uint32_t)((TY - 1 - ty) * OW + (TX - 1 - tx)) * 4u;
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    veff[g] = ((unsigned)(oy0[g] - ty) < (unsigned)OH && (unsigned)(ox0[g] - tx) < (unsigned)OW) ? vbase[g] : OOB;
+            }
+        }
+        const int row = wave * 4 + p / G, g = p % G;
+        const int ko = kob + row;
+        bload_lds4(rsrc, stage + row * LD + g * 64, veff[g],
+                   (live && ko < K) ? (uint32_t)ko * (uint32_t)OHW * 4u + tap_soff : SOFF_OOB);
+    }
+};
+
 #ifdef GZ2_STAMPS       // diagnostic builds only (tools/igemm2_conv_probe.hip, tools/conv_bench2.py --stamps)
 __device__ unsigned long long gz2_stamps[8192 * 8];
 #define GZ2_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -2536,17 +2604,25 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
             while (__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(64);
         }
     }
-    if (!gm.no_swizzle) {
-        const int q = nwg >> 3, rr = nwg & 7, x = bid & 7, i = bid >> 3;
-        bid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + i;
+    int y;
+    if (gm.var_chunks) {      // phases of unequal length: longest first over all tiles (see igemm_kernel)
+        const int tiles = gm.tiles_m * gm.tiles_n;
+        y = gm.phase_order[bid / tiles];
+        bid %= tiles;
+    } else {
+        if (!gm.no_swizzle) {
+            const int q = nwg >> 3, rr = nwg & 7, x = bid & 7, i = bid >> 3;
+            bid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + i;
+        }
+        y = bid % gm.ny;
+        bid /= gm.ny;
     }
-    const int y = bid % gm.ny;
-    bid /= gm.ny;
     const int tile_n = bid % gm.tiles_n;
     const int tile_m = bid / gm.tiles_n;
     const int z = blockIdx.z;
     const int kc0 = z * gm.chunks_per_split;
-    const int kc1 = min(gm.chunks, kc0 + gm.chunks_per_split);
+    const int kc1 = min(gm.var_chunks ? gm.phase_chunks[y] : gm.chunks, kc0 + gm.chunks_per_split);
+    if (gm.slab && gm.var_chunks && kc0 >= kc1) return;      // past this phase's last slab (uniform per workgroup)
 
     AL al;
     BL bl;
@@ -2745,7 +2821,7 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
 #endif
     if (gm.slab)
         store_slab<Epi::SWAP, TM, TN>(gm, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32, lane,
-                                      y * (int)gridDim.z + z);
+                                      gm.var_chunks ? gm.phase_slab0[y] + z : y * (int)gridDim.z + z);
     else
         Epi::template store<TM, TN>(pe, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32,
                                     lane, y, z);
@@ -3215,15 +3291,29 @@ constexpr size_t igemm2_lds_bytes() {
     return (size_t)(STAGES2 * (AL::ROWS * AL::LD + igemm2_a_extra<AL>() + BL::ROWS * BL::LD) + 32) * 4;
 }
 
-// same contract as launch_igemm (phases of equal length only)
+// same contract as launch_igemm
 template <class Cfg, class AL, class BL, class Epi>
 inline int launch_igemm2(const typename AL::Params& pa, const typename BL::Params& pb, const typename Epi::Params& pe,
-                         int M, int N, int K, int ny, int splits, hipStream_t stream, float* slab = nullptr) {
+                         int M, int N, int K, int ny, int splits, hipStream_t stream, float* slab = nullptr,
+                         const int* phase_chunks = nullptr) {
     static_assert(Epi::SWAP, "transposed accumulators (lanes along m)");
     GridMap gm;
     static int no_swz = getenv("GZ_NO_XCD_SWIZZLE") ? 1 : 0;
     gm.no_swizzle = no_swz;
     gm.var_chunks = 0;
+    if (phase_chunks && ny <= 8) {
+        gm.var_chunks = 1;
+        for (int i = 0; i < ny; ++i) {
+            gm.phase_chunks[i] = phase_chunks[i];
+            gm.phase_order[i] = i;
+        }
+        for (int i = 1; i < ny; ++i)          // insertion sort, stable, descending
+            for (int j = i; j > 0 && gm.phase_chunks[gm.phase_order[j]] > gm.phase_chunks[gm.phase_order[j - 1]]; --j) {
+                int t = gm.phase_order[j];
+                gm.phase_order[j] = gm.phase_order[j - 1];
+                gm.phase_order[j - 1] = t;
+            }
+    }
     gm.slab = nullptr;
     gm.slab_m = M;
     gm.slab_n = N;
@@ -3246,8 +3336,13 @@ inline int launch_igemm2(const typename AL::Params& pa, const typename BL::Param
                      ? (int)((long long)gm.chunks * 8 * Cfg::TM * Cfg::TN * 64 * 2 * stagger_pct / 100) : 0;
     if (slab && nz > 1) gm.slab = slab;
     SlabMap sm;
-    sm.var = 0;
-    for (int i = 0; i < 8; ++i) gm.phase_nz[i] = sm.nz[i] = gm.phase_slab0[i] = sm.slab0[i] = 0;
+    sm.var = gm.slab && gm.var_chunks;
+    for (int i = 0, at = 0; i < 8; ++i) {
+        int n = (sm.var && i < ny) ? (gm.phase_chunks[i] + gm.chunks_per_split - 1) / gm.chunks_per_split : 0;
+        gm.phase_nz[i] = sm.nz[i] = n;
+        gm.phase_slab0[i] = sm.slab0[i] = at;
+        at += n;
+    }
     static const size_t lds_extra = getenv("GZ_IGEMM2_LDS") ? (size_t)atoi(getenv("GZ_IGEMM2_LDS")) : 0;   // experiment:
     const size_t lds = igemm2_lds_bytes<Cfg, AL, BL>() + lds_extra;             // throttles workgroups per CU
     auto kern = igemm2_kernel<Cfg, AL, BL, Epi>;

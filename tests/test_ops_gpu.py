@@ -1061,3 +1061,33 @@ def test_igemm2_tap_major_forward_matches_torch(case):
     assert err < TOL, (err, F._TILES[tile])
     if case[:4] in ((64, 64, 64, 128), (64, 128, 32, 256), (64, 256, 16, 512), (70, 64, 64, 128)):
         assert F._TILES[tile] == "256x128", F._TILES[tile]
+
+
+IGEMM2_TAP_DG_CASES = [
+    # N, C (image side), H (image side), K (feature side): dx[N, C, H, H] from dy[N, K, H/2, H/2], 5x5 s2 p2
+    (64, 128, 32, 256),       # HoloGAN EXT-128 D.block2 backward-data: 64 tiles x 4 phases, 144 / 96 / 96 / 64 chunks, 3 splits
+    (64, 256, 16, 512),       # D.block3: 16 x 2 tiles, 288 / 192 / 192 / 128 chunks, 6 splits
+    (33, 160, 32, 200),       # ragged: 8448 pixels per phase, 160 = 128 + 32 columns, 200 feature channels (208 padded)
+    (256, 128, 32, 128),      # many tiles: unsplit or barely split
+]
+
+
+@pytest.mark.parametrize("case", IGEMM2_TAP_DG_CASES)
+def test_igemm2_tap_major_transposed_conv_matches_torch(case):
+    """Backward-data of the 5x5 s2 p2 convolution (phases of 9 / 6 / 6 / 4 taps) on the igemm2 skeleton: gather loader,
+    per-phase chunk counts, reduction cut into equal pieces across the phases (slabs + finish kernel)."""
+    F = _F()
+    from lightning_gan_zoo_amd._lib import lib
+    N, C, H, K = case
+    geom = F.Geom(5, 5, 2, 2)
+    tile = lib.gz_conv2d_tile(1, N, C, H, H, K, H // 2, H // 2, 5, 5, 2)
+    assert F._TILES[tile] == "256x128", F._TILES[tile]
+    gy = rnd(N, K, H // 2, H // 2, seed=61)
+    w = rnd(K, C, 5, 5, seed=62, scale=0.05)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = torch.nn.grad.conv2d_input((N, C, H, H), w, gy, stride=2, padding=2)
+    out = F._conv_dgrad_raw(gy.cuda(), w.cuda(), None, geom, (H, H), F.ACT_NONE, 0.0)
+    assert out.shape == ref.shape
+    err = rel(out, ref)
+    assert err < TOL, err
+    assert torch.equal(out, F._conv_dgrad_raw(gy.cuda(), w.cuda(), None, geom, (H, H), F.ACT_NONE, 0.0))

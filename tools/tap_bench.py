@@ -42,4 +42,10 @@ for name, C, H, K, k, st, pd in layers:
     fl = 2.0 * bs * OH * OH * K * C * k * k
     t = timeit(lambda: F._conv_fwd_raw(x, w, None, geom, 0, 0.))
     lab = F._TILES[lib.gz_conv2d_tile(0, bs, C, H, H, K, OH, OH, k, k, st)]
-    print("%-16s C%4d H%3d K%4d  %6.1f GF  %-8s %7.3f ms %6.1f TF" % (name, C, H, K, fl / 1e9, lab, t, fl / t / 1e9))
+    line = "%-16s C%4d H%3d K%4d  %6.1f GF  F %-8s %7.3f ms %6.1f TF" % (name, C, H, K, fl / 1e9, lab, t, fl / t / 1e9)
+    if st == 2:
+        gy = torch.randn(bs, K, OH, OH, device="cuda")
+        t = timeit(lambda: F._conv_dgrad_raw(gy, w, None, geom, (H, H), 0, 0.))
+        lab = F._TILES[lib.gz_conv2d_tile(1, bs, C, H, H, K, OH, OH, k, k, st)]
+        line += " | Dg %-8s %7.3f ms %6.1f TF" % (lab, t, fl / t / 1e9)
+    print(line)
