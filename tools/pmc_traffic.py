@@ -21,6 +21,9 @@ def label_of(name):
     if not m:
         # round 3: igemm2_kernel / igemm2r_kernel<gz::TileCfg2<WM, WN, TN, OCC>, loader...> (TM = 4)
         m2 = re.search(r"igemm2r?_kernel<gz::TileCfg2<(\d+), (\d+), (\d+), (\d+)>, gz::(\w+)<", name)
+        mw = re.search(r"igemm2w_kernel<gz::TileCfg2<(\d+), (\d+), (\d+), (\d+)>, (\d+),", name)
+        if mw:        # weight gradient with both operands by LDS-DMA: no loader types in the name
+            return "igemm<Wg,%dx%d>" % (int(mw.group(1)) * 128, int(mw.group(2)) * int(mw.group(3)) * 32)
         if not m2:
             return None
         wm, wn, tn = (int(m2.group(i)) for i in range(1, 4))
@@ -28,7 +31,7 @@ def label_of(name):
     else:
         wm, wn, tm, tn = (int(m.group(i)) for i in range(1, 5))
         loader = m.group(5)
-    if loader.startswith("ConvFwd"):
+    if loader.startswith("ConvFwd") or loader.startswith("ConvTap"):
         op = "F"
     elif loader.startswith("ConvDg"):
         op = "Dg"
