@@ -486,7 +486,8 @@ static SplitPlan fwd2_plan(const ConvShape& s) {
     if (off || s.K < 128) return SplitPlan{T64x64, 1};
     const long long tiles = ((M + 255) / 256) * ((s.K + 127) / 128);
     const int chunks = s.C;
-    if (tiles >= 64 && chunks >= 64) {
+    static const int min_tiles = getenv("GZ_FWD2_MIN_TILES") ? atoi(getenv("GZ_FWD2_MIN_TILES")) : 16;
+    if (tiles >= min_tiles && chunks >= 64) {
         int splits = (int)((256 + tiles - 1) / tiles);
         while (splits > 1 && chunks / splits < 32) --splits;
         if (splits > 1 && tiles * splits >= 256) return SplitPlan{T256x128, splits};
@@ -928,7 +929,8 @@ static SplitPlan dgrad_plan(const ConvShape& s) {
         static const bool off = getenv("GZ_NO_IGEMM2") != nullptr;
         const long long tiles = ((M + 255) / 256) * ((s.C + 127) / 128) * 4;
         const int chunks = s.K / 4;
-        if (!off && s.C >= 128 && tiles >= 64 && tiles < 256 && chunks >= 64) {
+        static const int min_tiles = getenv("GZ_DG2_MIN_TILES") ? atoi(getenv("GZ_DG2_MIN_TILES")) : 64;
+        if (!off && s.C >= 128 && tiles >= min_tiles && tiles < 256 && chunks >= 64) {
             int splits = (int)((256 + tiles - 1) / tiles);
             while (splits > 1 && chunks / splits < 32) --splits;
             if (splits > 1 && tiles * splits >= 256) return SplitPlan{T256x128, splits};
@@ -1352,7 +1354,13 @@ static int wgrad2_splits(const ConvShape& s) {
     const int chunks = (s.N * s.OH * s.OW + BK - 1) / BK;
     int splits = (int)((512 + tiles - 1) / tiles);
     if (splits < 1) splits = 1;
-    while (splits > 1 && chunks / splits < 64) --splits;       // >= 64 chunks per workgroup
+    // >= 64 chunks per workgroup for the register-staged kernel; the LDS-DMA kernel's chunks cost nothing but their
+    // MFMAs, so 32 are enough there (bs 128: D.block1-3's weight gradients move from the 128x128 kernel onto it)
+    static const int min_chunks_env = getenv("GZ_WG2_MIN_CHUNKS") ? atoi(getenv("GZ_WG2_MIN_CHUNKS")) : 0;
+    const bool dma = G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1 && s.H == 2 * s.OH && s.W == 2 * s.OW &&
+                     (s.OW == 4 || s.OW == 8 || s.OW % 16 == 0) && !getenv("GZ_NO_IGEMM2W");
+    const int min_chunks = min_chunks_env > 0 ? min_chunks_env : (dma ? 32 : 64);
+    while (splits > 1 && chunks / splits < min_chunks) --splits;
     return tiles * splits >= 256 ? splits : 0;
 }
 
