@@ -414,7 +414,8 @@ static int run_fwdtap2(const float* x, const float* wp, const float* bias, float
     EpiNCHWB::Params pe{y, M, s.K, s.OH * s.OW, make_fastdiv(s.OH * s.OW), bias, act, slope,
                         reinterpret_cast<f32x2*>(stats)};
     const int Kt = G::kh * G::kw * round_bk(s.C);
-    typename BL::Params pb{wp, Kt, round4(s.K), round4(s.K), 0};
+    // (1x1: the plain [C][K] weight image IS the tap-major one; it has no padding rows, the descriptor ends at row C)
+    typename BL::Params pb{wp, G::kh * G::kw == 1 ? s.C : Kt, round4(s.K), round4(s.K), 0};
     return launch_igemm2<Cfg, AL, BL, EpiNCHWB>(pa, pb, pe, M, s.K, Kt, 1, splits, st, slab);
 }
 
@@ -460,8 +461,9 @@ static TileId pick_tile_fwd(long long M, int K, int OW, int kh, int kw, int stri
 template <class G>
 static SplitPlan fwdtap2_plan(const ConvShape& s) {
     static const bool off = getenv("GZ_NO_IGEMM2") != nullptr || getenv("GZ_NO_IGEMM2_TAP") != nullptr;
-    if constexpr (BK % (G::kh * G::kw) == 0) return SplitPlan{T64x64, 1};
-    if (off || !fwd_tap_major(s.C, G::kh, G::kw) || s.K < 128 || (s.K & 3)) return SplitPlan{T64x64, 1};
+    if constexpr (BK % (G::kh * G::kw) == 0 && G::kh * G::kw != 1) return SplitPlan{T64x64, 1};
+    if (off || !(G::kh * G::kw == 1 ? s.C >= BK : fwd_tap_major(s.C, G::kh, G::kw)) || s.K < 128 || (s.K & 3))
+        return SplitPlan{T64x64, 1};
     const long long M = (long long)s.N * s.OH * s.OW;
     const long long tiles = ((M + 255) / 256) * ((s.K + 127) / 128);
     const int chunks = G::kh * G::kw * round_bk(s.C) / BK;
@@ -866,7 +868,9 @@ static int run_dgradtap2(const float* y, const float* wp, const float* bias, flo
     const int kpad = round_bk(s.K);
     const int Kt = AL::TY * AL::TX * kpad;
     const int ldc = round4(s.C);
-    typename BL::Params pb{wp, Kt, ldc, ldc, (long long)Kt * ldc};
+    // (1x1: the plain [K][C] image, without padding rows)
+    const int Kb = G::kh * G::kw == 1 ? s.K : Kt;
+    typename BL::Params pb{wp, Kb, ldc, ldc, (long long)Kb * ldc};
     const int M = s.N * AH * AW;
     typename Epi::Params pe{x, M, s.C, s.H, s.W, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW), bias, act, slope,
                             nullptr, 0};
@@ -880,8 +884,11 @@ template <class G>
 static SplitPlan dgradtap2_plan(const ConvShape& s) {
     static const bool off = getenv("GZ_NO_IGEMM2") != nullptr || getenv("GZ_NO_IGEMM2_TAP") != nullptr;
     constexpr int TY = (G::kh + G::s - 1) / G::s, TX = (G::kw + G::s - 1) / G::s;
-    if constexpr (G::s * G::s > 8 || (G::kh % G::s == 0 && G::kw % G::s == 0)) return SplitPlan{T64x64, 1};
-    if (off || !dgrad_tap_major(s.K, G::kh, G::kw, G::s) || s.C < 128 || (s.C & 3) || s.H % G::s || s.W % G::s)
+    constexpr bool one_by_one = G::kh * G::kw == 1;
+    if constexpr (G::s * G::s > 8 || (!one_by_one && G::kh % G::s == 0 && G::kw % G::s == 0 && BK % (TY * TX) == 0))
+        return SplitPlan{T64x64, 1};        // (k4 s2 p1 has its own loaders)
+    if (off || !(one_by_one ? s.K >= BK : dgrad_tap_major(s.K, G::kh, G::kw, G::s)) || s.C < 128 || (s.C & 3) ||
+        s.H % G::s || s.W % G::s)
         return SplitPlan{T64x64, 1};
     const long long M = (long long)s.N * (s.H / G::s) * (s.W / G::s);
     const long long tiles = ((M + 255) / 256) * ((s.C + 127) / 128);
@@ -890,6 +897,14 @@ static SplitPlan dgradtap2_plan(const ConvShape& s) {
     for (int ph = 0; ph < G::s * G::s; ++ph)
         total += (long long)dg_taps(G::kh, G::s, G::p, ph / G::s) * dg_taps(G::kw, G::s, G::p, ph % G::s) * kblocks;
     const int maxchunks = TY * TX * kblocks;
+    // one phase (stride 1): nothing to balance -- split only when the tiles alone do not fill the chip
+    if (G::s == 1) {
+        if (tiles >= 224 && maxchunks >= 8) return SplitPlan{T256x128, 1};
+        if (tiles * total < 512LL * 32) return SplitPlan{T64x64, 1};
+        int splits = (int)((256 + tiles - 1) / tiles);
+        while (splits > 1 && maxchunks / splits < 64) --splits;
+        return (splits > 1 && tiles * splits >= 192) ? SplitPlan{T256x128, splits} : SplitPlan{T64x64, 1};
+    }
     if (tiles * total < 512LL * 32) return SplitPlan{T64x64, 1};       // too little work for the big tile
     // ~384 workgroups of <= 96 chunks (measured on HoloGAN EXT-128's blocks, TFLOP/s of D.block2 / D.block3:
     // 256 workgroups 84 / 67, 384: 99 / 99, 512: 99 / 89, 768: 90 / 86; the round-2 kernels: 89 / 74)
@@ -1855,9 +1870,9 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
             const SplitPlan p2 = fwd2_plan<G4421>(s);
             if (p2.tile == T256x256 || p2.tile == T256x128) return p2.tile;
         }
-        if ((KH == 5 && KW == 5 && S == 2) || (KH == 3 && KW == 3 && S == 1)) {
+        if ((KH == 5 && KW == 5 && S == 2) || (KH == 3 && KW == 3 && S == 1) || (KH == 1 && KW == 1 && S == 1)) {
             ConvShape s{N, C, H, W, K, OH, OW};
-            const SplitPlan p2 = KH == 5 ? fwdtap2_plan<G5522>(s) : fwdtap2_plan<G3311>(s);
+            const SplitPlan p2 = KH == 5 ? fwdtap2_plan<G5522>(s) : KH == 3 ? fwdtap2_plan<G3311>(s) : fwdtap2_plan<G1110>(s);
             if (p2.tile == T256x128) return p2.tile;
         }
         return pick_tile_fwd((long long)N * OH * OW, K, OW, KH, KW, S, C * KH * KW);
@@ -1870,9 +1885,10 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
                 if (is_tile2(sp.tile)) return sp.tile;
             }
         }
-        if (KH == 5 && KW == 5 && S == 2) {
+        if ((KH == 5 && KW == 5 && S == 2) || (KH == 3 && KW == 3 && S == 1) || (KH == 1 && KW == 1 && S == 1)) {
             ConvShape s{N, C, H, W, K, OH, OW};
-            if (dgradtap2_plan<G5522>(s).tile == T256x128) return T256x128;
+            const SplitPlan pt = KH == 5 ? dgradtap2_plan<G5522>(s) : KH == 3 ? dgradtap2_plan<G3311>(s) : dgradtap2_plan<G1110>(s);
+            if (pt.tile == T256x128) return T256x128;
         }
         return pick_tile((long long)N * (H / S) * (W / S), C, S * S, K * ((KH + S - 1) / S) * ((KW + S - 1) / S));
     }

@@ -1035,6 +1035,8 @@ IGEMM2_TAP_CASES = [
     (64, 256, 16, 512, 5, 2, 2),      # D.block3: 64 tiles, 400 chunks -> 4 splits
     (64, 72, 32, 160, 3, 1, 1),       # 3x3 s1 p1, 72 channels (last chunk of a tap: 8 live rows), 160 = 128 + 32 columns
     (67, 72, 32, 160, 3, 1, 1),       # the same with a ragged last pixel tile (68608 pixels = 268 tiles)
+    (64, 1024, 16, 1024, 1, 1, 0),    # HoloGAN's 1x1 projection (its input gradient): one tap, 64 chunks
+    (70, 200, 32, 160, 1, 1, 0),      # 1x1 with 200 channels: 13 chunks, the last one 8 live rows; weight image without padding rows
     (70, 64, 64, 128, 5, 2, 2),       # 71680 pixels = 280 tiles: more than one workgroup per CU for some
     (33, 128, 32, 256, 5, 2, 2),      # 8448 pixels = 33 x 2 tiles, 200 chunks -> 3 splits of 67, ragged batch
 ]
@@ -1059,7 +1061,8 @@ def test_igemm2_tap_major_forward_matches_torch(case):
     assert out.shape == ref.shape
     err = rel(out, ref)
     assert err < TOL, (err, F._TILES[tile])
-    if case[:4] in ((64, 64, 64, 128), (64, 128, 32, 256), (64, 256, 16, 512), (70, 64, 64, 128)):
+    if case[:4] in ((64, 64, 64, 128), (64, 128, 32, 256), (64, 256, 16, 512), (70, 64, 64, 128), (64, 1024, 16, 1024),
+                    (70, 200, 32, 160)):
         assert F._TILES[tile] == "256x128", F._TILES[tile]
 
 
@@ -1091,3 +1094,32 @@ def test_igemm2_tap_major_transposed_conv_matches_torch(case):
     err = rel(out, ref)
     assert err < TOL, err
     assert torch.equal(out, F._conv_dgrad_raw(gy.cuda(), w.cuda(), None, geom, (H, H), F.ACT_NONE, 0.0))
+
+
+IGEMM2_TAP_DG_S1_CASES = [
+    # N, C (image side), H, K (feature side), k, pad: stride-1 input gradients (one phase)
+    (64, 256, 32, 256, 3, 1),         # residual-block 3x3: 256 x 2 tiles, 144 chunks, unsplit
+    (16, 128, 64, 136, 3, 1),         # 136 feature channels (144 padded), 256 tiles
+    (8, 256, 32, 512, 3, 1),          # 32 x 2 tiles, 288 chunks -> 4 splits
+    (64, 1024, 16, 1024, 1, 0),       # HoloGAN's 1x1 transposed convolution (forward)
+    (70, 160, 32, 200, 1, 0),         # 1x1, ragged everything
+]
+
+
+@pytest.mark.parametrize("case", IGEMM2_TAP_DG_S1_CASES)
+def test_igemm2_gather_stride1_input_gradient_matches_torch(case):
+    F = _F()
+    from lightning_gan_zoo_amd._lib import lib
+    N, C, H, K, k, pd = case
+    geom = F.Geom(k, k, 1, pd)
+    tile = lib.gz_conv2d_tile(1, N, C, H, H, K, H, H, k, k, 1)
+    assert F._TILES[tile] == "256x128", F._TILES[tile]
+    gy = rnd(N, K, H, H, seed=71)
+    w = rnd(K, C, k, k, seed=72, scale=0.05)
+    b = rnd(C, seed=73)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = torch.relu(torch.nn.grad.conv2d_input((N, C, H, H), w, gy, stride=1, padding=pd) + b.view(1, -1, 1, 1))
+    out = F._conv_dgrad_raw(gy.cuda(), w.cuda(), b.cuda(), geom, (H, H), F.ACT_RELU, 0.0)
+    assert out.shape == ref.shape
+    err = rel(out, ref)
+    assert err < TOL, err

@@ -32,7 +32,8 @@ def timeit(fn, n=30, warm_s=0.3):
 
 layers = [("holo128 D.b1", 64, 64, 128, 5, 2, 2), ("holo128 D.b2", 128, 32, 256, 5, 2, 2), ("holo128 D.b3", 256, 16, 512, 5, 2, 2),
           ("holo64 D.b1", 64, 32, 128, 5, 2, 2), ("holo64 D.b2", 128, 16, 256, 5, 2, 2), ("holo64 D.b3", 256, 8, 512, 5, 2, 2),
-          ("res 3x3 256@32", 256, 32, 256, 3, 1, 1), ("res 3x3 128@64", 128, 64, 128, 3, 1, 1)]
+          ("res 3x3 256@32", 256, 32, 256, 3, 1, 1), ("res 3x3 128@64", 128, 64, 128, 3, 1, 1),
+          ("holo 1x1 1024@16", 1024, 16, 1024, 1, 1, 0)]
 print("bs", bs, "GZ_NO_IGEMM2_TAP", os.environ.get("GZ_NO_IGEMM2_TAP"))
 for name, C, H, K, k, st, pd in layers:
     geom = F.Geom(k, k, st, pd)
@@ -43,7 +44,7 @@ for name, C, H, K, k, st, pd in layers:
     t = timeit(lambda: F._conv_fwd_raw(x, w, None, geom, 0, 0.))
     lab = F._TILES[lib.gz_conv2d_tile(0, bs, C, H, H, K, OH, OH, k, k, st)]
     line = "%-16s C%4d H%3d K%4d  %6.1f GF  F %-8s %7.3f ms %6.1f TF" % (name, C, H, K, fl / 1e9, lab, t, fl / t / 1e9)
-    if st == 2:
+    if True:
         gy = torch.randn(bs, K, OH, OH, device="cuda")
         t = timeit(lambda: F._conv_dgrad_raw(gy, w, None, geom, (H, H), 0, 0.))
         lab = F._TILES[lib.gz_conv2d_tile(1, bs, C, H, H, K, OH, OH, k, k, st)]
