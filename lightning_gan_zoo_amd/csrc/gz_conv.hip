@@ -1359,6 +1359,12 @@ using Cfg2Wg = TileCfg2<2, 2, 2, 2>;
 static bool wgrad2_narrow(const ConvShape& s) { return s.K < 256; }
 
 template <class G>
+static constexpr bool wgrad2w_geom() {
+    return (G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1) || (G::kh == 5 && G::kw == 5 && G::s == 2 && G::p == 2) ||
+           (G::kh == 3 && G::kw == 3 && G::s == 1 && G::p == 1);
+}
+
+template <class G>
 static int wgrad2_splits(const ConvShape& s) {
     static const bool off = getenv("GZ_NO_IGEMM2") != nullptr || getenv("GZ_NO_IGEMM2_WG") != nullptr;
     WgRowGeom rg;
@@ -1367,12 +1373,14 @@ static int wgrad2_splits(const ConvShape& s) {
     const long long tiles = wgrad2_narrow(s) ? (long long)((s.K + 127) / 128) * ((NTOT + 255) / 256)
                                              : (long long)((s.K + 255) / 256) * ((NTOT + 127) / 128);
     const int chunks = (s.N * s.OH * s.OW + BK - 1) / BK;
-    int splits = (int)((512 + tiles - 1) / tiles);
+    // at most ONE round of the chip's 512 workgroup slots (two per CU): 18 tiles x 29 splits = 522 workgroups took two
+    // rounds (3x3 s1 p1 256@32: 96 TFLOP/s; 28 splits: one round)
+    int splits = (int)(512 / tiles);
     if (splits < 1) splits = 1;
     // >= 64 chunks per workgroup for the register-staged kernel; the LDS-DMA kernel's chunks cost nothing but their
     // MFMAs, so 32 are enough there (bs 128: D.block1-3's weight gradients move from the 128x128 kernel onto it)
     static const int min_chunks_env = getenv("GZ_WG2_MIN_CHUNKS") ? atoi(getenv("GZ_WG2_MIN_CHUNKS")) : 0;
-    const bool dma = G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1 && s.H == 2 * s.OH && s.W == 2 * s.OW &&
+    const bool dma = wgrad2w_geom<G>() && s.H == G::s * s.OH && s.W == G::s * s.OW &&
                      (s.OW == 4 || s.OW == 8 || s.OW % 16 == 0) && !getenv("GZ_NO_IGEMM2W");
     const int min_chunks = min_chunks_env > 0 ? min_chunks_env : (dma ? 32 : 64);
     while (splits > 1 && chunks / splits < min_chunks) --splits;
@@ -1419,19 +1427,27 @@ static int run_wgrad2(const float* x, const float* y, float* dw, float* ws, size
 template <class G>
 static int wgrad2w_cw(const float* x, const float* y, const ConvShape& s) {
     static const bool off = getenv("GZ_NO_IGEMM2W") != nullptr;
-    if (off || G::kh != 4 || G::kw != 4 || G::s != 2 || G::p != 1) return 0;
-    if (s.H != 2 * s.OH || s.W != 2 * s.OW) return 0;
+    static const bool off_g = getenv("GZ_NO_IGEMM2WG") != nullptr;        // the generic-geometry image only
+    if (off || !wgrad2w_geom<G>()) return 0;
+    if (off_g && !(G::kh == 4 && G::kw == 4)) return 0;
+    if (s.H != G::s * s.OH || s.W != G::s * s.OW || (s.W & 3)) return 0;
     if ((((uintptr_t)x) | ((uintptr_t)y)) & 15) return 0;
     const int cw = s.OW == 4 ? 4 : s.OW == 8 ? 8 : (s.OW % 16 == 0 ? 16 : 0);
     if (!cw || s.OH % (16 / cw)) return 0;
     return cw;
 }
 
-template <class Cfg, int CW>
+template <class G, int BN, int CW>
+struct wg2w_image {
+    using type = std::conditional_t<G::kh == 4 && G::kw == 4, WgImgB2<BN, CW>, WgImgBG<BN, CW, G::kh, G::kw, G::s, G::p>>;
+};
+
+template <class G, class Cfg, int CW>
 static int run_wgrad2w(const float* x, const float* y, float* dw, float* ws, size_t ws_bytes, const ConvShape& s,
                        int splits, hipStream_t st) {
+    using BL = typename wg2w_image<G, Cfg::BN, CW>::type;
     const int KTOT = s.N * s.OH * s.OW;
-    const int NTOT = s.C * 16;
+    const int NTOT = s.C * G::kh * G::kw;
     Wg2Params p{x, y, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW)};
     const long long count = (long long)s.K * NTOT;
     if (splits > 1) {
@@ -1444,7 +1460,7 @@ static int run_wgrad2w(const float* x, const float* y, float* dw, float* ws, siz
     const int nz = (chunks + cps - 1) / cps;
     float* out = nz > 1 ? ws : dw;
     EpiRowMajorB::Params pe{out, s.K, NTOT, NTOT, count, nullptr, ACT_NONE, 0.f};
-    int rc = launch_igemm2w<Cfg, CW, EpiRowMajorB>(p, pe, s.K, NTOT, KTOT, splits, st);
+    int rc = launch_igemm2w<Cfg, BL, EpiRowMajorB>(p, pe, s.K, NTOT, KTOT, splits, st);
     if (rc != GZ_OK) return rc;
     if (nz > 1) {
         if (nz <= 8)
@@ -1458,14 +1474,17 @@ static int run_wgrad2w(const float* x, const float* y, float* dw, float* ws, siz
     return rc;
 }
 
-template <class Cfg>
+template <class G, class Cfg>
 static int run_wgrad2w_cw(int cw, const float* x, const float* y, float* dw, float* ws, size_t ws_bytes,
                           const ConvShape& s, int splits, hipStream_t st) {
-    switch (cw) {
-        case 4: return run_wgrad2w<Cfg, 4>(x, y, dw, ws, ws_bytes, s, splits, st);
-        case 8: return run_wgrad2w<Cfg, 8>(x, y, dw, ws, ws_bytes, s, splits, st);
-        default: return run_wgrad2w<Cfg, 16>(x, y, dw, ws, ws_bytes, s, splits, st);
+    if constexpr (wgrad2w_geom<G>()) {
+        switch (cw) {
+            case 4: return run_wgrad2w<G, Cfg, 4>(x, y, dw, ws, ws_bytes, s, splits, st);
+            case 8: return run_wgrad2w<G, Cfg, 8>(x, y, dw, ws, ws_bytes, s, splits, st);
+            default: return run_wgrad2w<G, Cfg, 16>(x, y, dw, ws, ws_bytes, s, splits, st);
+        }
     }
+    return GZ_ERR_UNSUPPORTED;
 }
 
 template <class G, class Cfg>
@@ -1500,10 +1519,11 @@ static int dispatch_wgrad(const float* x, const float* y, float* dw, float* ws, 
         if (splits > 0) {
             const int cw = wgrad2w_cw<G>(x, y, s);
             if (cw)
-                return wgrad2_narrow(s) ? run_wgrad2w_cw<Cfg128x256>(cw, x, y, dw, ws, ws_bytes, s, splits, st)
-                                        : run_wgrad2w_cw<Cfg2Wg>(cw, x, y, dw, ws, ws_bytes, s, splits, st);
-            return wgrad2_narrow(s) ? run_wgrad2<G, Cfg128x256>(x, y, dw, ws, ws_bytes, s, splits, st)
-                                    : run_wgrad2<G, Cfg2Wg>(x, y, dw, ws, ws_bytes, s, splits, st);
+                return wgrad2_narrow(s) ? run_wgrad2w_cw<G, Cfg128x256>(cw, x, y, dw, ws, ws_bytes, s, splits, st)
+                                        : run_wgrad2w_cw<G, Cfg2Wg>(cw, x, y, dw, ws, ws_bytes, s, splits, st);
+            if constexpr (G::kh == 4 && G::kw == 4)       // unaligned tensors: the register-staged loaders
+                return wgrad2_narrow(s) ? run_wgrad2<G, Cfg128x256>(x, y, dw, ws, ws_bytes, s, splits, st)
+                                        : run_wgrad2<G, Cfg2Wg>(x, y, dw, ws, ws_bytes, s, splits, st);
         }
         t = T128x128;
     }
@@ -1699,8 +1719,10 @@ size_t gz_conv2d_wgrad_workspace_bytes(int N, int C, int H, int W, int K, int OH
     // upper bound over the tile choices: smallest tile count is with 128x128 tiles
     long long tiles = (long long)((K + 127) / 128) * ((C * KH * KW + 127) / 128);
     int splits = wgrad_splits(tiles, chunks);
-    if (KH == 4 && KW == 4) {            // the igemm2 plan (k4 s2 p1) may split further
-        const int s2 = wgrad2_splits<G4421>(s);
+    {                                    // the igemm2 plans may split further
+        const int s2 = (KH == 4 && KW == 4) ? wgrad2_splits<G4421>(s)
+                       : (KH == 5 && KW == 5 && OH * 2 == H) ? wgrad2_splits<G5522>(s)
+                       : (KH == 3 && KW == 3 && OH == H) ? wgrad2_splits<G3311>(s) : 0;
         if (s2 > splits) splits = s2;
     }
     return splits > 1 ? (size_t)splits * count * 4 : 0;
@@ -1897,6 +1919,14 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
     if (KH == 4 && KW == 4 && S == 2 && forced_tile() < 0) {
         ConvShape s{N, C, H, W, K, OH, OW};
         if (wgrad2_splits<G4421>(s) > 0) return wgrad2_narrow(s) ? T128x256 : T256x128;
+    }
+    if (((KH == 5 && KW == 5 && S == 2) || (KH == 3 && KW == 3 && S == 1)) && forced_tile() < 0) {
+        // the LDS-DMA weight gradient with the generic raw-row image (needs H = S * OH, rows of 4 / 8 / 16k pixels)
+        ConvShape s{N, C, H, W, K, OH, OW};
+        const bool shape_ok = H == S * OH && W == S * OW && (W & 3) == 0 && (OW == 4 || OW == 8 || OW % 16 == 0) &&
+                              !getenv("GZ_NO_IGEMM2W") && !getenv("GZ_NO_IGEMM2WG");
+        const int sp = !shape_ok ? 0 : KH == 5 ? wgrad2_splits<G5522>(s) : wgrad2_splits<G3311>(s);
+        if (sp > 0) return wgrad2_narrow(s) ? T128x256 : T256x128;
     }
     if (NTOT <= 32) t = T128x32;
     else if (NTOT <= 64 || K <= 64) t = (K <= 64 ? T64x64 : T128x64);

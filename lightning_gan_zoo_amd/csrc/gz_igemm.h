@@ -3038,10 +3038,15 @@ struct WgImgB2 {
     static constexpr int PIECES = (NCH * CHQ + 255) / 256;                  // per wavefront and chunk
     static constexpr int ELEMS = PIECES * 4 * 256;
     // float offsets of the fragment read of k-step s = 4*g + t, half-wave h: pixel k = 8*g + 4*h + t = (r, x)
-    static constexpr int HOFF = CW == 4 ? 2 * RP : 8, GOFF = CW == 16 ? 16 : CW == 8 ? 2 * RP : 4 * RP;
+    static constexpr int HOFF = CW == 4 ? 2 * RP : 8, GOFF = CW == 16 ? 16 : CW == 8 ? 2 * RP : 4 * RP, TOFF = 2;
+    static constexpr int ROWS_PER_CHUNK = R, TAPS = 16;
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff[PIECES], flags[PIECES];
     int wave;
+    // float offset (inside the B image) of the lane that owns column `col` of the tile: (c, ky, kx) at pixel (0, 0)
+    __device__ __forceinline__ int lane_base(int tile, int col) const {
+        return (col >> 4) * CHP + ((col >> 2) & 3) * RP + (col & 3) + 3;
+    }
     __device__ __forceinline__ void init(const Wg2Params& p, int tile, int tid) {
         const ConvShape& s = p.s;
         // per-lane offsets are relative to the chunk's first input pixel (2*oy0, 2*ox0) and reach one row up and four
@@ -3068,10 +3073,69 @@ struct WgImgB2 {
     }
 };
 
-template <class Cfg, int CW, class Epi>
+// The same raw-row image for any geometry with W = S * OW, H = S * OH (5x5 s2 p2, 3x3 s1 p1): S * (R - 1) + KH rows per
+// channel, the column origin LP = P rounded up to a quad left of the chunk's first input column.  A 32-column block is
+// no longer a whole number of channels (25 or 9 taps each), so a lane's (c, ky, kx) differs from block to block: the
+// kernel keeps one base address per block.  Pitches from tools/wg_banks.py: 25 + 7 taps of two channels cannot tile the
+// 32 banks with quad-aligned rows, the best layouts are 2-way on a few lanes.
+template <int BN, int CW, int KH, int KW, int S, int P>
+struct WgImgBG {
+    static_assert(CW == 4 || CW == 8 || CW == 16, "chunk rectangles 4 x 4, 2 x 8, 1 x 16");
+    static constexpr int R = 16 / CW, TAPS = KH * KW;
+    static constexpr int LP = (P + 3) / 4 * 4;
+    static constexpr int IMG_ROWS = S * (R - 1) + KH;
+    static constexpr int RQ0 = (S * (CW - 1) + KW - 1 - P + LP) / 4 + 1;
+    static constexpr bool K5 = KH == 5 && KW == 5 && S == 2 && P == 2, K3 = KH == 3 && KW == 3 && S == 1 && P == 1;
+    static_assert(K5 || K3, "pitches are tabulated per geometry (tools/wg_banks.py)");
+    static constexpr int RQ = RQ0 + ((K5 && CW == 4) ? 1 : 0);
+    static constexpr int RP = RQ * 4;
+    static constexpr int CHP = IMG_ROWS * RP + 4 * (K5 ? (CW == 16 ? 0 : CW == 8 ? 4 : 2) : (CW == 16 ? 3 : CW == 8 ? 1 : 0));
+    static constexpr int CHQ = CHP / 4;
+    static constexpr int NCH = (BN % TAPS == 0) ? BN / TAPS : (BN - 1) / TAPS + 2;      // channels a tile's columns can touch
+    static constexpr int PIECES = (NCH * CHQ + 255) / 256;
+    static constexpr int ELEMS = PIECES * 4 * 256;
+    static constexpr int TOFF = S, HOFF = CW == 4 ? S * RP : 4 * S, GOFF = CW == 16 ? 8 * S : CW == 8 ? S * RP : 2 * S * RP;
+    static constexpr int ROWS_PER_CHUNK = R;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[PIECES], flags[PIECES];
+    int wave;
+    __device__ __forceinline__ int lane_base(int tile, int col) const {
+        const int n = tile * BN + col;
+        const int c = n / TAPS, tap = n - c * TAPS;
+        int cl = c - (tile * BN) / TAPS;
+        if (cl > NCH - 1) cl = NCH - 1;                  // columns past N (masked by the epilogue) stay inside the image
+        const int ky = tap / KW, kx = tap - ky * KW;
+        return cl * CHP + ky * RP + kx - P + LP;
+    }
+    __device__ __forceinline__ void init(const Wg2Params& p, int tile, int tid) {
+        const ConvShape& s = p.s;
+        const int shift = P * s.W + LP;
+        rsrc = make_rsrc(p.x - shift, (uint32_t)(s.N * s.C * s.H * s.W + shift) * 4u);
+        const int lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int c_lo = (tile * BN) / TAPS;
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+            const int gq = (wave * PIECES + j) * 64 + lane;
+            const int cl = gq / CHQ, rem = gq - cl * CHQ;
+            const int row = rem / RQ, q = rem - row * RQ;
+            const int c = c_lo + cl;
+            const int col0 = 4 * q - LP;
+            const bool inside = cl < NCH && c < s.C && row < IMG_ROWS && col0 <= S * CW;
+            voff[j] = inside ? (uint32_t)((c * s.H + row - P) * s.W + col0 + shift) * 4u : OOB;
+            flags[j] = (row < P ? 1u : 0u) | (row >= S * R + P ? 2u : 0u) | (col0 < 0 ? 4u : 0u) |
+                       (col0 >= S * CW ? 8u : 0u);
+        }
+    }
+    __device__ __forceinline__ void issue_piece(float* stage, int j, uint32_t soff, uint32_t cond) {
+        bload_lds16(rsrc, stage + (wave * PIECES + j) * 256, (flags[j] & cond) ? OOB : voff[j], soff);
+    }
+};
+
+template <class Cfg, class BL, class Epi>
 __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2w_kernel(Wg2Params p, typename Epi::Params pe, GridMap gm) {
     using AL = WgDyA2<Cfg::BM>;
-    using BL = WgImgB2<Cfg::BN, CW>;
+    constexpr int CW = 16 / BL::ROWS_PER_CHUNK;
     constexpr int TM = Cfg::TM, TN = Cfg::TN;
     static_assert(TM == 4 && TN == 2 && !Epi::SWAP, "fragment registers of the hand-ordered k-step");
     constexpr int A_ELEMS = AL::ELEMS, B_ELEMS = BL::ELEMS, STAGE = A_ELEMS + B_ELEMS;
@@ -3114,9 +3178,11 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2w_kernel(Wg2Params p, type
 #pragma unroll
     for (int g = 0; g < 2; ++g)
         a_addr[g] = lds0 + (uint32_t)(B_ELEMS + (wm * TM * 32 + l32) * BK + (((2 * g + half) ^ swz) << 2)) * 4u;
-    // B: lane (c, ky, kx) of the 32-column block j: channel wn*4 + 2*j + (l32 >> 4)
-    const uint32_t b_addr = lds0 + (uint32_t)((wn * 4 + (l32 >> 4)) * BL::CHP + ((l32 >> 2) & 3) * BL::RP + (l32 & 3) +
-                                              3 + half * BL::HOFF) * 4u;
+    // B: this lane's (c, ky, kx) in each of its two 32-column blocks
+    uint32_t b_addr[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+        b_addr[j] = lds0 + (uint32_t)(bl.lane_base(tile_n, wn * TN * 32 + j * 32 + l32) + half * BL::HOFF) * 4u;
 
     constexpr int NPA = AL::PIECES, NPB = BL::PIECES, NP = NPA + NPB, STEPS = BK / 2;
     static_assert(NP <= STEPS, "at most one LDS-DMA piece per k-step");
@@ -3130,8 +3196,9 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2w_kernel(Wg2Params p, type
         const uint32_t oy0 = fdiv(rem, p.div_ow);
         const uint32_t ox0 = rem - oy0 * (uint32_t)s.OW;
         soff_a = live ? (n * (uint32_t)(s.K * OHW) + rem) * 4u : SOFF_OOB;
-        soff_b = live ? (n * (uint32_t)(s.C * s.H * s.W) + 2u * oy0 * (uint32_t)s.W + 2u * ox0) * 4u : SOFF_OOB;
-        cond = (oy0 == 0 ? 1u : 0u) | ((int)oy0 + BL::R == s.OH ? 2u : 0u) | (ox0 == 0 ? 4u : 0u) |
+        const uint32_t st = (uint32_t)(s.H / s.OH);           // stride (H = S * OH)
+        soff_b = live ? (n * (uint32_t)(s.C * s.H * s.W) + st * oy0 * (uint32_t)s.W + st * ox0) * 4u : SOFF_OOB;
+        cond = (oy0 == 0 ? 1u : 0u) | ((int)oy0 + BL::ROWS_PER_CHUNK == s.OH ? 2u : 0u) | (ox0 == 0 ? 4u : 0u) |
                ((int)ox0 + CW == s.OW ? 8u : 0u);
     };
     auto issue_piece = [&](int st, int q) {
@@ -3148,9 +3215,9 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2w_kernel(Wg2Params p, type
     };
     auto fetch_b = [&](auto Sc, uint32_t so, float (&bf)[TN]) {
         constexpr int S = decltype(Sc)::value;
-        constexpr int BO = ((S >> 2) * BL::GOFF + 2 * (S & 3)) * 4;
-        bf[0] = lds_rd<BO>(b_addr + so);
-        bf[1] = lds_rd<BO + 2 * BL::CHP * 4>(b_addr + so);
+        constexpr int BO = ((S >> 2) * BL::GOFF + (S & 3) * BL::TOFF) * 4;
+        bf[0] = lds_rd<BO>(b_addr[0] + so);
+        bf[1] = lds_rd<BO>(b_addr[1] + so);
     };
 
     if (kc0 < kc1) {
@@ -3214,12 +3281,12 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2w_kernel(Wg2Params p, type
     Epi::template store<TM, TN>(pe, acc, tile_m * Cfg::BM + wm * TM * 32, tile_n * Cfg::BN + wn * TN * 32, lane, 0, z);
 }
 
-template <class Cfg, int CW>
+template <class Cfg, class BL>
 constexpr size_t igemm2w_lds_bytes() {
-    return (size_t)STAGES2 * (WgDyA2<Cfg::BM>::ELEMS + WgImgB2<Cfg::BN, CW>::ELEMS) * 4;
+    return (size_t)STAGES2 * (WgDyA2<Cfg::BM>::ELEMS + BL::ELEMS) * 4;
 }
 
-template <class Cfg, int CW, class Epi>
+template <class Cfg, class BL, class Epi>
 inline int launch_igemm2w(const Wg2Params& p, const typename Epi::Params& pe, int M, int N, int K, int splits,
                           hipStream_t stream) {
     GridMap gm;
@@ -3240,8 +3307,9 @@ inline int launch_igemm2w(const Wg2Params& p, const typename Epi::Params& pe, in
     gm.stagger = 0;
     for (int i = 0; i < 8; ++i) gm.phase_nz[i] = gm.phase_slab0[i] = 0;
     dim3 grid(gm.tiles_m * gm.tiles_n, 1, nz);
-    constexpr size_t lds = igemm2w_lds_bytes<Cfg, CW>();
-    auto kern = igemm2w_kernel<Cfg, CW, Epi>;
+    constexpr size_t lds = igemm2w_lds_bytes<Cfg, BL>();
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    auto kern = igemm2w_kernel<Cfg, BL, Epi>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -1123,3 +1123,39 @@ def test_igemm2_gather_stride1_input_gradient_matches_torch(case):
     assert out.shape == ref.shape
     err = rel(out, ref)
     assert err < TOL, err
+
+
+IGEMM2WG_CASES = [
+    # N, C, H (image side, square), K, k, stride, pad: the generic raw-row image of the LDS-DMA weight gradient
+    (64, 64, 64, 128, 5, 2, 2),       # HoloGAN EXT-128 D.block1: rows of 32 pixels, the 128 x 256 tile, 1600 columns
+    (64, 128, 32, 256, 5, 2, 2),      # D.block2: rows of 16 pixels, 3200 columns = 25 tiles
+    (64, 256, 16, 512, 5, 2, 2),      # D.block3: rows of 8 pixels (two per chunk)
+    (256, 256, 8, 512, 5, 2, 2),      # rows of 4 pixels (a whole 4 x 4 map per chunk)
+    (128, 52, 32, 256, 5, 2, 2),      # 52 channels: 1300 columns = 10.2 tiles, the last one mostly empty
+    (16, 64, 64, 256, 3, 1, 1),       # 3x3 s1 p1, rows of 64 pixels: interior chunks with both halo quads inside
+    (64, 128, 16, 256, 3, 1, 1),      # 3x3 s1 p1, rows of 16 pixels
+    (1024, 64, 8, 256, 3, 1, 1),      # 3x3 s1 p1, rows of 8 pixels
+    (4096, 64, 4, 256, 3, 1, 1),      # 3x3 s1 p1, 4 x 4 maps
+]
+
+
+@pytest.mark.parametrize("case", IGEMM2WG_CASES)
+def test_igemm2w_generic_geometry_weight_gradient(case):
+    """igemm2w_kernel with WgImgBG (5x5 s2 p2 and 3x3 s1 p1): a 32-column block is not a whole number of channels, top
+    halo of two rows, per-block lane bases -- against torch's CPU operator."""
+    F = _F()
+    from lightning_gan_zoo_amd._lib import lib
+    N, C, H, K, k, st, pd = case
+    geom = F.Geom(k, k, st, pd)
+    OH = (H + 2 * pd - k) // st + 1
+    tile = lib.gz_conv2d_tile(2, N, C, H, H, K, OH, OH, k, k, st)
+    assert F._TILES[tile] == ("256x128" if K >= 256 else "128x256"), F._TILES[tile]
+    x = rnd(N, C, H, H, seed=81)
+    gy = rnd(N, K, OH, OH, seed=82)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = torch.nn.grad.conv2d_weight(x, (K, C, k, k), gy, stride=st, padding=pd)
+    dw = F._conv_wgrad_raw(x.cuda(), gy.cuda(), geom)
+    assert dw.shape == ref.shape
+    err = rel(dw, ref)
+    assert err < TOL, err
+    assert torch.equal(dw, F._conv_wgrad_raw(x.cuda(), gy.cuda(), geom))

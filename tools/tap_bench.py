@@ -49,4 +49,9 @@ for name, C, H, K, k, st, pd in layers:
         t = timeit(lambda: F._conv_dgrad_raw(gy, w, None, geom, (H, H), 0, 0.))
         lab = F._TILES[lib.gz_conv2d_tile(1, bs, C, H, H, K, OH, OH, k, k, st)]
         line += " | Dg %-8s %7.3f ms %6.1f TF" % (lab, t, fl / t / 1e9)
+    if k != 1:
+        gy = torch.randn(bs, K, OH, OH, device="cuda")
+        t = timeit(lambda: F._conv_wgrad_raw(x, gy, geom))
+        lab = F._TILES[lib.gz_conv2d_tile(2, bs, C, H, H, K, OH, OH, k, k, st)]
+        line += " | Wg %-8s %7.3f ms %6.1f TF" % (lab, t, fl / t / 1e9)
     print(line)
