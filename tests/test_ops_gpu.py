@@ -1159,3 +1159,45 @@ def test_igemm2w_generic_geometry_weight_gradient(case):
     err = rel(dw, ref)
     assert err < TOL, err
     assert torch.equal(dw, F._conv_wgrad_raw(x.cuda(), gy.cuda(), geom))
+
+
+def _random_gather_cases(n, seed):
+    """Shapes around the igemm2 plans' boundaries (tile counts near 224 / 256, ragged pixel tiles, channel counts that
+    are not multiples of a chunk, column counts that are not multiples of a tile), seeded."""
+    import random
+    rng = random.Random(seed)
+    out = []
+    while len(out) < n:
+        k, st, pd = rng.choice([(5, 2, 2), (3, 1, 1), (1, 1, 0)])
+        H = rng.choice([8, 16, 32]) * (2 if st == 2 else 1)
+        C = rng.choice([16, 24, 64, 72, 128, 200])
+        K = rng.choice([128, 132, 160, 256, 320])
+        OH = H // st
+        pixels_wanted = rng.choice([150, 223, 224, 257, 300, 520]) * 256 // ((K + 127) // 128)
+        N = max(1, pixels_wanted // (OH * OH) + rng.choice([0, 1]))
+        if N * C * H * H > 40e6 or N * K * OH * OH > 40e6:
+            continue
+        out.append((N, C, H, K, k, st, pd))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_gather_cases(14, 7))
+def test_gather_paths_on_plan_boundaries(case):
+    """Forward, input gradient and weight gradient of the tap-major geometries at seeded shapes around the plans'
+    thresholds: whichever kernel the plan picks, the result matches torch (and repeats bit for bit)."""
+    F = _F()
+    N, C, H, K, k, st, pd = case
+    geom = F.Geom(k, k, st, pd)
+    OH = (H + 2 * pd - k) // st + 1
+    x = rnd(N, C, H, H, seed=91)
+    w = rnd(K, C, k, k, seed=92, scale=0.05)
+    gy = rnd(N, K, OH, OH, seed=93)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    y = F._conv_fwd_raw(x.cuda(), w.cuda(), None, geom, F.ACT_NONE, 0.0)
+    assert rel(y, TF.conv2d(x, w, None, st, pd)) < TOL
+    dx = F._conv_dgrad_raw(gy.cuda(), w.cuda(), None, geom, (H, H), F.ACT_NONE, 0.0)
+    assert rel(dx, torch.nn.grad.conv2d_input((N, C, H, H), w, gy, stride=st, padding=pd)) < TOL
+    dw = F._conv_wgrad_raw(x.cuda(), gy.cuda(), geom)
+    assert rel(dw, torch.nn.grad.conv2d_weight(x, (K, C, k, k), gy, stride=st, padding=pd)) < TOL
+    assert torch.equal(dx, F._conv_dgrad_raw(gy.cuda(), w.cuda(), None, geom, (H, H), F.ACT_NONE, 0.0))
+    assert torch.equal(dw, F._conv_wgrad_raw(x.cuda(), gy.cuda(), geom))
