@@ -652,13 +652,16 @@ __global__ __launch_bounds__(256) void dgrad_smallc_k4s2p1_kernel(const float* _
 // The four wavefronts of a workgroup own the SAME 64 lane positions and every fourth feature channel each (the
 // channel loop is the only long dimension: at bs 128 one wavefront per 64 positions would leave the chip with 512
 // wavefronts); their partial sums meet in LDS and wavefront 0 applies bias / activation and stores.
-template <int C, int KS>      // KS = 4: channel loop split over the workgroup's wavefronts; KS = 1: 256 lane positions
+// KH = 5 (round 3): the 5x5 s2 p2 transposed convolution has the same 3 x 3 neighbourhood (rows a-1 .. a+1) and
+// 9 / 6 / 6 / 4 taps per phase; its weights come in the tap-major pack (pack_dgrad_tap: [phase][tap][ko padded][4]).
+template <int C, int KS, int KH = 4>      // KS = 4: channel loop split over the workgroup's wavefronts; KS = 1: 256 lane positions
 __global__ __launch_bounds__(256) void dgrad_smallc4_k4s2p1_kernel(const float* __restrict__ y,
                                                                    const float* __restrict__ wp,
                                                                    const float* __restrict__ bias,
                                                                    float* __restrict__ x, ConvShape s,
                                                                    FastDiv div_ohw4, FastDiv div_ow4, int act,
                                                                    float slope) {
+    constexpr int P = KH == 4 ? 1 : 2, TMAX = (KH + 1) / 2;
     __shared__ float part[KS > 1 ? 3 : 1][KS > 1 ? 16 * C : 1][64];
     const int OW4 = s.OW >> 2, OHW = s.OH * s.OW;
     const uint32_t M4 = (uint32_t)s.N * s.OH * OW4;
@@ -689,7 +692,9 @@ __global__ __launch_bounds__(256) void dgrad_smallc4_k4s2p1_kernel(const float* 
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[q][i][j][c] = 0.f;
-    const long long phase_stride = (long long)s.K * 16;    // floats: K * 4 taps * ldc(4)
+    const int kpad = round_bk(s.K);
+    const long long phase_stride = KH == 4 ? (long long)s.K * 16             // floats: K * 4 taps * ldc(4)
+                                           : (long long)TMAX * TMAX * kpad * 4;
     for (int ko = wave; ko < s.K; ko += KS) {
         float v[3][6];
         const uint32_t soff = (uint32_t)ko * (uint32_t)OHW * 4u;
@@ -705,18 +710,23 @@ __global__ __launch_bounds__(256) void dgrad_smallc4_k4s2p1_kernel(const float* 
         for (int py = 0; py < 2; ++py)
 #pragma unroll
             for (int px = 0; px < 2; ++px) {
-                const float* wrow = wp + (py * 2 + px) * phase_stride + (long long)ko * 16;
+                const int ny = dg_taps(KH, 2, P, py), nx = dg_taps(KH, 2, P, px);
+                const float* wrow = KH == 4 ? wp + (py * 2 + px) * phase_stride + (long long)ko * 16
+                                            : wp + (py * 2 + px) * phase_stride + (long long)ko * 4;
 #pragma unroll
-                for (int ty = 0; ty < 2; ++ty)
+                for (int ty = 0; ty < TMAX; ++ty)
 #pragma unroll
-                    for (int tx = 0; tx < 2; ++tx) {
-                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wrow + (ty * 2 + tx) * 4);
-                        const int ry = (py + 1) / 2 - ty + 1, rx = (px + 1) / 2 - tx + 1;
+                    for (int tx = 0; tx < TMAX; ++tx) {
+                        if (ty < ny && tx < nx) {      // (folded after unrolling)
+                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(
+                                KH == 4 ? wrow + (ty * 2 + tx) * 4 : wrow + (long long)(ty * nx + tx) * kpad * 4);
+                            const int ry = (py + P) / 2 - ty + 1, rx = (px + P) / 2 - tx + 1;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
+                            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                            for (int c = 0; c < C; ++c)
-                                acc[q][py][px][c] = fmaf(v[ry][q + rx], w4[c], acc[q][py][px][c]);
+                                for (int c = 0; c < C; ++c)
+                                    acc[q][py][px][c] = fmaf(v[ry][q + rx], w4[c], acc[q][py][px][c]);
+                        }
                     }
             }
     }
@@ -764,6 +774,27 @@ __global__ __launch_bounds__(256) void dgrad_smallc4_k4s2p1_kernel(const float* 
             }
         }
     }
+}
+
+// 5x5 s2 p2 onto <= 4 channels (HoloGAN's critic: the gradient of its first convolution with respect to the image):
+// the four-positions kernel only (rows of OW/4 lanes inside a wavefront, 16-byte aligned tensors, tap-major pack)
+static bool dgrad_direct5_ok(const float* y, const float* x, const ConvShape& s) {
+    static const bool off = getenv("GZ_NO_SMALLC") != nullptr || getenv("GZ_NO_SMALLC5") != nullptr;
+    return !off && s.C <= 4 && s.H == 2 * s.OH && s.W == 2 * s.OW && s.OW % 4 == 0 && 64 % (s.OW / 4) == 0 &&
+           (((uintptr_t)y | (uintptr_t)x) & 15) == 0 && dgrad_tap_major(s.K, 5, 5, 2);
+}
+
+template <int C>
+static int run_dgrad_smallc5(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s, int act,
+                             float slope, hipStream_t st) {
+    const long long M4 = (long long)s.N * s.OH * s.OW / 4;
+    if (M4 < 2 * 1024 * 64)
+        hipLaunchKernelGGL((dgrad_smallc4_k4s2p1_kernel<C, 4, 5>), dim3((unsigned)((M4 + 63) / 64)), dim3(256), 0, st, y, wp,
+                           bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope);
+    else
+        hipLaunchKernelGGL((dgrad_smallc4_k4s2p1_kernel<C, 1, 5>), dim3((unsigned)((M4 + 255) / 256)), dim3(256), 0, st, y,
+                           wp, bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope);
+    return launch_status();
 }
 
 template <int C>
@@ -976,6 +1007,16 @@ static int dispatch_dgrad(const float* y, const float* wp, const float* bias, fl
             case 2: return run_dgrad_smallc<2>(y, wp, bias, x, s, act, slope, st);
             case 3: return run_dgrad_smallc<3>(y, wp, bias, x, s, act, slope, st);
             default: return run_dgrad_smallc<4>(y, wp, bias, x, s, act, slope, st);
+        }
+    }
+    if constexpr (G::kh == 5 && G::kw == 5 && G::s == 2 && G::p == 2) {
+        if (dgrad_direct5_ok(y, x, s)) {
+            switch (s.C) {
+                case 1: return run_dgrad_smallc5<1>(y, wp, bias, x, s, act, slope, st);
+                case 2: return run_dgrad_smallc5<2>(y, wp, bias, x, s, act, slope, st);
+                case 3: return run_dgrad_smallc5<3>(y, wp, bias, x, s, act, slope, st);
+                default: return run_dgrad_smallc5<4>(y, wp, bias, x, s, act, slope, st);
+            }
         }
     }
     long long M = (long long)s.N * (s.H / G::s) * (s.W / G::s);

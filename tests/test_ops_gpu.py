@@ -1201,3 +1201,21 @@ def test_gather_paths_on_plan_boundaries(case):
     assert rel(dw, torch.nn.grad.conv2d_weight(x, (K, C, k, k), gy, stride=st, padding=pd)) < TOL
     assert torch.equal(dx, F._conv_dgrad_raw(gy.cuda(), w.cuda(), None, geom, (H, H), F.ACT_NONE, 0.0))
     assert torch.equal(dw, F._conv_wgrad_raw(x.cuda(), gy.cuda(), geom))
+
+
+@pytest.mark.parametrize("case", [(3, 3, 16, 16), (2, 1, 32, 24), (4, 4, 64, 64), (64, 3, 128, 64), (130, 3, 64, 72),
+                                  (5, 2, 8, 16)])
+def test_small_channel_transposed_conv_5x5(case):
+    """ConvTranspose2d k5 s2 p2 (output_padding 1) onto <= 4 image channels -- the gradient of HoloGAN's first critic
+    convolution with respect to the image: the four-positions direct kernel with the tap-major weight pack (9 / 6 / 6 / 4
+    taps per phase), both the channel-split (small maps) and the full-chip form; bias + tanh epilogue."""
+    F = _F()
+    N, C, H, K = case                      # image side [N, C, H, H], feature side [N, K, H/2, H/2]
+    geom = F.Geom(5, 5, 2, 2)
+    gy = rnd(N, K, H // 2, H // 2, seed=27)
+    w = rnd(K, C, 5, 5, seed=28, scale=0.1)
+    b = rnd(C, seed=29)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = torch.tanh(torch.nn.grad.conv2d_input((N, C, H, H), w, gy, stride=2, padding=2) + b.view(1, -1, 1, 1))
+    out = F._conv_dgrad_raw(gy.cuda(), w.cuda(), b.cuda(), geom, (H, H), F.ACT_TANH, 0.0)
+    assert out.shape == ref.shape and rel(out, ref) < TOL
