@@ -21,7 +21,7 @@ def label_of(name):
     if not m:
         # round 3: igemm2_kernel / igemm2r_kernel<gz::TileCfg2<WM, WN, TN, OCC>, loader...> (TM = 4)
         m2 = re.search(r"igemm2r?_kernel<gz::TileCfg2<(\d+), (\d+), (\d+), (\d+)>, gz::(\w+)<", name)
-        mw = re.search(r"igemm2w_kernel<gz::TileCfg2<(\d+), (\d+), (\d+), (\d+)>, (\d+),", name)
+        mw = re.search(r"igemm2w_kernel<gz::TileCfg2<(\d+), (\d+), (\d+), (\d+)>, ", name)
         if mw:        # weight gradient with both operands by LDS-DMA: no loader types in the name
             return "igemm<Wg,%dx%d>" % (int(mw.group(1)) * 128, int(mw.group(2)) * int(mw.group(3)) * 32)
         if not m2:
