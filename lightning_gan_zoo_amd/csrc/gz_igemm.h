@@ -2978,7 +2978,8 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2r_kernel(typename AL::Para
 //      the lane (c, ky, kx) reads  image[c][2*r + ky][2*x + kx + 3]  with r, x from k: row / channel pitches are chosen
 //      so that the 32 (c, ky, kx) lanes of a half-wave fall on 32 different banks, and every k-step's offset is an
 //      immediate.
-// No VALU and no ds_write in the loop; 24 LDS reads per chunk and wavefront instead of 48.  Ring, counted vmcnt,
+// No VALU and no ds_write in the k-steps (per chunk: a dozen VALU instructions for the stage offsets and the halo
+// flags of the two B pieces); 24 LDS reads per chunk and wavefront instead of 48.  Ring, counted vmcnt,
 // barrier placement and the epilogue (D[m][n], lanes along n, split-K slabs through the epilogue) as above.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
