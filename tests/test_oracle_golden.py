@@ -97,8 +97,11 @@ def compare(out, golden, tol, label, atol_scale=None, cond=None, cond_factor=10.
         strict = k.startswith(STRICT_PREFIXES)
         if cond is not None and not strict:
             t = max(tol, grad_floor, cond_factor * cond.get(k, 0.0))
-            if k.startswith("grad1_"):
-                t = max(t, pair1_grad_floor)     # see test_product_matches_stable_mask_fixture (hologan)
+            if k.startswith("grad1_g/"):
+                # the GENERATOR's second-pair gradients only (they hang on the critic's nearly cancelling input
+                # gradient); the critic's own second-pair gradients keep max(tol, 10 cond): see
+                # test_product_matches_stable_mask_fixture (hologan)
+                t = max(t, pair1_grad_floor)
             if k.startswith("final/"):
                 t = max(t, 1e-2)     # a few % of entries take the other +-lr branch; see update_agreement
         g64, r64 = got.astype(np.float64).ravel(), ref.astype(np.float64).ravel()

@@ -88,7 +88,8 @@ def test_product_matches_stable_mask_fixture(expt):
     = 1.6e-3 -- the reference's own fp32-vs-fp64 pair shows exactly that (cond 5e-4 .. 7e-3 on the discriminator's
     second-pair gradients, <= 1e-4 elsewhere).  Hence max(1e-3, 10 cond) per quantity, as everywhere else.
 
-    Second-pair gradients, hologan only: 5e-2.  The discriminator's input gradient is a sum of nearly cancelling
+    Second-pair GENERATOR gradients (``grad1_g/*``), hologan only: 5e-2; the discriminator's second-pair gradients
+    keep the ordinary bar.  The discriminator's input gradient is a sum of nearly cancelling
     contributions (|d loss / d image| = 0.07 against 15 inside the blocks), so ONE LeakyReLU decision of the G step
     taken the other way moves the generator's gradients by up to 3.8e-2 (final_layer) -- measured in round 2 by
     running this product with two split-K plans of the same ConvTranspose3d, i.e. a 1e-9 relative perturbation of
