@@ -788,7 +788,8 @@ template <int C>
 static int run_dgrad_smallc5(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s, int act,
                              float slope, hipStream_t st) {
     const long long M4 = (long long)s.N * s.OH * s.OW / 4;
-    if (M4 < 2 * 1024 * 64)
+    static const long long split_below = getenv("GZ_SMALLC_SPLIT_BELOW") ? atoll(getenv("GZ_SMALLC_SPLIT_BELOW")) : 36 * 1024;
+    if (M4 < split_below)
         hipLaunchKernelGGL((dgrad_smallc4_k4s2p1_kernel<C, 4, 5>), dim3((unsigned)((M4 + 63) / 64)), dim3(256), 0, st, y, wp,
                            bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope);
     else
@@ -805,9 +806,12 @@ static int run_dgrad_smallc(const float* y, const float* wp, const float* bias, 
     // a row of OW/4 lanes must not straddle two wavefronts (the halo columns come from the neighbour LANES)
     if (!one_pos && s.OW % 4 == 0 && 64 % (s.OW / 4) == 0 && (((uintptr_t)y | (uintptr_t)x) & 15) == 0) {
         const long long M4 = M / 4;
-        // fewer than two wavefronts per SIMD of lane positions (bs 128 at 32x32: 512 wavefronts): split the channel
-        // loop over the workgroup instead (0.080 -> 0.056 ms there; at bs 512 the unsplit form is 2x faster)
-        if (M4 < 2 * 1024 * 64 && s.K >= 16)
+        // few lane positions (bs 128 at 32x32: 512 wavefronts): split the channel loop over the workgroup instead
+        // (0.080 -> 0.056 ms there; at bs 512 the unsplit form is 2x faster)
+        // (round 3: measured crossover between bs 128 and bs 160 at 32x32 feature maps -- 32768 / 40960 lane positions;
+        // bs 256: 114 -> 91 us for G's last layer without the split)
+        static const long long split_below = getenv("GZ_SMALLC_SPLIT_BELOW") ? atoll(getenv("GZ_SMALLC_SPLIT_BELOW")) : 36 * 1024;
+        if (M4 < split_below && s.K >= 16)
             hipLaunchKernelGGL((dgrad_smallc4_k4s2p1_kernel<C, 4>), dim3((unsigned)((M4 + 63) / 64)), dim3(256), 0, st, y,
                                wp, bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope);
         else
