@@ -261,7 +261,7 @@ def test_loss_trajectory_tracks_oracle(expt):
     from the same default initialisation (same seed -> bit-identical parameters) on the same batches and latents,
     product on the GPU vs oracle on the CPU.  The first losses must agree to 1e-3; afterwards the optimizers
     turn rounding-level gradient differences into +-lr parameter differences, so the trajectories are held to
-    2e-2 for wgan_gp (observed 1.0e-2) and 1e-4 for dc_gan / R1 (observed 3e-7 / 2e-7), and the generator's eval-mode output (BatchNorm running statistics) is compared at
+    2e-2 (observed over the pool's boxes: 3e-7 .. 9e-3 dc_gan, 1e-3 .. 1e-2 wgan_gp with a 5e-2 bar, 2e-7 R1), and the generator's eval-mode output (BatchNorm running statistics) is compared at
     the end with the oracle carrying the product's state."""
     from helpers import FixedNoise, synthetic_noise, synthetic_real
     kw = dict(batch_size=8, features=8, noise_dim=16)
@@ -296,10 +296,10 @@ def test_loss_trajectory_tracks_oracle(expt):
     d = np.abs(traj["hip"] - traj["cpu"]) / np.maximum(1.0, np.abs(traj["cpu"]))
     print(f"{expt}: trajectory deviation first {d[:2].max():.1e}, max {d.max():.1e}; losses {traj['cpu'][:2]} -> {traj['cpu'][-2:]}")
     # wgan_gp: Adam with beta1 = 0 follows the sign of every gradient entry and the penalty (|g| - 1)^2 is steep: a
-    # different (equally valid) summation order moves single losses of its 24 by ~1e-2 (round 3: 1.0e-2; with round
-    # 2's first tile shapes 2.8e-2, which is why the bar was 5e-2 for a while).  dc_gan and R1 stay at rounding level
-    # (3e-7, 2e-7) and are held to 1e-4.
-    assert d[:2].max() < TOL and d.max() < (2e-2 if expt == "wgan_gp" else 1e-4)
+    # different (equally valid) summation order -- new tile shapes in round 2 -- moved one of its 24 losses by 2.8e-2.
+    # The bars are NOT tightened to one box's observation (round 3 tried 1e-4 for dc_gan after seeing 3e-7: the next
+    # box's CPU oracle, with another thread count and hence another summation order, gave 5.9e-3).
+    assert d[:2].max() < TOL and d.max() < (5e-2 if expt == "wgan_gp" else 2e-2)
     assert np.abs(traj["cpu"][-2:] - traj["cpu"][:2]).max() > 1e-4, "the scenario did not train"
     # eval-mode generator (running statistics) with the product's trained state in the oracle
     hip, cpu = steps["hip"][0], steps["cpu"][0]
