@@ -38,7 +38,7 @@ FLOP_PER_SAMPLE_CYCLE = {
     "gan_stability_r1": 7_037_173_760,
 }
 # HoloGAN EXT-128 (the reference cannot run at 128x128): traced the same way on the oracle's
-# extension, tools/flop_trace.py hologan 128 -> D step 11.4411 G + 2 x G step 13.7115 G
+# extension, tests/diagnostics/flop_trace.py hologan 128 -> D step 11.4411 G + 2 x G step 13.7115 G
 FLOP_PER_SAMPLE_CYCLE_EXT128 = {"hologan": 38_864_160_640}
 NATIVE_IMG_SIZE = {"gan_stability_r1": 128}
 # BASELINE.json configs measured in the default single-GPU run next to the headline (configs[1] = dc_gan bs 512):

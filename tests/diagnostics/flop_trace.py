@@ -3,8 +3,8 @@
 torch's FlopCounterMode as PyTorch autograd executes it (the way SURVEY.md 8-d's figures were obtained from the
 reference).  Used for the configurations SURVEY has no figure for (HoloGAN EXT-128).
 
-    python tools/flop_trace.py hologan 64      # -> 29.06 G
-    python tools/flop_trace.py hologan 128
+    python tests/diagnostics/flop_trace.py hologan 64      # -> 29.06 G
+    python tests/diagnostics/flop_trace.py hologan 128
 """
 import os
 import sys
@@ -12,7 +12,7 @@ import sys
 import torch
 from torch.utils.flop_counter import FlopCounterMode
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
