@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Headline benchmark: images/sec of the DCGAN G+D training step (64x64, synthetic data, fp32) on
-N MI355X GPUs of one node, through the reference's own surface (training_step / backward /
-optimizer.step with Lightning's per-batch optimizer alternation and toggle).
+"""Headline benchmark: images/sec of the DCGAN G+D training step (64x64, synthetic data, fp32, bs=128/GPU --
+the batch BASELINE.json's metric string names) on N MI355X GPUs of one node, through the reference's own surface
+(training_step / backward / optimizer.step with Lightning's per-batch optimizer alternation and toggle).
+The same run also measures BASELINE config 2 / 4 (bs=512/GPU, the north star's roofline batch) as
+``sub_configs.dc_gan_bs512`` -- on one GPU and, with ``--gpus N``, on all N ranks -- and, on one GPU, config 3
+(wgan_gp bs 256), config 5's per-GPU workload (hologan bs 64, at 64x64 and as EXT-128) and wgan bs 512.
 
     python bench.py [--gpus N --steps K --warmup W --batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -41,12 +44,14 @@ FLOP_PER_SAMPLE_CYCLE = {
 # extension, tests/diagnostics/flop_trace.py hologan 128 -> D step 11.4411 G + 2 x G step 13.7115 G
 FLOP_PER_SAMPLE_CYCLE_EXT128 = {"hologan": 38_864_160_640}
 NATIVE_IMG_SIZE = {"gan_stability_r1": 128}
-# BASELINE.json configs measured in the default single-GPU run next to the headline (configs[1] = dc_gan bs 512):
-# the metric string's own batch, config 3 (wgan_gp bs 256) and config 5's per-GPU workload (hologan bs 64, at the
-# parity-pinned 64x64 and as EXT-128)
-SUB_CONFIGS = (("dc_gan_bs128", "dc_gan", 128, 64), ("wgan_gp_bs256", "wgan_gp", 256, 64),
-               ("hologan_bs64", "hologan", 64, 64), ("hologan_ext128_bs64", "hologan", 64, 128))
-DEFAULT_BATCH = {"dc_gan": 512, "wgan": 512, "wgan_gp": 256, "hologan": 64, "gan_stability_r1": 64}
+# BASELINE.json configs measured in the default run next to the headline (the metric string's dc_gan bs 128 / GPU):
+# configs[1] / [3] = dc_gan bs 512 / GPU (every world size), and on one GPU config 3 (wgan_gp bs 256), config 5's
+# per-GPU workload (hologan bs 64, at the parity-pinned 64x64 and as EXT-128) and the 5 : 1 wgan cycle
+SUB_CONFIGS = (("dc_gan_bs128", "dc_gan", 128, 64), ("dc_gan_bs512", "dc_gan", 512, 64),
+               ("wgan_gp_bs256", "wgan_gp", 256, 64), ("hologan_bs64", "hologan", 64, 64),
+               ("hologan_ext128_bs64", "hologan", 64, 128), ("wgan_bs512", "wgan", 512, 64))
+MULTI_GPU_SUB_CONFIGS = ("dc_gan_bs128", "dc_gan_bs512")     # what a --gpus N run times on all ranks
+DEFAULT_BATCH = {"dc_gan": 128, "wgan": 512, "wgan_gp": 256, "hologan": 64, "gan_stability_r1": 64}
 PEAK_FP32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
 TIMER_EVERY = 4     # per-launch HIP events on every 4th cycle of the timed region (they cost ~5 % when always on)
 
@@ -58,7 +63,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reps", type=int, default=3, help="repetitions of the K-step timed region; the median is reported")
     ap.add_argument("--batch", type=int, default=None,
-                    help="per-GPU batch (default: BASELINE configs: dc_gan 512, wgan_gp 256, hologan 64)")
+                    help="per-GPU batch (default: BASELINE's: dc_gan 128 = the metric string, wgan_gp 256, hologan 64)")
     ap.add_argument("--expt", default="dc_gan")
     ap.add_argument("--img-size", type=int, default=None,
                     help="default 64 (128 for gan_stability_r1); 128 with --expt hologan is EXT-128, not parity-pinned")
@@ -216,16 +221,23 @@ def cpu_baseline(batch=128, budget_s=14.0):
                       % (batch, best[1], avail, len(times), med * 1e3)}
 
 
-def load_traffic(label):
+def load_traffic(config_key, label):
+    """HBM bytes per launch of kernel ``label`` in configuration ``config_key`` from the round's PMC passes
+    (profiles/traffic.json, written by tools/pmc_traffic.py from two separate ``rocprofv3 --pmc`` runs of this same
+    command: counters cannot be collected inside a timed run).  None when that configuration was not profiled."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(label)
+            tab = json.load(f)
     except Exception:  # noqa: BLE001
         return None
+    per_cfg = tab.get(config_key)
+    if isinstance(per_cfg, dict):
+        return per_cfg.get(label)
+    return None
 
 
-def roofline_of(timer, ms_per_step, steps, flop_cycle):
+def roofline_of(timer, ms_per_step, steps, flop_cycle, config_key=None):
     """The igemm kernel with the largest total time in the sampled cycles, plus the whole step."""
     agg = timer.summary()
     if not agg:
@@ -237,7 +249,7 @@ def roofline_of(timer, ms_per_step, steps, flop_cycle):
     return {
         "bound": "mfma", "kernel": label, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-        "traffic": load_traffic(label),
+        "traffic": load_traffic(config_key, label),
         "launches": n, "avg_launch_ms": round(ms / n, 4),
         "sampled_cycles": sampled_cycles,
         "share_of_step": round(ms / (ms_per_step * sampled_cycles), 3),
@@ -259,40 +271,72 @@ def flop_per_cycle(expt, batch, img_size):
     return float("nan")                # no traced FLOP count for this size
 
 
-def sub_record(F, expt, batch, img_size, device, steps, warmup, reps, use_timer):
-    """One more BASELINE configuration on this GPU, measured exactly like the headline (same trainer, same timed
-    region, per-launch HIP events on the launch stream for the roofline of its dominant kernel)."""
+def config_key_of(expt, batch, img_size):
+    for key, e, b, i in SUB_CONFIGS:
+        if (e, b, i) == (expt, batch, img_size):
+            return key
+    return "%s_bs%d_%d" % (expt, batch, img_size)
+
+
+def measure(F, expt, batch, img_size, device, rank, world, steps, warmup, reps, use_timer, force_sync=False,
+            graph=False):
+    """One configuration, timed as the contract says: ``warmup`` untimed cycles, then ``reps`` regions of exactly
+    ``steps`` optimizer cycles, each bracketed by barrier + synchronize, max over ranks, the median region reported;
+    per-launch HIP events on the launch stream (every 4th cycle of the first region) give the roofline of the dominant
+    kernel.  With world > 1 the trainer carries the gradient exchange (ddp.GradSync) and the record its overlap."""
     import torch
-    module, trainer = build_trainer(expt, batch, device, 1, img_size=img_size)
-    data = synthetic_batch(batch, device, 0, img_size)
+    module, trainer = build_trainer(expt, batch, device, world, force_sync, img_size, graph)
+    data = synthetic_batch(batch, device, rank, img_size)
     timer = F.KernelTimer()
-    for _ in range(2):
+    for _ in range(8 if graph else 2):          # graph mode: eager warm-up + capture of both optimizer steps
         trainer.step(data)
     trainer.finish()
-    if use_timer:
+    if use_timer and not graph:                 # per-launch events cannot be recorded inside a replayed graph
         F.set_kernel_timer(timer)
-    times, _, dt = timed_pairs(trainer, data, steps, warmup, 1, timer, reps)
+    sync = getattr(trainer, "grad_sync", None)
+    times, per_rank, dt = timed_pairs(trainer, data, steps, warmup, world, timer, reps,
+                                      on_timed_start=(sync.exposed_wait_ms if sync is not None and sync.measure else None))
     F.set_kernel_timer(None)
     torch.cuda.synchronize()
     ms = dt / steps * 1e3
-    per_cycle = len(trainer.order)
-    rec = {"workload": "%s synthetic %dx%d bs=%d/GPU, one optimizer cycle of %d batches%s"
+    per_cycle = len(trainer.order)              # batches per optimizer cycle: 2 (dc_gan, wgan_gp), 6 (wgan), 3 (hologan)
+    rec = {"workload": "%s synthetic %dx%d bs=%d/GPU, one optimizer cycle of %d batches (Lightning alternation + "
+                       "toggle), reference optimizer, fp32%s"
                        % (expt, img_size, img_size, batch, per_cycle,
                           " (EXT-128: stride-2 extension, not parity-pinned)" if expt == "hologan" and img_size == 128 else ""),
-           "value": round(per_cycle * batch * steps / dt, 1), "unit": "images/s", "ms_per_step": round(ms, 3),
-           "steps": steps, "ms_per_step_each": [round(t / steps * 1e3, 3) for t in times]}
+           "value": round(per_cycle * batch * world * steps / dt, 1), "unit": "images/s", "ms_per_step": round(ms, 3),
+           "n_gpus": world, "steps": steps, "batches_per_step": per_cycle,
+           "ms_per_step_each": [round(t / steps * 1e3, 3) for t in times],
+           "per_rank_ms_per_step": [round(t / steps * 1e3, 3) for t in per_rank]}
+    if sync is not None:
+        rec["grad_exchange"] = {"buckets": [[(e - s0) * 4 for s0, e, _, _ in fg.buckets] for fg in sync.flats],
+                                **sync.stats}
+        if sync.measure:
+            # how much of the exchange was EXPOSED on this rank: time the compute stream sat behind a gradient bucket
+            # that had not been reduced yet (events around every wait), per optimizer cycle of the timed region
+            w = sync.exposed_wait_ms()
+            cycles = steps * reps
+            rec["grad_exchange"]["overlap"] = {
+                "exposed_wait_ms_per_step": {"discriminator": round(w["discriminator"] / cycles, 4),
+                                             "generator": round(w["generator"] / cycles, 4)},
+                "waits_per_step": round(w["waits"] / cycles, 2), "rank": rank,
+                "note": "sum of (wait end - wait start) on the compute stream; 0 = fully hidden behind compute"}
+        if hasattr(sync, "cu_budget"):
+            rec["grad_exchange"]["cu_budget"] = sync.cu_budget
     fl = flop_per_cycle(expt, batch, img_size)
-    roof = roofline_of(timer, times[0] / steps * 1e3, steps, fl)
-    if roof is not None:
-        if roof["whole_step"] is not None:
+    if rank == 0:
+        roof = roofline_of(timer, times[0] / steps * 1e3, steps, fl, config_key_of(expt, batch, img_size))
+        if roof is not None:
+            if roof["whole_step"] is not None:      # the whole step is priced on the reported (median) time
+                a = fl / (ms * 1e-3) / 1e12
+                roof["whole_step"].update(achieved=round(a, 2), frac=round(a / PEAK_FP32_MFMA_TFLOPS, 4))
+            rec["roofline"] = roof
+        elif fl == fl:
             a = fl / (ms * 1e-3) / 1e12
-            roof["whole_step"].update(achieved=round(a, 2), frac=round(a / PEAK_FP32_MFMA_TFLOPS, 4))
-        roof["traffic"] = None
-        rec["roofline"] = roof
-    elif fl == fl:
-        a = fl / (ms * 1e-3) / 1e12
-        rec["roofline"] = {"whole_step": {"flop_per_step": fl, "achieved": round(a, 2),
-                                          "frac": round(a / PEAK_FP32_MFMA_TFLOPS, 4)}}
+            rec["roofline"] = {"whole_step": {"flop_per_step": fl, "achieved": round(a, 2),
+                                              "frac": round(a / PEAK_FP32_MFMA_TFLOPS, 4)}}
+    if sync is not None:
+        sync.close()
     del trainer, module, data
     gc.unfreeze()
     gc.collect()
@@ -336,96 +380,62 @@ def run_rank(args):
     torch.set_num_threads(min(8, torch.get_num_threads()))
     if args.force_grad_sync and world == 1 and not dist.is_initialized() and "RANK" in os.environ:
         dist.init_process_group("nccl", device_id=device)
-    module, trainer = build_trainer(args.expt, args.batch, device, world, args.force_grad_sync, args.img_size,
-                                    args.graph)
-    if args.graph:
-        args.no_kernel_timer = True        # per-launch events cannot be recorded inside a replayed graph
-    batch = synthetic_batch(args.batch, device, rank, args.img_size)
-    timer = F.KernelTimer()
-    # warm-up happens inside timed_pairs; the per-launch HIP events are recorded during the first timed repetition
-    for _ in range(8 if args.graph else 2):     # graph mode: eager warm-up + capture of both optimizer steps
-        trainer.step(batch)
-    trainer.finish()
-    if not args.no_kernel_timer:
-        F.set_kernel_timer(timer)
-    sync0 = getattr(trainer, "grad_sync", None)
-    times, per_rank, dt = timed_pairs(trainer, batch, args.steps, args.warmup, world, timer, args.reps,
-                                      on_timed_start=(sync0.exposed_wait_ms if sync0 is not None and sync0.measure else None))
-    F.set_kernel_timer(None)
-    torch.cuda.synchronize()
-    ms_per_step = dt / args.steps * 1e3
-    per_cycle = len(trainer.order)            # batches per optimizer cycle: 2 (dc_gan, wgan_gp), 6 (wgan), 3 (hologan)
-    value = per_cycle * args.batch * world * args.steps / dt
-    flop_cycle = flop_per_cycle(args.expt, args.batch, args.img_size)
+    use_timer = not args.no_kernel_timer
+    head = measure(F, args.expt, args.batch, args.img_size, device, rank, world, args.steps, args.warmup, args.reps,
+                   use_timer, args.force_grad_sync, args.graph)
+    head_key = config_key_of(args.expt, args.batch, args.img_size)
 
     out = {
         "metric": "images/sec (G+D step) at %dx%d bs=%d/GPU" % (args.img_size, args.img_size, args.batch),
-        "value": round(value, 1),
+        "value": head["value"],
         "unit": "images/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3),
+        "ms_per_step": head["ms_per_step"],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "%s synthetic %dx%d bs=%d/GPU, one optimizer cycle of %d batches (Lightning "
-                               "alternation + toggle), reference optimizer, fp32"
-                               % (args.expt, args.img_size, args.img_size, args.batch, per_cycle),
+        "config": {"workload": head["workload"], "key": head_key,
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                   "images_counted": "%d*bs*n_gpus per step (every batch of the cycle)" % per_cycle},
-        "repetitions": {"count": args.reps, "ms_per_step_each": [round(t / args.steps * 1e3, 3) for t in times],
-                        "reported": "median"},
-        "per_rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],
+                   "images_counted": "%d*bs*n_gpus per step (every batch of the cycle)" % head["batches_per_step"]},
+        "repetitions": {"count": args.reps, "ms_per_step_each": head["ms_per_step_each"], "reported": "median"},
+        "per_rank_ms_per_step": head["per_rank_ms_per_step"],
     }
     if world > 1:
         out["rccl_ranks"] = dist.get_world_size()
         if rehearsal:
             out["rehearsal"] = "all ranks on cuda:0, gloo transport: code-path check only, not a measurement"
-        sync = trainer.grad_sync
-        out["grad_exchange"] = {"buckets": [[(e - s) * 4 for s, e, _, _ in fg.buckets] for fg in sync.flats],
-                                **sync.stats}
-        if sync.measure:
-            # how much of the exchange was EXPOSED on this rank: time the compute stream sat behind a gradient bucket
-            # that had not been reduced yet (events around every wait), per optimizer cycle of the timed region
-            w = sync.exposed_wait_ms()
-            cycles = args.steps * args.reps
-            out["grad_exchange"]["overlap"] = {
-                "exposed_wait_ms_per_step": {"discriminator": round(w["discriminator"] / cycles, 4),
-                                             "generator": round(w["generator"] / cycles, 4)},
-                "waits_per_step": round(w["waits"] / cycles, 2), "rank": rank,
-                "note": "sum of (wait end - wait start) on the compute stream; 0 = fully hidden behind compute"}
+    if "grad_exchange" in head:
+        out["grad_exchange"] = head["grad_exchange"]
+    if "roofline" in head:
+        out["roofline"] = head["roofline"]
 
+    default_run = args.expt == "dc_gan" and args.img_size == 64 and not args.no_bs128
+    if default_run:
+        # the other BASELINE configurations.  Every world size: dc_gan bs 512 / GPU (configs 2 and 4, the north star's
+        # roofline batch), timed on ALL ranks exactly like the headline.  One GPU only: config 3 (wgan_gp bs 256),
+        # config 5's per-GPU workload (hologan bs 64; 64x64 parity-pinned and EXT-128), wgan bs 512.
+        out["sub_configs"] = {}
+        for key, expt, bs, img in SUB_CONFIGS:
+            if key == head_key or (world > 1 and key not in MULTI_GPU_SUB_CONFIGS):
+                continue
+            steps = args.steps if expt == "dc_gan" else min(args.steps, args.sub_steps)
+            out["sub_configs"][key] = measure(F, expt, bs, img, device, rank, world, steps, args.warmup, args.reps,
+                                              use_timer)
+        big = out["sub_configs"].get("dc_gan_bs512")
+        if big is not None and rank == 0:
+            w = (big.get("roofline") or {}).get("whole_step") or {}
+            out["config"]["workload"] += ("; the north star's roofline batch bs=512/GPU in the same run: %.0f images/s, "
+                                          "%.3f ms per pair, whole step %.3f of the fp32 MFMA peak "
+                                          "(sub_configs.dc_gan_bs512)" % (big["value"], big["ms_per_step"],
+                                                                          w.get("frac", float("nan"))))
     if rank == 0:
-        roof = roofline_of(timer, times[0] / args.steps * 1e3, args.steps, flop_cycle)
-        if roof is not None:
-            if roof["whole_step"] is not None:     # the whole step is priced on the reported (median) time
-                a = flop_cycle / (ms_per_step * 1e-3) / 1e12
-                roof["whole_step"].update(achieved=round(a, 2), frac=round(a / PEAK_FP32_MFMA_TFLOPS, 4))
-            out["roofline"] = roof
-        if world == 1 and not args.no_bs128 and args.expt == "dc_gan" and args.img_size == 64:
-            # the other BASELINE configurations a single GPU runs: the metric string's bs=128/GPU, config 3
-            # (wgan_gp bs 256), config 5's per-GPU workload (hologan bs 64; 64x64 parity-pinned and EXT-128)
-            del trainer, module
-            gc.unfreeze()
-            gc.collect()
-            torch.cuda.empty_cache()
-            out["sub_configs"] = {}
-            for key, expt, bs, img in SUB_CONFIGS:
-                if expt == args.expt and bs == args.batch and img == args.img_size:
-                    continue
-                steps = args.steps if expt == "dc_gan" else min(args.steps, args.sub_steps)
-                out["sub_configs"][key] = sub_record(F, expt, bs, img, device, steps, args.warmup, args.reps,
-                                                     not args.no_kernel_timer)
-            if "dc_gan_bs128" in out["sub_configs"]:
-                b = out["sub_configs"]["dc_gan_bs128"]
-                out["bs128"] = b                 # the key earlier rounds' records used
-                out["config"]["workload"] += ("; the metric string's bs=128/GPU on the same GPU: %.0f images/s, "
-                                              "%.3f ms per pair (sub_configs.dc_gan_bs128)" % (b["value"], b["ms_per_step"]))
         if world == 1 and not args.no_cpu_baseline and args.expt == "dc_gan":
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(128, 12.0)
+            out["cpu_baseline"]["bs64"] = cpu_baseline(64, 7.0)        # BASELINE config 1's batch
         print(json.dumps(out), file=result_out, flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -189,15 +189,25 @@ class TensorFileImages:
     def __init__(self, path, batch, device, rank=0, world=1):
         data = torch.load(path) if path.endswith(".pt") else torch.from_numpy(np.load(path))
         self.data, self.batch, self.device = data.float(), batch, device
+        self.rank, self.world, self.epoch = rank, world, 0
         self.order = shard_indices(len(self.data), rank, world)
+
+    def set_epoch(self, epoch):
+        """The epoch the next ``iter()`` starts with (Lightning: ``sampler.set_epoch(trainer.current_epoch)``)."""
+        self.epoch = int(epoch)
 
     def __len__(self):
         return len(self.order)
 
     def __iter__(self):
-        order = torch.tensor(self.order)
+        epoch = self.epoch
         while True:
-            for i in range(0, len(order), self.batch):        # no shuffling, as the reference's train_dataloader (:89-92)
+            # one process: no shuffling, as the reference's train_dataloader (:89-92); data parallel: the
+            # DistributedSampler(shuffle=True) permutation of this epoch (shard_indices)
+            order = torch.tensor(self.order if self.world <= 1
+                                 else shard_indices(len(self.data), self.rank, self.world, epoch))
+            epoch += 1
+            for i in range(0, len(order), self.batch):
                 real = self.data[order[i:i + self.batch]]
                 if torch.device(self.device).type == "cuda":
                     real = real.pin_memory().to(self.device, non_blocking=True)
@@ -234,13 +244,20 @@ class ImageFolderImages:
         self.samples, self.classes = image_folder_samples(root)
         if not self.samples:
             raise FileNotFoundError("no images under %r" % root)
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.epoch = rank, world, 0
         self.order = shard_indices(len(self.samples), rank, world)          # (length / unshuffled view; see host_batches)
         self.batch, self.size, self.channels = batch, img_size, channels
         self.mean, self.std, self.device, self.prefetch = mean, std, torch.device(device), prefetch
 
     def __len__(self):
         return len(self.order)
+
+    def set_epoch(self, epoch):
+        """The epoch the next ``host_batches()`` / ``iter()`` starts with.  Lightning calls
+        ``sampler.set_epoch(trainer.current_epoch)`` at every epoch start, so a run resumed from a checkpoint of epoch
+        E continues with the permutation ``randperm(seed + E)``, not with ``seed + 0`` again (``fit`` passes the
+        checkpoint's epoch here)."""
+        self.epoch = int(epoch)
 
     def decode(self, path):
         from PIL import Image
@@ -253,7 +270,7 @@ class ImageFolderImages:
     def host_batches(self):
         """uint8 [b, S, S, C] arrays and int64 labels, epoch after epoch: dataset order in one process, a fresh
         DistributedSampler(shuffle=True) permutation per epoch under data parallelism (shard_indices)."""
-        epoch = 0
+        epoch = self.epoch
         while True:
             order = self.order if self.world <= 1 else shard_indices(len(self.samples), self.rank, self.world, epoch)
             epoch += 1
@@ -403,7 +420,7 @@ class CheckpointKeeper:
 # ---------------------------------------------------------------------------------------------------------
 # the loop
 # ---------------------------------------------------------------------------------------------------------
-def fit(module, cfg, data, run, sync=None, rank=0, world=1, evaluate=None):
+def fit(module, cfg, data, run, sync=None, rank=0, world=1, evaluate=None, slow_group=None):
     """``pl.Trainer(max_epochs=cfg.train.num_epochs, resume_from_checkpoint=find_ckpt(...)).fit(model)`` for the
     step classes of this package (reference run_network.py:61-72).  Returns (module, trainer, global_step)."""
     from .harness import Trainer
@@ -420,6 +437,8 @@ def fit(module, cfg, data, run, sync=None, rank=0, world=1, evaluate=None):
         trainer.batch_idx = step
         if keeper is not None:
             keeper.load_state(kst, ckpt)
+        if hasattr(data, "set_epoch"):
+            data.set_epoch(epoch)         # the sampler's permutation continues at seed + epoch (Lightning: set_epoch)
         if rank == 0:
             print("resumed from %s at step %d (epoch %d)" % (ckpt, step, epoch))
     # a full Python garbage collection walks every object torch has created (~70 ms, several training steps):
@@ -456,6 +475,8 @@ def fit(module, cfg, data, run, sync=None, rank=0, world=1, evaluate=None):
             trainer.end_epoch()           # lr_scheduler.step(), current_epoch += 1
             epoch += 1
             metrics = evaluate(module, epoch) if evaluate is not None else None
+            if slow_group is not None:    # ranks > 0 wait for rank 0's Inception pass on the long-timeout group
+                torch.distributed.barrier(group=slow_group)
             checkpoint(metrics)
     trainer.finish()
     if step % steps_per_epoch:            # a run cut short by max_steps still leaves a resumable state
@@ -570,24 +591,43 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # with the FID evaluator on, rank 0 alone generates val.fid_n_samples images and runs InceptionV3 over them at
-        # every epoch end while the other ranks wait in the checkpoint's collectives: far longer than the 10 minutes
-        # after which the default watchdog aborts the job
-        import datetime
-        kw = {"timeout": datetime.timedelta(hours=6)} if wants_fid(cfg, run) else {}
         if rehearsal:
-            dist.init_process_group("gloo", **kw)
+            dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=device, **kw)
+            dist.init_process_group("nccl", device_id=device)
     module = locate(cfg.model.lm["_target_"])(cfg, logging_dir="output").to(device)
+    slow_group = None
     if world > 1:
         from .ddp import GradSync
         sync = GradSync(module)
-    evaluate = make_fid_evaluator(cfg, run, module, device) if rank == 0 else None
-    if world > 1 and wants_fid(cfg, run):
-        torch.distributed.barrier()            # rank 0 has the real activations (computed or loaded) before step 0
+        if wants_fid(cfg, run):
+            # with the FID evaluator on, rank 0 alone generates val.fid_n_samples images and runs InceptionV3 over them
+            # at start-up and at every epoch end -- far longer than the default watchdog's 10 minutes.  Only THOSE waits
+            # get a long timeout (their own group); every training collective keeps the default, so a rank that dies
+            # mid-training is still noticed in minutes.
+            import datetime
+            # (gloo: the wait is a host-side one, no GPU stream sits behind it)
+            slow_group = torch.distributed.new_group(timeout=datetime.timedelta(hours=6), backend="gloo")
+    evaluate, failure = None, None
+    if rank == 0:
+        try:
+            evaluate = make_fid_evaluator(cfg, run, module, device)
+        except BaseException as e:  # noqa: BLE001  (SystemExit from a missing weight file included)
+            failure = e
+            if slow_group is None:
+                raise
+    if slow_group is not None:
+        # rank 0 has the real activations (computed or loaded) before step 0 -- or failed, and then says so: the
+        # other ranks leave with it instead of sitting in a barrier for the long timeout
+        flag = torch.tensor([1 if failure is not None else 0])
+        torch.distributed.broadcast(flag, 0, group=slow_group)
+        if int(flag.item()):
+            if rank == 0:
+                print("FID evaluator could not be built on rank 0: %r" % (failure,), file=sys.stderr)
+            torch.distributed.destroy_process_group()
+            raise SystemExit(2)
     data = build_data(cfg, run, device, rank, world)
-    out = fit(module, cfg, data, run, sync=sync, rank=rank, world=world, evaluate=evaluate)
+    out = fit(module, cfg, data, run, sync=sync, rank=rank, world=world, evaluate=evaluate, slow_group=slow_group)
     if world > 1:
         torch.distributed.destroy_process_group()
     return out

@@ -19,6 +19,9 @@ class HostNormalisedFolder:
     def __len__(self):
         return len(self.folder)
 
+    def set_epoch(self, epoch):
+        self.folder.set_epoch(epoch)
+
     def __iter__(self):
         f = self.folder
         for imgs, labels in f.host_batches():

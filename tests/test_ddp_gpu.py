@@ -69,20 +69,27 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--reps", "1", "--batch", "32", "--no-cpu-baseline", "--no-kernel-timer"],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+                        "--reps", "1", "--no-cpu-baseline", "--no-kernel-timer"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
+    # the headline is the metric string's configuration (BASELINE.json: bs=128/GPU) ...
+    assert "bs=128/GPU" in out["metric"] and out["config"]["key"] == "dc_gan_bs128"
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and len(out["per_rank_ms_per_step"]) == 2
-    assert out["config"]["global_batch"] == 64 and out["scaling"] == "weak" and "rehearsal" in out
-    ex = out["grad_exchange"]
-    assert ex["buckets_from_hooks"] > 0 and ex["buckets_after_backward"] == 0
-    # the overlap report of the first real multi-GPU run: exposed wait per optimizer cycle and network
-    ov = ex["overlap"]
-    assert set(ov["exposed_wait_ms_per_step"]) == {"discriminator", "generator"} and ov["waits_per_step"] >= 2
-    assert all(v >= 0.0 for v in ov["exposed_wait_ms_per_step"].values())
+    assert out["config"]["global_batch"] == 256 and out["scaling"] == "weak" and "rehearsal" in out
+    # ... and the north star's bs=512/GPU is timed on ALL ranks in the same run (a SCALE run yields both curves)
+    big = out["sub_configs"]["dc_gan_bs512"]
+    assert set(out["sub_configs"]) == {"dc_gan_bs512"} and big["n_gpus"] == 2 and len(big["per_rank_ms_per_step"]) == 2
+    assert big["value"] > 0 and "bs=512/GPU" in big["workload"]
+    for rec in (out, big):
+        ex = rec["grad_exchange"]
+        assert ex["buckets_from_hooks"] > 0 and ex["buckets_after_backward"] == 0
+        # the overlap report of the first real multi-GPU run: exposed wait per optimizer cycle and network
+        ov = ex["overlap"]
+        assert set(ov["exposed_wait_ms_per_step"]) == {"discriminator", "generator"} and ov["waits_per_step"] >= 2
+        assert all(v >= 0.0 for v in ov["exposed_wait_ms_per_step"].values())
 
 
 def test_two_rank_training_run_rehearsal_on_one_gpu(tmp_path):

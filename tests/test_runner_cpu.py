@@ -138,6 +138,41 @@ def test_image_folder_reshuffles_per_epoch_under_data_parallelism(tmp_path):
     assert next(one)[1].tolist() == next(one)[1].tolist() == [c for _, c in R.image_folder_samples(root)[0]]
 
 
+def test_resumed_run_continues_the_sampler_at_the_checkpoints_epoch(tmp_path):
+    """advisor finding (round 3): Lightning calls ``sampler.set_epoch(trainer.current_epoch)``, so a DDP run resumed
+    from a checkpoint of epoch E draws ``randperm(seed + E)`` next -- not ``seed + 0`` again.  ``fit`` hands the
+    checkpoint's epoch to the data object; the order the resumed rank then consumes is shard_indices(n, r, w, E)."""
+    from test_input_step import make_folder
+    from lightning_gan_zoo_amd.run_network import ImageFolderImages
+    root = str(tmp_path / "imgs")
+    make_folder(root)                                   # 6 images, 2 ranks -> 3 per rank and epoch
+    samples = R.image_folder_samples(root)[0]
+    for rank in range(2):
+        f = ImageFolderImages(root, 3, 8, 3, 0.5, 0.5, "cpu", rank=rank, world=2)
+        f.set_epoch(2)
+        it = f.host_batches()
+        for epoch in (2, 3):
+            want = [samples[j][1] for j in R.shard_indices(len(samples), rank, 2, epoch)]
+            assert next(it)[1].tolist() == want, (rank, epoch)
+    # through fit(): a run of 2 epochs, then a resumed one -- the data object is told to start at epoch 2
+    seen = []
+
+    class Recorder(ImageFolderImages):
+        def set_epoch(self, epoch):
+            seen.append(epoch)
+            super().set_epoch(epoch)
+
+    from cpu_harness import HostNormalisedFolder
+    ck = str(tmp_path / "ck")
+    torch.set_num_threads(2)
+    args = SMALL + ["train.batch_size=3", "train.ckpt_dir=" + ck, "train.img_size=8"]
+    data = lambda: HostNormalisedFolder(Recorder(root, 3, 8, 3, 0.5, 0.5, "cpu", rank=0, world=2))  # noqa: E731
+    run_on_cpu("dc_gan", args + ["max_steps=2"], data=data())          # one batch per epoch: two epochs
+    assert seen == []                                   # a fresh run starts at epoch 0 by itself
+    run_on_cpu("dc_gan", args + ["max_steps=3"], data=data())
+    assert seen == [2]                                  # resumed: told the checkpoint's epoch
+
+
 def test_a_run_cut_short_keeps_the_best_checkpoint(tmp_path):
     """advisor finding (round 2): ``+max_steps`` ending mid-epoch wrote step=N.ckpt and swept model_best-fid=X.ckpt
     away.  ModelCheckpoint(save_top_k=1) never removes its best file for a state without a better metric."""

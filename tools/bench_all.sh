@@ -6,6 +6,6 @@ for e in dc_gan wgan wgan_gp hologan gan_stability_r1; do
   python - <<PY
 import json
 d=json.load(open("gpurun_out/${e}_line.json"))
-print("$e", d["value"], "img/s", d["ms_per_step"], "ms", d.get("bs128"))
+print("$e", d["value"], "img/s", d["ms_per_step"], "ms", (d.get("sub_configs") or {}).get("dc_gan_bs512", {}).get("ms_per_step"))
 PY
 done

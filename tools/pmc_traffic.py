@@ -1,9 +1,11 @@
 """HBM bytes per launch of every implicit-GEMM kernel from two rocprofv3 PMC passes.
 
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dirA> -- python bench.py --steps 3 --warmup 1 \
-        --no-cpu-baseline --no-bs128 --no-kernel-timer
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dirA> -- python bench.py --batch 128 --steps 3 \
+        --warmup 1 --reps 1 --no-cpu-baseline --no-sub-configs --no-kernel-timer
     rocprofv3 --pmc WRITE_SIZE ... -d <dirB> -- (same)
-    python tools/pmc_traffic.py <dirA> <dirB> profiles/traffic.json profiles/<round>_traffic_pmc_detail.json
+    python tools/pmc_traffic.py <dirA> <dirB> profiles/traffic.json profiles/<round>_traffic_pmc_detail.json dc_gan_bs128
+
+The last argument is bench.py's configuration key (SUB_CONFIGS): traffic.json holds one table per configuration.
 
 traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes (MI355X_MICROARCH.md, HBM section: FETCH_SIZE under-reports
 reads by 2x on gfx950; the raw sum is kept in the detail file).  Labels match bench.py's roofline labels.
@@ -65,6 +67,17 @@ if __name__ == "__main__":
         traffic[lab] = int((2 * fk + wk) * 1024)
         detail[lab] = {"launches_sampled": nf, "fetch_kb_raw": round(fk, 1), "write_kb": round(wk, 1),
                        "hbm_bytes_per_launch_corrected": traffic[lab], "hbm_bytes_per_launch_raw": int((fk + wk) * 1024)}
-    json.dump(traffic, open(sys.argv[3], "w"), indent=1)
-    json.dump(detail, open(sys.argv[4], "w"), indent=1)
+    key = sys.argv[5] if len(sys.argv) > 5 else "dc_gan_bs512"
+    try:
+        table = json.load(open(sys.argv[3]))
+    except Exception:  # noqa: BLE001
+        table = {}
+    table[key] = traffic
+    json.dump(table, open(sys.argv[3], "w"), indent=1)
+    try:
+        alld = json.load(open(sys.argv[4]))
+    except Exception:  # noqa: BLE001
+        alld = {}
+    alld[key] = detail
+    json.dump(alld, open(sys.argv[4], "w"), indent=1)
     print(json.dumps(detail, indent=1))

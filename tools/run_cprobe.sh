@@ -1,4 +1,5 @@
 #!/bin/bash
+# binaries: make -C tools (tools/Makefile records each variant's -D flags)
 for v in base nobar nodma same novm; do
   echo "== $v (1 WG/CU: +40000 B LDS)"
   tools/bin/cp_$v 512 256 16 128 128 40000

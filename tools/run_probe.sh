@@ -1,4 +1,5 @@
 #!/bin/bash
+# binaries: make -C tools (tools/Makefile records each variant's -D flags)
 P=tools/bin/igemm2_probe
 for v in 0 1; do
 $P 131072 256 2048 $v
