@@ -87,6 +87,35 @@ int gz_conv2d_wgrad_fuses_bias(int N, int C, int H, int W, int K, int OH, int OW
 int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* dbias, float* workspace, size_t ws_bytes, int N,
                     int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream);
 
+/* Round 4 -- the dispatch as data.  gz_conv2d_plan writes a one-line description of the kernel a launch of op (0 F, 1 Dg,
+ * 2 Wg) with this shape takes -- skeleton (igemm / igemm2 / igemm2w / a direct kernel), tile, operand loaders, number of
+ * reduction slabs, BatchNorm statistics rows -- into buf; returns the text length or a negative error.  Pure host logic
+ * (callable without a GPU); tests/test_dispatch_plan.py pins it for every layer of the BASELINE configurations, so a
+ * heuristic edit that moves a layer onto another kernel shows up as a diff.  Describes the launch for 16-byte aligned
+ * tensors with the advertised workspace. */
+int gz_conv2d_plan(int op, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, char* buf,
+                   int buflen);
+
+/* Round 4 -- weight gradients straight into the optimizer's (or the gradient exchange's) buffer.
+ * gz_conv2d_wgrad_partial: as gz_conv2d_wgrad, but a launch that splits its reduction leaves the slabs in `workspace`
+ * and reports them (*nz_out slabs, *stride_out floats apart); *nz_out == 1 means dw is complete.  gz_reduce_multi then
+ * sums the slabs of many parameters -- and of several launches per parameter (a discriminator applied to a real and a
+ * fake batch) -- in ONE launch, writing (beta 0) or accumulating into (beta 1) each gradient.  Replaces the per-layer
+ * slab reductions plus autograd's `grad += new` launches (reference: torch's AccumulateGrad behind every Conv2d /
+ * ConvTranspose2d weight of core/models/standard_networks.py:20-24,36-43,60-73).  The table is plain host memory of
+ * gz_reduce_multi_table_bytes() bytes, zero-initialised, filled with gz_reduce_multi_add (at most
+ * gz_reduce_multi_max_jobs() gradients of gz_reduce_multi_max_sources() launches each; counts and strides multiples
+ * of 4 floats, 16-byte aligned pointers). */
+int gz_conv2d_wgrad_partial(const float* x, const float* y, float* dw, float* workspace, size_t ws_bytes, int N, int C,
+                            int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, int* nz_out,
+                            long long* stride_out, hipStream_t stream);
+int gz_reduce_multi_max_jobs(void);
+int gz_reduce_multi_max_sources(void);
+size_t gz_reduce_multi_table_bytes(void);
+int gz_reduce_multi_add(void* table_host, float* out, long long count, int beta, const float* slabs, int nz,
+                        long long stride);
+int gz_reduce_multi(void* table_host, hipStream_t stream);
+
 /* Convolution + BatchNorm statistics in one launch (standard_networks.py:34-44,80-88: conv / transpose_conv ->
  * batch_norm): the epilogue also writes, per output channel and per group of pixels, (sum, sum of squares) of the
  * raw convolution output to stats[rows][channels][2]; gz_batchnorm_finalize turns them into the coefficients and

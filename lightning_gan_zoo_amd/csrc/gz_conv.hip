@@ -9,6 +9,7 @@
 // (SURVEY.md appendix C), so these three close the gradient-penalty double backward.
 // Replaces, for the hot path, the aten ops behind torch.nn.Conv2d / ConvTranspose2d at
 // reference core/models/standard_networks.py:20-24,36-43,60-73,80-87.
+#include <cstdio>
 #include <type_traits>
 
 #include "gz_igemm.h"
@@ -35,7 +36,7 @@ static bool is_tile2(TileId t) { return t >= T256x256; }
 // CUs idle (those launches keep igemm_kernel + split-K).  256x128 tiles keep two workgroups per CU, whose prologues /
 // epilogues overlap each other's main loops: preferred unless that halves a long reduction's operand reuse for nothing.
 static TileId pick_tile2(long long M, long long N, int ny, int kdim) {
-    static const bool off = getenv("GZ_NO_IGEMM2") != nullptr;
+    const bool off = knobs().no_igemm2;
     if (!off && N > 32 && N <= 64 && kdim >= 256) {             // one 64-wide column of 512-pixel tiles
         const long long t = ((M + 511) / 512) * ny;
         return t >= 512 ? T512x64 : T64x64;
@@ -43,7 +44,7 @@ static TileId pick_tile2(long long M, long long N, int ny, int kdim) {
     if (off || N < 128 || kdim < 256) return T64x64;            // "not applicable"
     const long long t128 = ((M + 255) / 256) * ((N + 127) / 128) * ny;
     const long long t256 = ((M + 255) / 256) * ((N + 255) / 256) * ny;
-    static const int force = getenv("GZ_IGEMM2_TILE") ? atoi(getenv("GZ_IGEMM2_TILE")) : 0;
+    const int force = knobs().igemm2_tile;
     if (force == 256 && N >= 256 && t256 >= 256) return T256x256;
     if (force == 128 && t128 >= 256) return T256x128;
     if (t128 >= 512) return T256x128;
@@ -52,24 +53,7 @@ static TileId pick_tile2(long long M, long long N, int ny, int kdim) {
     return T64x64;
 }
 
-static int g_force_tile = -2;
-
-static int forced_tile() {
-    if (g_force_tile == -2) {
-        const char* e = getenv("GZ_TILE");
-        g_force_tile = e ? atoi(e) : -1;
-    }
-    return g_force_tile;
-}
-
-static int min_wgs() {
-    static int t = -1;
-    if (t < 0) {
-        const char* e = getenv("GZ_MIN_WGS");
-        t = e ? atoi(e) : 1536;
-    }
-    return t;
-}
+static int forced_tile() { return knobs().tile; }
 
 // Tile choice.  Measured on the DCGAN layers at bs 512 (tools/conv_bench.py, round 2, 4 / 6 / 8 co-resident
 // workgroups per CU for the three shapes): a launch that fills the chip runs at ~125 (128x128), ~112 (128x64) and
@@ -88,10 +72,10 @@ static TileId pick_tile(long long M, long long N, int ny, int kdim = 0) {
     // shapes whatever the tile count says: bs 128, G.block2's input gradient 0.370 -> 0.305 ms, G.block3's 0.309 ->
     // 0.295, their forward 0.337 -> 0.324 / 0.299 -> 0.293; the 8.6 GFLOP discriminator layers of that batch lose 10 %
     // the same way (16 chunks per workgroup: prologue, slab write and finish dominate) and stay with the score.
-    static const bool no_big = getenv("GZ_NO_BIG_SPLIT") != nullptr;
+    const bool no_big = knobs().no_big_split;
     if (!no_big && kdim > 0 && N > 64 && tiles(128, 128) * ((kdim + BK - 1) / BK) >= 65536) return T128x128;
-    if (getenv("GZ_MIN_WGS")) {           // round-1 rule, kept for experiments
-        const long long want = min_wgs();
+    if (knobs().min_wgs > 0) {            // round-1 rule, kept for experiments
+        const long long want = knobs().min_wgs;
         if (N <= 64) return tiles(128, 64) >= want ? T128x64 : T64x64;
         if (tiles(128, 128) >= want) return T128x128;
         if (tiles(128, 64) >= want) return T128x64;
@@ -132,10 +116,8 @@ static long long tile_count(TileId t, long long M, long long N, int ny) {
 
 static SplitPlan plan_split(long long M, long long N, int Kdim, int ny, TileId normal) {
     SplitPlan none{normal, 1};
-    static int off = getenv("GZ_NO_SPLITK") ? 1 : 0;
-    static int target = getenv("GZ_SPLIT_TARGET") ? atoi(getenv("GZ_SPLIT_TARGET")) : 1024;
-    static int below = getenv("GZ_SPLIT_BELOW") ? atoi(getenv("GZ_SPLIT_BELOW")) : 512;
-    if (off) return none;
+    const int target = knobs().split_target, below = knobs().split_below;
+    if (knobs().no_splitk) return none;
     const int chunks = (Kdim + BK - 1) / BK;
     const long long tiles = tile_count(normal, M, N, ny);
     if (chunks < 16 || tiles >= below) return none;
@@ -184,12 +166,11 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
 // Tap-major reduction order (gz_igemm.h: ConvFwdALoaderTap / ConvDgALoaderTap) is used when the tap count does not
 // divide a chunk (3x3, 5x5) and there are enough channels to fill the BK-wide channel blocks.
 static bool fwd_tap_major(int C, int KH, int KW) {
-    static int off = getenv("GZ_NO_TAPMAJOR") ? 1 : 0;
-    return !off && (BK % (KH * KW) != 0) && C >= BK;
+    return !knobs().no_tapmajor && (BK % (KH * KW) != 0) && C >= BK;
 }
 
 static bool dgrad_tap_major(int K, int KH, int KW, int S) {
-    static int off = getenv("GZ_NO_TAPMAJOR") ? 1 : 0;
+    const bool off = knobs().no_tapmajor;
     const int taps = ((KH + S - 1) / S) * ((KW + S - 1) / S);
     const bool fixed = (KH % S == 0) && (KW % S == 0) && (BK % taps == 0);
     return !off && !fixed && K >= BK;
@@ -334,6 +315,81 @@ __global__ __launch_bounds__(64 * RS_WAVES) void reduce_slabs_kernel(const float
 }
 
 
+// Round 4: ONE launch sums the slabs of MANY weight gradients (the pack_multi idea applied to the other end of the
+// step).  A split weight-gradient launch may leave its slabs unreduced (gz_conv2d_wgrad_partial); at the end of a
+// backward pass -- or when a gradient bucket of the data-parallel exchange is complete -- gz_reduce_multi adds, per
+// parameter, the slabs of every launch that contributed (a discriminator used on a real and a fake batch has two
+// sources) and either writes or ACCUMULATES into the gradient (beta = 1: p.grad already holds earlier contributions;
+// under data parallelism p.grad is a view of the flat exchange buffer).  Replaces, per DCGAN pair, 12 reduce launches
+// + 11 framework `add_` launches of gradient accumulation by 2-4 launches.  The table travels as a kernel argument
+// (no staging copy).  Summation order is fixed: wavefront w of a workgroup takes slabs w, w+4, ... of source 0, then
+// of source 1, ...; the four partial sums meet in LDS in wavefront order.
+constexpr int REDUCE_MAX_JOBS = 24, REDUCE_MAX_SRC = 4;
+struct ReduceSrc {
+    const float* p;
+    long long stride;          // floats between consecutive slabs
+    int nz, pad;
+};
+struct ReduceJob {
+    float* out;
+    long long count;           // floats, a multiple of 4
+    int beta, nsrc, block0, pad;
+    ReduceSrc src[REDUCE_MAX_SRC];
+};
+struct ReduceTable {
+    int njobs, pad;
+    ReduceJob jobs[REDUCE_MAX_JOBS];
+};
+
+__global__ __launch_bounds__(256) void reduce_multi_kernel(ReduceTable t) {
+    __shared__ f32x4 part[3][64];
+    const int b = blockIdx.x;
+    int j = 0;
+    while (j + 1 < t.njobs && t.jobs[j + 1].block0 <= b) ++j;
+    const ReduceJob& jb = t.jobs[j];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long i = ((long long)(b - jb.block0) * 64 + lane) * 4;
+    const bool live = i < jb.count;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    if (live) {
+        for (int q = 0; q < jb.nsrc; ++q) {
+            const float* p = jb.src[q].p + i;
+            const long long st = jb.src[q].stride;
+            const int nz = jb.src[q].nz;
+            int z = wave;
+            for (; z + 12 < nz; z += 16) {          // four independent 16-byte loads in flight per lane
+                a0 += *reinterpret_cast<const f32x4*>(p + (long long)z * st);
+                a1 += *reinterpret_cast<const f32x4*>(p + (long long)(z + 4) * st);
+                a2 += *reinterpret_cast<const f32x4*>(p + (long long)(z + 8) * st);
+                a3 += *reinterpret_cast<const f32x4*>(p + (long long)(z + 12) * st);
+            }
+            for (; z < nz; z += 4) a0 += *reinterpret_cast<const f32x4*>(p + (long long)z * st);
+        }
+    }
+    a0 = (a0 + a1) + (a2 + a3);
+    if (wave > 0) part[wave - 1][lane] = a0;
+    __syncthreads();
+    if (wave == 0 && live) {
+        f32x4 r = ((a0 + part[0][lane]) + part[1][lane]) + part[2][lane];
+        f32x4* o = reinterpret_cast<f32x4*>(jb.out + i);
+        if (jb.beta) r += *o;
+        *o = r;
+    }
+}
+
+// set by gz_conv2d_wgrad_partial around its dispatch: the split launch reports its slabs instead of reducing them
+struct WgDefer {
+    int nz;
+    long long stride;
+};
+static thread_local WgDefer* tl_wg_defer = nullptr;
+static bool defer_reduce(int nz, long long stride) {
+    if (!tl_wg_defer) return false;
+    tl_wg_defer->nz = nz;
+    tl_wg_defer->stride = stride;
+    return true;
+}
+
 template <int KH, int KW, int S, int P>
 struct Geo {
     static constexpr int kh = KH, kw = KW, s = S, p = P;
@@ -375,7 +431,7 @@ static int run_fwd(const float* x, const float* wp, const float* bias, float* y,
     int Kg = s.C * G::kh * G::kw;
     typename BL::Params pb{wp, Kg, round4(s.K), round4(s.K), 0};
     if constexpr (G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1) {
-        static const bool no_row4 = getenv("GZ_NO_ROW4") != nullptr;          // experiment: the K4V loader
+        const bool no_row4 = knobs().no_row4;          // experiment: the K4V loader
         // OW >= 16 only: with shorter rows the stride-2 fragment reads of the lanes of a half-wave fall on 2*OW / 2
         // banks (OW = 4: an 8-way conflict; measured 113 -> 108 TFLOP/s on D.block3, 122 -> 117 on G.block2's
         // backward), where K4V's im2col image stays conflict-free; at OW = 16 / 32 it is +5 % (D.block1) or neutral
@@ -460,7 +516,7 @@ static TileId pick_tile_fwd(long long M, int K, int OW, int kh, int kw, int stri
 // splits to give every CU a workgroup, each with >= 32 chunks
 template <class G>
 static SplitPlan fwdtap2_plan(const ConvShape& s) {
-    static const bool off = getenv("GZ_NO_IGEMM2") != nullptr || getenv("GZ_NO_IGEMM2_TAP") != nullptr;
+    const bool off = knobs().no_igemm2 || knobs().no_igemm2_tap;
     if constexpr (BK % (G::kh * G::kw) == 0 && G::kh * G::kw != 1) return SplitPlan{T64x64, 1};
     if (off || !(G::kh * G::kw == 1 ? s.C >= BK : fwd_tap_major(s.C, G::kh, G::kw)) || s.K < 128 || (s.K & 3))
         return SplitPlan{T64x64, 1};
@@ -484,11 +540,11 @@ static SplitPlan fwd2_plan(const ConvShape& s) {
     const long long M = (long long)s.N * s.OH * s.OW;
     TileId t = s.K > 64 ? pick_tile2(M, s.K, 1, s.C * 16) : T64x64;
     if (t == T256x256 || t == T256x128) return SplitPlan{t, 1};
-    static const bool off = getenv("GZ_NO_IGEMM2") != nullptr;
+    const bool off = knobs().no_igemm2;
     if (off || s.K < 128) return SplitPlan{T64x64, 1};
     const long long tiles = ((M + 255) / 256) * ((s.K + 127) / 128);
     const int chunks = s.C;
-    static const int min_tiles = getenv("GZ_FWD2_MIN_TILES") ? atoi(getenv("GZ_FWD2_MIN_TILES")) : 16;
+    const int min_tiles = knobs().fwd2_min_tiles;
     if (tiles >= min_tiles && chunks >= 64) {
         int splits = (int)((256 + tiles - 1) / tiles);
         while (splits > 1 && chunks / splits < 32) --splits;
@@ -779,7 +835,7 @@ __global__ __launch_bounds__(256) void dgrad_smallc4_k4s2p1_kernel(const float* 
 // 5x5 s2 p2 onto <= 4 channels (HoloGAN's critic: the gradient of its first convolution with respect to the image):
 // the four-positions kernel only (rows of OW/4 lanes inside a wavefront, 16-byte aligned tensors, tap-major pack)
 static bool dgrad_direct5_ok(const float* y, const float* x, const ConvShape& s) {
-    static const bool off = getenv("GZ_NO_SMALLC") != nullptr || getenv("GZ_NO_SMALLC5") != nullptr;
+    const bool off = knobs().no_smallc || knobs().no_smallc5;
     return !off && s.C <= 4 && s.H == 2 * s.OH && s.W == 2 * s.OW && s.OW % 4 == 0 && 64 % (s.OW / 4) == 0 &&
            (((uintptr_t)y | (uintptr_t)x) & 15) == 0 && dgrad_tap_major(s.K, 5, 5, 2);
 }
@@ -788,7 +844,7 @@ template <int C>
 static int run_dgrad_smallc5(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s, int act,
                              float slope, hipStream_t st) {
     const long long M4 = (long long)s.N * s.OH * s.OW / 4;
-    static const long long split_below = getenv("GZ_SMALLC_SPLIT_BELOW") ? atoll(getenv("GZ_SMALLC_SPLIT_BELOW")) : 36 * 1024;
+    const long long split_below = knobs().smallc_split_below;
     if (M4 < split_below)
         hipLaunchKernelGGL((dgrad_smallc4_k4s2p1_kernel<C, 4, 5>), dim3((unsigned)((M4 + 63) / 64)), dim3(256), 0, st, y, wp,
                            bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope);
@@ -802,7 +858,7 @@ template <int C>
 static int run_dgrad_smallc(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s, int act,
                             float slope, hipStream_t st) {
     long long M = (long long)s.N * s.OH * s.OW;
-    static const bool one_pos = getenv("GZ_SMALLC_ONE_POS") != nullptr;          // experiment: the round-1 kernel
+    const bool one_pos = knobs().smallc_one_pos;          // experiment: the round-1 kernel
     // a row of OW/4 lanes must not straddle two wavefronts (the halo columns come from the neighbour LANES)
     if (!one_pos && s.OW % 4 == 0 && 64 % (s.OW / 4) == 0 && (((uintptr_t)y | (uintptr_t)x) & 15) == 0) {
         const long long M4 = M / 4;
@@ -810,7 +866,7 @@ static int run_dgrad_smallc(const float* y, const float* wp, const float* bias, 
         // (0.080 -> 0.056 ms there; at bs 512 the unsplit form is 2x faster)
         // (round 3: measured crossover between bs 128 and bs 160 at 32x32 feature maps -- 32768 / 40960 lane positions;
         // bs 256: 114 -> 91 us for G's last layer without the split)
-        static const long long split_below = getenv("GZ_SMALLC_SPLIT_BELOW") ? atoll(getenv("GZ_SMALLC_SPLIT_BELOW")) : 36 * 1024;
+        const long long split_below = knobs().smallc_split_below;
         if (M4 < split_below && s.K >= 16)
             hipLaunchKernelGGL((dgrad_smallc4_k4s2p1_kernel<C, 4>), dim3((unsigned)((M4 + 63) / 64)), dim3(256), 0, st, y,
                                wp, bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope);
@@ -862,7 +918,7 @@ static int run_dgrad(const float* y, const float* wp, const float* bias, float* 
         return launch_igemm<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kg, G::s * G::s, splits, st, slab, pc);
     }
     if constexpr (G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1) {
-        static const bool no_row4 = getenv("GZ_NO_ROW4") != nullptr;          // experiment: the per-element loader
+        const bool no_row4 = knobs().no_row4;          // experiment: the per-element loader
         if (!no_row4 && AW % 4 == 0 && (((uintptr_t)y) & 15) == 0) {
             using AR = ConvDgALoaderRow4<Cfg::BM, 4, 4, 2, 1>;
             return launch_igemm<Cfg, AR, BL, Epi>(pa, pb, pe, M, s.C, Kg, G::s * G::s, splits, st, slab);
@@ -917,7 +973,7 @@ static int run_dgradtap2(const float* y, const float* wp, const float* bias, flo
 
 template <class G>
 static SplitPlan dgradtap2_plan(const ConvShape& s) {
-    static const bool off = getenv("GZ_NO_IGEMM2") != nullptr || getenv("GZ_NO_IGEMM2_TAP") != nullptr;
+    const bool off = knobs().no_igemm2 || knobs().no_igemm2_tap;
     constexpr int TY = (G::kh + G::s - 1) / G::s, TX = (G::kw + G::s - 1) / G::s;
     constexpr bool one_by_one = G::kh * G::kw == 1;
     if constexpr (G::s * G::s > 8 || (!one_by_one && G::kh % G::s == 0 && G::kw % G::s == 0 && BK % (TY * TX) == 0))
@@ -943,8 +999,7 @@ static SplitPlan dgradtap2_plan(const ConvShape& s) {
     if (tiles * total < 512LL * 32) return SplitPlan{T64x64, 1};       // too little work for the big tile
     // ~384 workgroups of <= 96 chunks (measured on HoloGAN EXT-128's blocks, TFLOP/s of D.block2 / D.block3:
     // 256 workgroups 84 / 67, 384: 99 / 99, 512: 99 / 89, 768: 90 / 86; the round-2 kernels: 89 / 74)
-    static const int wgs = getenv("GZ_TAP_WGS") ? atoi(getenv("GZ_TAP_WGS")) : 384;
-    static const int cps_max = getenv("GZ_TAP_CPS_MAX") ? atoi(getenv("GZ_TAP_CPS_MAX")) : 96;
+    const int wgs = knobs().tap_wgs, cps_max = knobs().tap_cps_max;
     long long cps = (tiles * total + wgs - 1) / wgs;
     if (cps < 32) cps = 32;
     if (cps > cps_max) cps = cps_max;
@@ -963,7 +1018,7 @@ static bool dgrad2_ok(const ConvShape& s) {
 template <class G>
 static bool dgrad_direct(const float* x, const ConvShape& s) {
     return G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1 && s.C <= 4 && s.H == 2 * s.OH && s.W == 2 * s.OW &&
-           (((uintptr_t)x & 7) == 0) && !getenv("GZ_NO_SMALLC");
+           (((uintptr_t)x & 7) == 0) && !knobs().no_smallc;
 }
 
 template <class G>
@@ -976,10 +1031,10 @@ static SplitPlan dgrad_plan(const ConvShape& s) {
         if (is_tile2(t2)) return SplitPlan{t2, 1};
         // 64-255 tiles of 256x128 (small batches, deep layers): cut the reduction so that >= 256 workgroups exist,
         // each with >= 32 chunks (as the forward convolution does)
-        static const bool off = getenv("GZ_NO_IGEMM2") != nullptr;
+        const bool off = knobs().no_igemm2;
         const long long tiles = ((M + 255) / 256) * ((s.C + 127) / 128) * 4;
         const int chunks = s.K / 4;
-        static const int min_tiles = getenv("GZ_DG2_MIN_TILES") ? atoi(getenv("GZ_DG2_MIN_TILES")) : 64;
+        const int min_tiles = knobs().dg2_min_tiles;
         if (!off && s.C >= 128 && tiles >= min_tiles && tiles < 256 && chunks >= 64) {
             int splits = (int)((256 + tiles - 1) / tiles);
             while (splits > 1 && chunks / splits < 32) --splits;
@@ -1133,7 +1188,7 @@ __global__ __launch_bounds__(256) void conv3x3_smallch_kernel(const float* __res
 }
 
 static bool conv3_smallch_ok(int N, int CI, int CO, int H, int W) {
-    static int off = getenv("GZ_NO_SMALLCH_CONV") ? 1 : 0;
+    const bool off = knobs().no_smallch_conv;
     // measured against the implicit-GEMM path (tools/resnet_bench.py): wins when the output side fits one 16-row
     // MFMA tile and the input side fills at least half a 16-channel block (16->16 @ 128x128: 123 -> 72 us);
     // loses for 3 input channels (K dimension mostly padding) and for 32 output channels
@@ -1143,7 +1198,7 @@ static bool conv3_smallch_ok(int N, int CI, int CO, int H, int W) {
 static int run_conv3_smallch(const float* in, const float* wp, const float* bias, float* out, int N, int CI, int CO,
                              int H, int W, int tap_major, int flip, int act, float slope, hipStream_t st) {
     const int groups = N * H * (W >> 4);
-    static int gpw = getenv("GZ_C3_GPW") ? atoi(getenv("GZ_C3_GPW")) : 4;
+    const int gpw = knobs().c3_gpw;
     long long blocks = (groups + 4 * gpw - 1) / (4 * gpw);   // >= gpw pixel groups per wavefront: the weights are staged per workgroup
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
@@ -1279,7 +1334,7 @@ __global__ __launch_bounds__(256) void wgrad_smallch_k3_kernel(const float* __re
 }
 
 static bool wgrad_smallch_ok(const ConvShape& s, int KH, int KW, int S, int P) {
-    static int off = getenv("GZ_NO_SMALLCH_WG") ? 1 : 0;
+    const bool off = knobs().no_smallch_wg;
     const int kt = (s.K + 15) / 16, ct = (s.C + 15) / 16;      // 16x16 tiles per tap: at most 4 (36 accumulators)
     return !off && KH == 3 && KW == 3 && S == 1 && P == 1 && kt * ct <= 4 && (s.W & 15) == 0 &&
            (long long)s.N * s.H * s.W >= 65536;
@@ -1320,13 +1375,8 @@ static int run_wgrad_smallch(const float* x, const float* y, float* dw, float* d
 // Wg
 // ---------------------------------------------------------------------------
 static int wg_target() {
-    static int t = -1;
-    if (t < 0) {
-        const char* e = getenv("GZ_WG_TARGET");
-        t = e ? atoi(e) : 1024;      // 4 workgroups of the 128x128 shape per CU (round 2; was 1536 at 2 per CU)
-        if (t < 1) t = 1;
-    }
-    return t;
+    const int t = knobs().wg_target;     // 1024: 4 workgroups of the 128x128 shape per CU (round 2; was 1536 at 2 per CU)
+    return t < 1 ? 1 : t;
 }
 
 // Split-K so that ~4 workgroups per CU are in flight: the wgrad loaders are gather-heavy and only
@@ -1385,6 +1435,7 @@ static int launch_wgrad(const typename AL::Params& pa, const typename BL::Params
     int rc = launch_igemm<Cfg, AL, BL, EpiRowMajorB>(pa, pb, pe, s.K, NTOT, KTOT, 1, splits, st);
     if (rc != GZ_OK) return rc;
     if (nz > 1) {
+        if (defer_reduce(nz, count)) return rc;
         if (nz <= 8)
             hipLaunchKernelGGL(reduce_few_slabs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws, dw,
                                nz, count);
@@ -1411,7 +1462,7 @@ static constexpr bool wgrad2w_geom() {
 
 template <class G>
 static int wgrad2_splits(const ConvShape& s) {
-    static const bool off = getenv("GZ_NO_IGEMM2") != nullptr || getenv("GZ_NO_IGEMM2_WG") != nullptr;
+    const bool off = knobs().no_igemm2 || knobs().no_igemm2_wg;
     WgRowGeom rg;
     const int NTOT = s.C * G::kh * G::kw;
     if (off || s.K < 128 || s.K % 32 || NTOT < 256 - 128 * !wgrad2_narrow(s) || !wg_row_geom<G>(s, &rg)) return 0;
@@ -1424,9 +1475,9 @@ static int wgrad2_splits(const ConvShape& s) {
     if (splits < 1) splits = 1;
     // >= 64 chunks per workgroup for the register-staged kernel; the LDS-DMA kernel's chunks cost nothing but their
     // MFMAs, so 32 are enough there (bs 128: D.block1-3's weight gradients move from the 128x128 kernel onto it)
-    static const int min_chunks_env = getenv("GZ_WG2_MIN_CHUNKS") ? atoi(getenv("GZ_WG2_MIN_CHUNKS")) : 0;
+    const int min_chunks_env = knobs().wg2_min_chunks;
     const bool dma = wgrad2w_geom<G>() && s.H == G::s * s.OH && s.W == G::s * s.OW &&
-                     (s.OW == 4 || s.OW == 8 || s.OW % 16 == 0) && !getenv("GZ_NO_IGEMM2W");
+                     (s.OW == 4 || s.OW == 8 || s.OW % 16 == 0) && !knobs().no_igemm2w;
     const int min_chunks = min_chunks_env > 0 ? min_chunks_env : (dma ? 32 : 64);
     while (splits > 1 && chunks / splits < min_chunks) --splits;
     return tiles * splits >= 256 ? splits : 0;
@@ -1457,6 +1508,7 @@ static int run_wgrad2(const float* x, const float* y, float* dw, float* ws, size
     int rc = launch_igemm2r<Cfg, AL, BL, EpiRowMajorB>(pa, pb, pe, s.K, NTOT, KTOT, splits, st);
     if (rc != GZ_OK) return rc;
     if (nz > 1) {
+        if (defer_reduce(nz, count)) return rc;
         if (nz <= 8)
             hipLaunchKernelGGL(reduce_few_slabs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws, dw,
                                nz, count);
@@ -1470,16 +1522,21 @@ static int run_wgrad2(const float* x, const float* y, float* dw, float* ws, size
 
 // ... and with both operands by LDS-DMA (igemm2w_kernel: k4 s2 p1 only, pixel rows of 4, 8 or a multiple of 16)
 template <class G>
-static int wgrad2w_cw(const float* x, const float* y, const ConvShape& s) {
-    static const bool off = getenv("GZ_NO_IGEMM2W") != nullptr;
-    static const bool off_g = getenv("GZ_NO_IGEMM2WG") != nullptr;        // the generic-geometry image only
+static int wgrad2w_cw_shape(const ConvShape& s) {        // pixel-chunk width of the LDS-DMA weight gradient, 0 = not applicable
+    const bool off = knobs().no_igemm2w;
+    const bool off_g = knobs().no_igemm2wg;        // the generic-geometry image only
     if (off || !wgrad2w_geom<G>()) return 0;
     if (off_g && !(G::kh == 4 && G::kw == 4)) return 0;
     if (s.H != G::s * s.OH || s.W != G::s * s.OW || (s.W & 3)) return 0;
-    if ((((uintptr_t)x) | ((uintptr_t)y)) & 15) return 0;
     const int cw = s.OW == 4 ? 4 : s.OW == 8 ? 8 : (s.OW % 16 == 0 ? 16 : 0);
     if (!cw || s.OH % (16 / cw)) return 0;
     return cw;
+}
+
+template <class G>
+static int wgrad2w_cw(const float* x, const float* y, const ConvShape& s) {
+    if ((((uintptr_t)x) | ((uintptr_t)y)) & 15) return 0;
+    return wgrad2w_cw_shape<G>(s);
 }
 
 template <class G, int BN, int CW>
@@ -1508,6 +1565,7 @@ static int run_wgrad2w(const float* x, const float* y, float* dw, float* ws, siz
     int rc = launch_igemm2w<Cfg, BL, EpiRowMajorB>(p, pe, s.K, NTOT, KTOT, splits, st);
     if (rc != GZ_OK) return rc;
     if (nz > 1) {
+        if (defer_reduce(nz, count)) return rc;
         if (nz <= 8)
             hipLaunchKernelGGL(reduce_few_slabs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws, dw,
                                nz, count);
@@ -1538,7 +1596,7 @@ static int run_wgrad(const float* x, const float* y, float* dw, float* ws, size_
     const int KTOT = s.N * s.OH * s.OW;
     const int NTOT = s.C * G::kh * G::kw;
     WgRowGeom rg;
-    static int generic_only = getenv("GZ_WG_GENERIC") ? 1 : 0;
+    const bool generic_only = knobs().wg_generic;
     if (!generic_only && wg_row_geom<G>(s, &rg)) {
         using AL = WgALoaderRow<Cfg::BM>;
         using BL = WgBLoaderRow<Cfg::BN, G::kh, G::kw, G::s, G::p>;
@@ -1791,6 +1849,71 @@ int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* dbias, flo
 #undef CALL
 }
 
+int gz_conv2d_wgrad_partial(const float* x, const float* y, float* dw, float* workspace, size_t ws_bytes, int N, int C,
+                            int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, int* nz_out,
+                            long long* stride_out, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (!nz_out || !stride_out) return GZ_ERR_BAD_SHAPE;
+    ConvShape s{N, C, H, W, K, OH, OW};
+    if (!shape_ok(s, KH, KW, S, P)) return GZ_ERR_BAD_SHAPE;
+    if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
+    *nz_out = 1;
+    *stride_out = (long long)K * C * KH * KW;
+    if (wgrad_smallch_ok(s, KH, KW, S, P)) return run_wgrad_smallch(x, y, dw, nullptr, workspace, ws_bytes, s, stream);
+    WgDefer d{1, *stride_out};
+    tl_wg_defer = &d;
+#define CALL(G) dispatch_wgrad<G>(x, y, dw, workspace, ws_bytes, s, stream)
+    const int rc = [&]() -> int { GZ_GEOM_DISPATCH(CALL) }();
+#undef CALL
+    tl_wg_defer = nullptr;
+    *nz_out = d.nz;
+    *stride_out = d.stride;
+    return rc;
+}
+
+int gz_reduce_multi_max_jobs(void) { return REDUCE_MAX_JOBS; }
+int gz_reduce_multi_max_sources(void) { return REDUCE_MAX_SRC; }
+size_t gz_reduce_multi_table_bytes(void) { return sizeof(ReduceTable); }
+
+/* table_host: a ReduceTable filled through gz_reduce_multi_add (host memory; copied into the kernel argument) */
+int gz_reduce_multi_add(void* table_host, float* out, long long count, int beta, const float* slabs, int nz,
+                        long long stride) {
+    ReduceTable* t = reinterpret_cast<ReduceTable*>(table_host);
+    if (!t || !out || !slabs || count <= 0 || (count & 3) || (stride & 3) || nz < 1 ||
+        (((uintptr_t)out | (uintptr_t)slabs) & 15))
+        return GZ_ERR_BAD_SHAPE;
+    for (int j = 0; j < t->njobs; ++j)
+        if (t->jobs[j].out == out) {            // another contribution to the same gradient
+            ReduceJob& jb = t->jobs[j];
+            if (jb.count != count || jb.nsrc >= REDUCE_MAX_SRC) return GZ_ERR_UNSUPPORTED;
+            jb.src[jb.nsrc++] = ReduceSrc{slabs, stride, nz, 0};
+            return GZ_OK;
+        }
+    if (t->njobs >= REDUCE_MAX_JOBS) return GZ_ERR_UNSUPPORTED;
+    ReduceJob& jb = t->jobs[t->njobs++];
+    jb.out = out;
+    jb.count = count;
+    jb.beta = beta ? 1 : 0;
+    jb.nsrc = 1;
+    jb.block0 = 0;
+    jb.src[0] = ReduceSrc{slabs, stride, nz, 0};
+    return GZ_OK;
+}
+
+int gz_reduce_multi(void* table_host, hipStream_t stream) {
+    gz::clear_stale_error();
+    ReduceTable* t = reinterpret_cast<ReduceTable*>(table_host);
+    if (!t || t->njobs <= 0 || t->njobs > REDUCE_MAX_JOBS) return GZ_ERR_BAD_SHAPE;
+    long long blocks = 0;
+    for (int j = 0; j < t->njobs; ++j) {
+        t->jobs[j].block0 = (int)blocks;
+        blocks += (t->jobs[j].count + 255) / 256;
+    }
+    if (blocks <= 0 || blocks >= (1ll << 31)) return GZ_ERR_TOO_LARGE;
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, *t);
+    return launch_status();
+}
+
 // ---- convolution + BatchNorm statistics in one launch --------------------------------------------------------
 static int stats_wm(TileId t) { return t == T128x32 ? 4 : 2; }
 static int stats_tm_rows(TileId t, long long M) {       // partial rows per phase: tiles_m * WM
@@ -1969,7 +2092,7 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
         // the LDS-DMA weight gradient with the generic raw-row image (needs H = S * OH, rows of 4 / 8 / 16k pixels)
         ConvShape s{N, C, H, W, K, OH, OW};
         const bool shape_ok = H == S * OH && W == S * OW && (W & 3) == 0 && (OW == 4 || OW == 8 || OW % 16 == 0) &&
-                              !getenv("GZ_NO_IGEMM2W") && !getenv("GZ_NO_IGEMM2WG");
+                              !knobs().no_igemm2w && !knobs().no_igemm2wg;
         const int sp = !shape_ok ? 0 : KH == 5 ? wgrad2_splits<G5522>(s) : wgrad2_splits<G3311>(s);
         if (sp > 0) return wgrad2_narrow(s) ? T128x256 : T256x128;
     }
@@ -1984,6 +2107,123 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
     int f = forced_tile();
     if (f >= 0 && f <= 3 && !(f == T128x128 && NTOT <= 64)) t = f;
     return t;
+}
+
+/* ---- which kernel a launch takes, as text (round 4: the dispatch is pinned by tests/test_dispatch_plan.py) ---------
+ * Runs on the CPU (no HIP call).  Describes the launch for 16-byte aligned tensors and a workspace of the advertised
+ * size -- an unaligned view or a missing workspace falls back to the element-wise loaders / an unsplit plan. */
+}  // extern "C" (the describe_* templates need C++ linkage)
+
+static const char* tile_text(TileId t) {
+    switch (t) {
+        case T128x128: return "128x128";
+        case T128x64: return "128x64";
+        case T128x32: return "128x32";
+        case T64x64: return "64x64";
+        case T256x256: return "256x256";
+        case T256x128: return "256x128";
+        case T512x64: return "512x64";
+        default: return "128x256";
+    }
+}
+
+template <class G>
+static int describe_fwd(const ConvShape& s, char* b, size_t n) {
+    if (G::kh == 3 && G::kw == 3 && G::s == 1 && G::p == 1 && conv3_smallch_ok(s.N, s.C, s.K, s.H, s.W))
+        return snprintf(b, n, "F direct conv3x3_smallch<mfma16x16x4>");
+    const SplitPlan sp = fwd_plan<G>(s);
+    const int rows = gz_conv2d_fwd_stats_rows(s.N, s.C, s.H, s.W, s.K, s.OH, s.OW, G::kh, G::kw, G::s, G::p);
+    if (is_tile2(sp.tile)) {
+        const bool rowsA = fwd2_ok<G>(s);
+        const int kdim = rowsA ? s.C * 16 : G::kh * G::kw * round_bk(s.C);
+        return snprintf(b, n, "F igemm2<%s> %s slabs=%d bn_stats_rows=%d", tile_text(sp.tile),
+                        rowsA ? "ConvFwdA2(raw rows, LDS-DMA 16B)" : "ConvTapA2(gather, LDS-DMA 4B)",
+                        split_nz(kdim, sp.splits), rows);
+    }
+    const char* loader = "ConvFwdALoader";
+    const int bm = sp.tile == T64x64 ? 64 : 128;
+    if (BK % (G::kh * G::kw) != 0 && fwd_tap_major(s.C, G::kh, G::kw)) loader = "ConvFwdALoaderTap";
+    else if (G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1)
+        loader = (!knobs().no_row4 && s.W == 2 * s.OW && s.H == 2 * s.OH && s.OW >= 16 && s.OW <= bm && bm % s.OW == 0)
+                     ? "ConvFwdALoaderRow4" : "ConvFwdALoaderK4V";
+    return snprintf(b, n, "F igemm<%s> %s slabs=%d bn_stats_rows=%d", tile_text(sp.tile), loader,
+                    split_nz(fwd_kdim<G>(s), sp.splits), rows);
+}
+
+template <class G>
+static int describe_dgrad(const ConvShape& s, char* b, size_t n) {
+    if (s.H % G::s || s.W % G::s) return snprintf(b, n, "Dg unsupported (H, W not multiples of the stride)");
+    if (G::kh == 3 && G::kw == 3 && G::s == 1 && G::p == 1 && conv3_smallch_ok(s.N, s.K, s.C, s.H, s.W))
+        return snprintf(b, n, "Dg direct conv3x3_smallch<mfma16x16x4>");
+    const long long M = (long long)s.N * s.OH * s.OW;
+    if (dgrad_direct<G>(nullptr, s)) {
+        if (!knobs().smallc_one_pos && s.OW % 4 == 0 && 64 % (s.OW / 4) == 0)
+            return snprintf(b, n, "Dg direct dgrad_smallc4_k4s2p1<C=%d,KS=%d>", s.C,
+                            (M / 4 < knobs().smallc_split_below && s.K >= 16) ? 4 : 1);
+        return snprintf(b, n, "Dg direct dgrad_smallc_k4s2p1<C=%d>", s.C);
+    }
+    if (G::kh == 5 && G::kw == 5 && G::s == 2 && G::p == 2 && dgrad_direct5_ok(nullptr, nullptr, s))
+        return snprintf(b, n, "Dg direct dgrad_smallc4_k5s2p2<C=%d,KS=%d>", s.C, M / 4 < knobs().smallc_split_below ? 4 : 1);
+    constexpr int TAPS = ((G::kh + G::s - 1) / G::s) * ((G::kw + G::s - 1) / G::s);
+    const SplitPlan sp = dgrad_plan<G>(s);
+    const int rows = gz_conv2d_dgrad_stats_rows(s.N, s.C, s.H, s.W, s.K, s.OH, s.OW, G::kh, G::kw, G::s, G::p);
+    const bool tapm = dgrad_tap_major(s.K, G::kh, G::kw, G::s);
+    const int kk = tapm ? round_bk(s.K) : s.K;
+    if (is_tile2(sp.tile)) {
+        const bool rowsA = dgrad2_ok<G>(s);
+        return snprintf(b, n, "Dg igemm2<%s> %s splits=%d bn_stats_rows=%d", tile_text(sp.tile),
+                        rowsA ? "ConvDgA2(row-shared, LDS-DMA 16B)" : "ConvDgTapA2(gather, LDS-DMA 4B)", sp.splits, rows);
+    }
+    const char* loader = "ConvDgALoader";
+    if (tapm && !(G::kh % G::s == 0 && G::kw % G::s == 0 && BK % TAPS == 0)) loader = "ConvDgALoaderTap";
+    else if (G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1 && !knobs().no_row4 && (s.W / 2) % 4 == 0)
+        loader = "ConvDgALoaderRow4";
+    return snprintf(b, n, "Dg igemm<%s> %s splits=%d bn_stats_rows=%d", tile_text(sp.tile), loader,
+                    sp.splits > 1 ? sp.splits : 1, rows);
+    (void)kk;
+}
+
+template <class G>
+static int describe_wgrad(const ConvShape& s, char* b, size_t n) {
+    if (wgrad_smallch_ok(s, G::kh, G::kw, G::s, G::p))
+        return snprintf(b, n, "Wg direct wgrad_smallch_k3<mfma16x16x4> slabs=%d", wgrad_smallch_blocks(s));
+    TileId t = (TileId)gz_conv2d_tile(2, s.N, s.C, s.H, s.W, s.K, s.OH, s.OW, G::kh, G::kw, G::s);
+    const int chunks = (s.N * s.OH * s.OW + BK - 1) / BK;
+    const int NTOT = s.C * G::kh * G::kw;
+    if (t == T256x128 || t == T128x256) {
+        const int splits = wgrad2_splits<G>(s);
+        if (splits > 0) {
+            const int cw = wgrad2w_cw_shape<G>(s);
+            const int cps = (chunks + splits - 1) / splits, nz = (chunks + cps - 1) / cps;
+            if (cw)
+                return snprintf(b, n, "Wg igemm2w<%s> %s<CW=%d>(both operands LDS-DMA) slabs=%d", tile_text(t),
+                                (G::kh == 4 && G::kw == 4) ? "WgImgB2" : "WgImgBG", cw, nz);
+            if (G::kh == 4 && G::kw == 4)
+                return snprintf(b, n, "Wg igemm2r<%s> WgALoaderRow+WgBLoaderRow(register-staged) slabs=%d", tile_text(t), nz);
+        }
+        t = T128x128;
+    }
+    const int bm = t == T64x64 ? 64 : 128, bn = t == T128x128 ? 128 : (t == T128x32 ? 32 : 64);
+    const long long tiles = (long long)((s.K + bm - 1) / bm) * ((NTOT + bn - 1) / bn);
+    const int splits = wgrad_splits(tiles, chunks, bm * bn >= 128 * 128);
+    const int cps = (chunks + splits - 1) / splits, nz = (chunks + cps - 1) / cps;
+    WgRowGeom rg;
+    const bool row = !knobs().wg_generic && wg_row_geom<G>(s, &rg);
+    return snprintf(b, n, "Wg igemm<%s> %s slabs=%d", tile_text(t), row ? "WgALoaderRow+WgBLoaderRow" : "WgALoader+WgBLoader", nz);
+}
+
+extern "C" {
+
+int gz_conv2d_plan(int op, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, char* buf,
+                   int buflen) {
+    if (!buf || buflen <= 0) return GZ_ERR_BAD_SHAPE;
+    buf[0] = 0;
+    ConvShape s{N, C, H, W, K, OH, OW};
+    if (!shape_ok(s, KH, KW, S, P) || op < 0 || op > 2) return GZ_ERR_BAD_SHAPE;
+    const size_t n = (size_t)buflen;
+#define CALL(G) (op == 0 ? describe_fwd<G>(s, buf, n) : op == 1 ? describe_dgrad<G>(s, buf, n) : describe_wgrad<G>(s, buf, n))
+    GZ_GEOM_DISPATCH(CALL)
+#undef CALL
 }
 
 size_t gz_gemm_workspace_bytes(int M, int N, int K) {

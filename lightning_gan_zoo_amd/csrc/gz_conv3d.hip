@@ -15,7 +15,7 @@ static inline int r4(int v) { return (v + 3) & ~3; }
 
 // split-K of under-filled F / Dg launches: same policy as gz_conv.hip (plan_split)
 static int plan3(int tile, long long M, long long N, int Kdim, int ny) {
-    static int off = getenv("GZ_NO_SPLITK") ? 1 : 0;
+    const bool off = knobs().no_splitk;
     if (off) return 1;
     const int bm = tile == 3 ? 64 : 128, bn = tile == 0 ? 128 : (tile == 2 ? 32 : 64);
     const long long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * ny;
@@ -40,8 +40,8 @@ struct DgPlan3 {
 
 static DgPlan3 plan3_dg(int tile, long long Mp, long long C, int K, int KS, int S, int P) {
     DgPlan3 none{1, 0};
-    static int off = getenv("GZ_NO_SPLITK") ? 1 : 0;
-    static int even = getenv("GZ_DG3_EVEN_SPLIT") ? 1 : 0;      // experiment: the round-1 plan (same slab count per phase)
+    const bool off = knobs().no_splitk;
+    const bool even = knobs().dg3_even_split;      // experiment: the round-1 plan (same slab count per phase)
     const int bm = tile == 3 ? 64 : 128, bn = tile == 0 ? 128 : (tile == 2 ? 32 : 64);
     const long long tp = ((Mp + bm - 1) / bm) * ((C + bn - 1) / bn);
     int pc[8], maxpc = 0;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void transpose_pad3_kernel(const float* __rest
 
 // forward weights in tap-major order (Conv3DFwdALoaderTap): wp[(tap, c)][ld] = w[ko][c][tap], c padded to BK
 static bool fwd3_tap_major(int C) {
-    static int off = getenv("GZ_NO_TAPMAJOR") ? 1 : 0;
+    const bool off = knobs().no_tapmajor;
     return !off && C >= BK;
 }
 
@@ -193,7 +193,7 @@ static int run_dgrad3(const float* y, const float* wp, const float* bias, float*
 }
 
 static int splits3(long long tiles, int chunks) {
-    static int target = getenv("GZ_WG3_TARGET") ? atoi(getenv("GZ_WG3_TARGET")) : 1024;
+    const int target = knobs().wg3_target;
     if (tiles >= 256) return 1;
     long long want = (target + tiles - 1) / tiles;
     long long cap = chunks / 8 > 0 ? chunks / 8 : 1;
@@ -349,7 +349,7 @@ int gz_conv3d_wgrad(const float* x, const float* y, float* dw, float* workspace,
     if (big3((long long)N * C * D * H * W) || big3((long long)N * K * OD * OH * OW)) return GZ_ERR_TOO_LARGE;
     long long NTOT = (long long)C * KS * KS * KS;
     int t = NTOT <= 32 ? 2 : ((NTOT <= 64 || K <= 64) ? (K <= 64 ? 3 : 1) : 0);
-    static int force = getenv("GZ_WG3_TILE") ? atoi(getenv("GZ_WG3_TILE")) : -1;      // experiment
+    const int force = knobs().wg3_tile;      // experiment
     if (force >= 0 && t == 0) t = force;
 #define CALL(CFG) run_wgrad3<CFG, 3, 2, 1>(x, y, dw, workspace, ws_bytes, s, stream)
     GZ3_TILE_SWITCH(t, CALL)

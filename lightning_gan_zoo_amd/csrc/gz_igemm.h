@@ -28,6 +28,7 @@
 //   void store(const Params&, acc, m_base, n_base, lane, y, z);
 #pragma once
 #include "gz_common.h"
+#include "gz_knobs.h"
 #include <type_traits>
 
 namespace gz {
@@ -2127,8 +2128,7 @@ inline int launch_igemm(const typename AL::Params& pa, const typename BL::Params
                         const typename Epi::Params& pe, int M, int N, int K, int ny, int splits,
                         hipStream_t stream, float* slab = nullptr, const int* phase_chunks = nullptr) {
     GridMap gm;
-    static int no_swz = getenv("GZ_NO_XCD_SWIZZLE") ? 1 : 0;
-    gm.no_swizzle = no_swz;
+    gm.no_swizzle = knobs().no_xcd_swizzle;
     gm.stagger = 0;
     gm.var_chunks = 0;
     if (phase_chunks && ny <= 8) {
@@ -2165,7 +2165,7 @@ inline int launch_igemm(const typename AL::Params& pa, const typename BL::Params
         gm.phase_slab0[i] = sm.slab0[i] = at;
         at += n;
     }
-    static int dyn_lds = getenv("GZ_DYN_LDS") ? atoi(getenv("GZ_DYN_LDS")) : 0;   // experiment: throttle workgroups per CU
+    const int dyn_lds = knobs().dyn_lds;   // experiment: throttle workgroups per CU
     hipLaunchKernelGGL((igemm_kernel<Cfg, AL, BL, Epi>), grid, dim3(NT), dyn_lds, stream, pa, pb, pe, gm);
     if (gm.slab) {
         const int fm = (M + 31) / 32, fn = (N + 31) / 32;
@@ -3293,8 +3293,7 @@ template <class Cfg, class BL, class Epi>
 inline int launch_igemm2w(const Wg2Params& p, const typename Epi::Params& pe, int M, int N, int K, int splits,
                           hipStream_t stream) {
     GridMap gm;
-    static int no_swz = getenv("GZ_NO_XCD_SWIZZLE") ? 1 : 0;
-    gm.no_swizzle = no_swz;
+    gm.no_swizzle = knobs().no_xcd_swizzle;
     gm.var_chunks = 0;
     gm.slab = nullptr;
     gm.slab_m = M;
@@ -3328,8 +3327,7 @@ template <class Cfg, class AL, class BL, class Epi>
 inline int launch_igemm2r(const typename AL::Params& pa, const typename BL::Params& pb, const typename Epi::Params& pe,
                           int M, int N, int K, int splits, hipStream_t stream) {
     GridMap gm;
-    static int no_swz = getenv("GZ_NO_XCD_SWIZZLE") ? 1 : 0;
-    gm.no_swizzle = no_swz;
+    gm.no_swizzle = knobs().no_xcd_swizzle;
     gm.var_chunks = 0;
     gm.slab = nullptr;
     gm.slab_m = M;
@@ -3369,8 +3367,7 @@ inline int launch_igemm2(const typename AL::Params& pa, const typename BL::Param
                          const int* phase_chunks = nullptr) {
     static_assert(Epi::SWAP, "transposed accumulators (lanes along m)");
     GridMap gm;
-    static int no_swz = getenv("GZ_NO_XCD_SWIZZLE") ? 1 : 0;
-    gm.no_swizzle = no_swz;
+    gm.no_swizzle = knobs().no_xcd_swizzle;
     gm.var_chunks = 0;
     if (phase_chunks && ny <= 8) {
         gm.var_chunks = 1;
@@ -3402,7 +3399,7 @@ inline int launch_igemm2(const typename AL::Params& pa, const typename BL::Param
     // two in lockstep would take 524 k -- and a forced half-tile offset changes neither the layer (143.3 -> 142.8
     // TFLOP/s) nor the step (21.43 vs 21.40 ms).  What a launch does lose is its ramp: ~19 us until the first
     // round's prologues are through plus the last round's tail, ~6 % of a 1 ms launch.
-    static const int stagger_pct = getenv("GZ_IGEMM2_STAGGER") ? atoi(getenv("GZ_IGEMM2_STAGGER")) : 0;
+    const int stagger_pct = knobs().igemm2_stagger;
     gm.stagger = (Cfg::OCC == 2 && nz == 1 && grid.x >= 1536)
                      ? (int)((long long)gm.chunks * 8 * Cfg::TM * Cfg::TN * 64 * 2 * stagger_pct / 100) : 0;
     if (slab && nz > 1) gm.slab = slab;
@@ -3414,7 +3411,7 @@ inline int launch_igemm2(const typename AL::Params& pa, const typename BL::Param
         gm.phase_slab0[i] = sm.slab0[i] = at;
         at += n;
     }
-    static const size_t lds_extra = getenv("GZ_IGEMM2_LDS") ? (size_t)atoi(getenv("GZ_IGEMM2_LDS")) : 0;   // experiment:
+    const size_t lds_extra = (size_t)knobs().igemm2_lds;   // experiment:
     const size_t lds = igemm2_lds_bytes<Cfg, AL, BL>() + lds_extra;             // throttles workgroups per CU
     auto kern = igemm2_kernel<Cfg, AL, BL, Epi>;
     static bool attr_done = false;       // per instantiation

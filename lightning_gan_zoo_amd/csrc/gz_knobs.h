@@ -1,0 +1,93 @@
+// Every run-time switch of the kernel library, in ONE struct that is filled ONCE (first use).
+//
+// Product behaviour never depends on the environment: the struct holds the shipped defaults unless the process was
+// started with GZ_EXPERIMENTS=1, in which case each field may be overridden by the GZ_* variable named next to it
+// (the measurement helpers under tools/ set both).  The launchers read `knobs().field`; no launcher calls getenv.
+// The two settings a product caller may change go through the C ABI instead (include/gz_ops.h): gz_set_cu_budget.
+#pragma once
+#include <stdlib.h>
+#include <string.h>
+
+namespace gz {
+
+// X(type, field, environment variable, default)
+#define GZ_KNOB_LIST(X)                                                                                               \
+    /* tile / skeleton choice */                                                                                      \
+    X(bool, no_igemm2, "GZ_NO_IGEMM2", false)               /* keep everything on igemm_kernel (round 2) */         \
+    X(bool, no_igemm2_tap, "GZ_NO_IGEMM2_TAP", false)       /* ... the gather-loader launches only */               \
+    X(bool, no_igemm2_wg, "GZ_NO_IGEMM2_WG", false)         /* ... the weight gradients only */                     \
+    X(bool, no_igemm2w, "GZ_NO_IGEMM2W", false)             /* register-staged instead of LDS-DMA weight gradient */ \
+    X(bool, no_igemm2wg, "GZ_NO_IGEMM2WG", false)           /* ... its generic-geometry image only */               \
+    X(int, igemm2_tile, "GZ_IGEMM2_TILE", 0)                /* 128 / 256: force the igemm2 N tile */                 \
+    X(int, tile, "GZ_TILE", -1)                             /* 0..3: force the igemm_kernel tile */                  \
+    X(int, min_wgs, "GZ_MIN_WGS", 0)                        /* > 0: the round-1 tile rule with this target */        \
+    X(bool, no_big_split, "GZ_NO_BIG_SPLIT", false)                                                                   \
+    X(bool, no_splitk, "GZ_NO_SPLITK", false)                                                                         \
+    X(int, split_target, "GZ_SPLIT_TARGET", 1024)                                                                     \
+    X(int, split_below, "GZ_SPLIT_BELOW", 512)                                                                        \
+    X(bool, no_tapmajor, "GZ_NO_TAPMAJOR", false)                                                                     \
+    X(bool, no_row4, "GZ_NO_ROW4", false)                                                                             \
+    X(int, fwd2_min_tiles, "GZ_FWD2_MIN_TILES", 16)                                                                   \
+    X(int, dg2_min_tiles, "GZ_DG2_MIN_TILES", 64)                                                                     \
+    X(int, tap_wgs, "GZ_TAP_WGS", 384)                                                                                \
+    X(int, tap_cps_max, "GZ_TAP_CPS_MAX", 96)                                                                         \
+    X(int, wg_target, "GZ_WG_TARGET", 1024)                                                                           \
+    X(int, wg2_min_chunks, "GZ_WG2_MIN_CHUNKS", 0)                                                                    \
+    X(bool, wg_generic, "GZ_WG_GENERIC", false)                                                                       \
+    /* direct kernels */                                                                                              \
+    X(bool, no_smallc, "GZ_NO_SMALLC", false)                                                                         \
+    X(bool, no_smallc5, "GZ_NO_SMALLC5", false)                                                                       \
+    X(bool, smallc_one_pos, "GZ_SMALLC_ONE_POS", false)                                                               \
+    X(long long, smallc_split_below, "GZ_SMALLC_SPLIT_BELOW", 36 * 1024)                                              \
+    X(bool, no_smallch_conv, "GZ_NO_SMALLCH_CONV", false)                                                             \
+    X(bool, no_smallch_wg, "GZ_NO_SMALLCH_WG", false)                                                                 \
+    X(int, c3_gpw, "GZ_C3_GPW", 4)                                                                                    \
+    /* launch shape experiments */                                                                                    \
+    X(bool, no_xcd_swizzle, "GZ_NO_XCD_SWIZZLE", false)                                                               \
+    X(int, dyn_lds, "GZ_DYN_LDS", 0)                                                                                  \
+    X(int, igemm2_stagger, "GZ_IGEMM2_STAGGER", 0)                                                                    \
+    X(int, igemm2_lds, "GZ_IGEMM2_LDS", 0)                                                                            \
+    /* 3-D convolutions, normalisation, resampling */                                                                 \
+    X(bool, dg3_even_split, "GZ_DG3_EVEN_SPLIT", false)                                                               \
+    X(int, wg3_target, "GZ_WG3_TARGET", 1024)                                                                         \
+    X(int, wg3_tile, "GZ_WG3_TILE", -1)                                                                               \
+    X(bool, norm_unfused, "GZ_NORM_UNFUSED", false)                                                                   \
+    X(int, norm_bwd_cache, "GZ_NORM_BWD_CACHE", 4)                                                                    \
+    X(bool, resample_fwd_direct, "GZ_RESAMPLE_FWD_DIRECT", false)                                                     \
+    X(int, resample_bwd_mode, "GZ_RESAMPLE_BWD", 0)         /* 1 "scatter" (round 1), 2 "gather" */
+
+struct Knobs {
+    bool experiments;       // GZ_EXPERIMENTS=1: the fields below were read from the environment
+#define GZ_KNOB_FIELD(type, name, env, dflt) type name;
+    GZ_KNOB_LIST(GZ_KNOB_FIELD)
+#undef GZ_KNOB_FIELD
+};
+
+inline void knob_read(bool& v, const char* e) { v = e != nullptr; }
+inline void knob_read(int& v, const char* e) {
+    if (!e) return;
+    if (!strcmp(e, "scatter")) v = 1;
+    else if (!strcmp(e, "gather")) v = 2;
+    else v = atoi(e);
+}
+inline void knob_read(long long& v, const char* e) { if (e) v = atoll(e); }
+
+inline const Knobs& knobs() {
+    static const Knobs k = [] {
+        Knobs n;
+#define GZ_KNOB_INIT(type, name, env, dflt) n.name = dflt;
+        GZ_KNOB_LIST(GZ_KNOB_INIT)
+#undef GZ_KNOB_INIT
+        const char* on = getenv("GZ_EXPERIMENTS");
+        n.experiments = on && on[0] && on[0] != '0';
+        if (n.experiments) {
+#define GZ_KNOB_ENV(type, name, env, dflt) knob_read(n.name, getenv(env));
+            GZ_KNOB_LIST(GZ_KNOB_ENV)
+#undef GZ_KNOB_ENV
+        }
+        return n;
+    }();
+    return k;
+}
+
+}  // namespace gz

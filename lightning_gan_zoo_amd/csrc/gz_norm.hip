@@ -9,6 +9,7 @@
 // elementwise apply, so each tensor is streamed once per pass with 16-byte accesses.
 // `per_channel` = 1 selects coefficient index row % C (BatchNorm), 0 selects the row itself.
 #include "gz_common.h"
+#include "gz_knobs.h"
 #include "../../include/gz_ops.h"
 
 namespace gz {
@@ -866,10 +867,10 @@ int gz_norm_act_bwd(const float* gout, const float* x, const float* coef, float*
     if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
     RowGeom rg = row_geom((long long)N * C, inner);
     ApplyGeom g = apply_geom(N, C, inner, per_channel);
-    static const bool unfused = getenv("GZ_NORM_UNFUSED") != nullptr;      // experiment: the three-launch path
+    const bool unfused = knobs().norm_unfused;      // experiment: the three-launch path
     if (!per_channel && !unfused) {
         const bool channel_affine = !affine_per_row && (dgamma || dbeta);
-        static const int max_cache = getenv("GZ_NORM_BWD_CACHE") ? atoi(getenv("GZ_NORM_BWD_CACHE")) : 4;
+        const int max_cache = knobs().norm_bwd_cache;
         const int per_lane = (rg.q4 + rg.lpr - 1) / rg.lpr;
 #define GZ_RB(CACHE)                                                                                                  \
     hipLaunchKernelGGL(rownorm_bwd_fused_kernel<CACHE>, dim3(row_grid(rg)), dim3(PW_THREADS), 0, stream, gout, x, coef, \

@@ -7,6 +7,7 @@
 // HBM-bound gather (forward) / float-atomic scatter-add (backward; 8 adds of 4 B per output element).
 #include <cstdlib>
 #include "gz_common.h"
+#include "gz_knobs.h"
 #include "../../include/gz_ops.h"
 
 namespace gz {
@@ -360,7 +361,7 @@ int gz_rigid_resample_fwd(const float* vox, const float* minv, float* out2d, lon
     if (N <= 0 || C <= 0 || S <= 0) return GZ_ERR_BAD_SHAPE;
     const int S3 = S * S * S;
     const size_t lds = (size_t)FW_LC * S3 * sizeof(float);
-    static const bool direct = getenv("GZ_RESAMPLE_FWD_DIRECT") != nullptr;      // experiment: the round-1 kernel
+    const bool direct = knobs().resample_fwd_direct;      // experiment: the round-1 kernel
     if (!idx_out && !direct && S3 % 4 == 0 && lds <= 64 * 1024 && (((uintptr_t)vox) & 15) == 0) {
         hipLaunchKernelGGL(resample_fwd_staged_kernel, dim3(N, (C + FW_LC - 1) / FW_LC), dim3(RS_THREADS), lds, stream,
                            vox, minv, out2d, N, C, S);
@@ -381,7 +382,7 @@ int gz_rigid_resample_bwd(const float* gout2d, const float* minv, float* gvox, f
                           int N, int C, int S, hipStream_t stream) {
     gz::clear_stale_error();
     if (N <= 0 || C <= 0 || S <= 0) return GZ_ERR_BAD_SHAPE;
-    static const char* mode = getenv("GZ_RESAMPLE_BWD");      // experiments: "scatter" (round 1), "gather"
+    const int mode = knobs().resample_bwd_mode;      // experiments: 1 "scatter" (round 1), 2 "gather"
     const int S3 = S * S * S;
     const size_t lds_staged = (size_t)LC * S3 * sizeof(float);
     if (!mode && workspace && ws_bytes >= gz_rigid_resample_bwd_workspace_bytes(N, S) && S3 % 4 == 0 &&
@@ -402,7 +403,7 @@ int gz_rigid_resample_bwd(const float* gout2d, const float* minv, float* gvox, f
                            flag);
         return launch_status();
     }
-    if (!mode || mode[0] == 'g') {
+    if (!mode || mode == 2) {
         dim3 grid((S3 + RS_THREADS - 1) / RS_THREADS, N, (C + BG_CH - 1) / BG_CH);
         hipLaunchKernelGGL(resample_bwd_gather_kernel, grid, dim3(RS_THREADS), 0, stream, gout2d, minv, gvox, N, C, S,
                            (const int*)nullptr);

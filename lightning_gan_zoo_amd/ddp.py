@@ -88,8 +88,11 @@ class GradSync:
         self.measure = bool(os.environ.get("GZ_DDP_MEASURE"))
         self._waits = []              # (optimizer_idx, start event, end event) or (optimizer_idx, seconds)
         self.hooks = [n.register_forward_pre_hook(self._make_hook(i)) for i, n in enumerate(self.nets)]
+        self.net_of = {}              # id(param) -> optimizer_idx
+        self.reported = set()         # parameters whose gradient of the running backward pass is complete
         for idx, fg in enumerate(self.flats):
             for p in fg.params:
+                self.net_of[id(p)] = idx
                 self.hooks.append(p.register_post_accumulate_grad_hook(self._make_grad_hook(idx)))
 
     def _make_hook(self, idx):
@@ -99,14 +102,35 @@ class GradSync:
 
     def _make_grad_hook(self, idx):
         def hook(p):
-            if self.active != idx or not self.overlap:
-                return
-            b = self.flats[idx].bucket_of[id(p)]
-            self.remaining[idx][b] -= 1
-            if self.remaining[idx][b] == 0:
-                self._issue(idx, b)
-                self.stats["buckets_from_hooks"] += 1
+            self._param_ready(idx, p)
         return hook
+
+    def sink_listener(self, p):
+        """functional's gradient sinks (harness.Trainer turns them on): every weight-gradient launch of this backward
+        pass that feeds ``p`` has been queued -- the parameter counts as delivered; its slabs are summed into the flat
+        buffer (one gz_reduce_multi launch per bucket) right before the bucket's all-reduce is issued."""
+        idx = self.net_of.get(id(p))
+        if idx is not None:
+            self._param_ready(idx, p)
+
+    def _param_ready(self, idx, p):
+        if self.active != idx or not self.overlap or id(p) in self.reported:
+            return
+        self.reported.add(id(p))
+        fg = self.flats[idx]
+        b = fg.bucket_of[id(p)]
+        self.remaining[idx][b] -= 1
+        if self.remaining[idx][b] == 0:
+            self._flush_sinks(fg.params[fg.buckets[b][2]:fg.buckets[b][3]])
+            self._issue(idx, b)
+            self.stats["buckets_from_hooks"] += 1
+
+    @staticmethod
+    def _flush_sinks(params=None):
+        from . import functional as F
+        if params is not None and not params[0].is_cuda:
+            return
+        F.flush_grad_sinks(params)
 
     def _reduces(self):
         return self.world > 1 or self.always_reduce
@@ -133,9 +157,12 @@ class GradSync:
                                          for (_, _, lo, hi) in fg.buckets]
         self.works[optimizer_idx] = []
         self.issued[optimizer_idx] = set()
+        self.reported = set()
 
     def after_backward(self, optimizer_idx, optimizer):
         fg = self.flats[optimizer_idx]
+        if fg.flat.is_cuda:
+            self._flush_sinks()          # whatever no complete bucket has claimed yet
         fg.rebind()
         self.active = None
         for b in range(len(fg.buckets)):       # whatever the hooks did not cover (unused parameters, overlap off)

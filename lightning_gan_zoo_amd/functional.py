@@ -384,6 +384,139 @@ def _conv_wgrad_raw(x, g, geom, with_bias=False):
     return dw
 
 
+# ---------------------------------------------------------------------------
+# gradient sinks (round 4): weight gradients go straight into ``p.grad``
+# ---------------------------------------------------------------------------
+# torch's AccumulateGrad adds every contribution to an existing ``p.grad`` with a launch of its own (the discriminator
+# is applied twice per D step: 11 `add_` per DCGAN pair; under data parallelism ``p.grad`` is a view of the flat
+# exchange buffer, so EVERY gradient pays one: 25 per pair), and every split weight-gradient launch is followed by its
+# own slab reduction.  With sinks on (harness.Trainer / ddp.GradSync turn them on; the Lightning drop-in route and
+# plain ``loss.backward()`` users keep autograd's behaviour), a first-order backward
+#   * leaves the slabs of a split weight-gradient launch unreduced (gz_conv2d_wgrad_partial) and returns None to
+#     autograd for that parameter,
+#   * ``flush_grad_sinks()`` -- called once after backward, or per gradient bucket by GradSync -- sums the slabs of all
+#     pending parameters in ONE launch (gz_reduce_multi), writing a fresh ``p.grad`` (beta 0) or accumulating into the
+#     existing one (beta 1: gradient accumulation, the flat exchange buffer).
+# Double-backward graphs (create_graph=True) never take this path.
+class _SinkState:
+    enabled = False
+    listener = None           # callable(param): every contribution of this backward pass has been queued
+    pending = {}              # id(param) -> [param, [(slabs, nz, stride), ...]]
+    uses = {}                 # id(param) -> forward uses not yet matched by a backward contribution
+
+
+_sinks = _SinkState()
+
+
+def set_grad_sinks(enabled, listener=None):
+    """Turn the direct-to-``p.grad`` weight-gradient path on / off; returns the previous (enabled, listener)."""
+    old = (_sinks.enabled, _sinks.listener)
+    flush_grad_sinks()
+    _sinks.enabled, _sinks.listener = bool(enabled), listener
+    _sinks.uses.clear()
+    return old
+
+
+def grad_sinks_enabled():
+    return _sinks.enabled
+
+
+def reset_grad_sink_uses():
+    """Forget forward uses that never met their backward (a graph that was dropped): called at the top of a step."""
+    _sinks.uses.clear()
+
+
+def _sink_note_use(w):
+    if _sinks.enabled and w.requires_grad and torch.is_grad_enabled() and isinstance(w, torch.nn.Parameter):
+        _sinks.uses[id(w)] = _sinks.uses.get(id(w), 0) + 1
+
+
+def _sink_done(w):
+    """One forward use of ``w`` has delivered its gradient (through the sink or through autograd)."""
+    k = id(w)
+    n = _sinks.uses.get(k)
+    if n is None:
+        return
+    if n > 1:
+        _sinks.uses[k] = n - 1
+        return
+    del _sinks.uses[k]
+    if _sinks.listener is not None and k in _sinks.pending:
+        _sinks.listener(w)
+
+
+def _sink_conv_wgrad(w, x, g, geom):
+    """The weight gradient of a convolution into the sink of parameter ``w``; False = not taken (the caller computes
+    it the ordinary way).  x / g are the operands gz_conv2d_wgrad takes."""
+    if not _sinks.enabled or not isinstance(w, torch.nn.Parameter) or (w.numel() & 3):
+        return False
+    N, C, H, W = x.shape
+    _, K, OH, OW = g.shape
+    nbytes = lib.gz_conv2d_wgrad_workspace_bytes(N, C, H, W, K, OH, OW, geom.kh, geom.kw)
+    if not nbytes:
+        return False
+    ws = _ws(nbytes // 4, x.device)
+    dw = torch.empty((K, C, geom.kh, geom.kw), device=x.device, dtype=torch.float32)   # unsplit launches write here
+    nz, stride = ctypes.c_int(0), ctypes.c_longlong(0)
+    _timed(2, (N, C, H, W, K, OH, OW), geom, 2.0 * N * OH * OW * K * C * geom.kh * geom.kw, lambda: check(
+        lib.gz_conv2d_wgrad_partial(_p(x), _p(g), _p(dw), _p(ws), nbytes, N, C, H, W, K, OH, OW, geom.kh, geom.kw,
+                                    geom.stride, geom.pad, ctypes.byref(nz), ctypes.byref(stride), _stream()),
+        "conv2d_wgrad_partial"))
+    src = (ws, nz.value, stride.value) if nz.value > 1 else (dw, 1, w.numel())
+    if src[2] & 3:
+        return False if nz.value <= 1 else _sink_fail("slab stride")
+    _sinks.pending.setdefault(id(w), [w, []])[1].append(src)
+    _sink_done(w)
+    return True
+
+
+def _sink_fail(what):
+    raise RuntimeError("lightning_gan_zoo_amd: gradient sink cannot take this launch (%s)" % what)
+
+
+def flush_grad_sinks(params=None):
+    """Sum the queued weight-gradient slabs into ``p.grad`` -- of ``params`` (an iterable) or of everything pending --
+    with as few gz_reduce_multi launches as the table size allows."""
+    if not _sinks.pending:
+        return
+    if params is None:
+        keys = list(_sinks.pending)
+    else:
+        keys = [id(p) for p in params if id(p) in _sinks.pending]
+    if not keys:
+        return
+    max_jobs, max_src = lib.gz_reduce_multi_max_jobs(), lib.gz_reduce_multi_max_sources()
+    nb = lib.gz_reduce_multi_table_bytes()
+    st = _stream()
+    table, njobs = (ctypes.c_char * nb)(), 0
+    for k in keys:
+        w, srcs = _sinks.pending.pop(k)
+        fresh = w.grad is None
+        target = torch.empty_like(w, memory_format=torch.contiguous_format) if fresh else w.grad
+        if not target.is_contiguous() or target.dtype != torch.float32:
+            _sink_fail("p.grad is not a contiguous float32 tensor")
+        if njobs >= max_jobs:
+            check(lib.gz_reduce_multi(table, st), "reduce_multi")
+            table, njobs = (ctypes.c_char * nb)(), 0
+        for (slabs, nz, stride) in srcs[:max_src]:
+            check(lib.gz_reduce_multi_add(table, _p(target), w.numel(), 0 if fresh else 1, _p(slabs), nz, stride),
+                  "reduce_multi_add")
+        njobs += 1
+        if len(srcs) > max_src:       # more launches contributed than one job holds (not on the benchmarked paths):
+            check(lib.gz_reduce_multi(table, st), "reduce_multi")          # the rest accumulates in launches of its own
+            for lo in range(max_src, len(srcs), max_src):
+                table = (ctypes.c_char * nb)()
+                for (slabs, nz, stride) in srcs[lo:lo + max_src]:
+                    check(lib.gz_reduce_multi_add(table, _p(target), w.numel(), 1, _p(slabs), nz, stride),
+                          "reduce_multi_add")
+                check(lib.gz_reduce_multi(table, st), "reduce_multi")
+            table, njobs = (ctypes.c_char * nb)(), 0
+        if fresh:
+            w.grad = target
+    if njobs:
+        check(lib.gz_reduce_multi(table, st), "reduce_multi")
+
+
 def _act_bwd_raw(g, out, act, slope):
     dx = torch.empty_like(g)
     check(lib.gz_act_bwd(_p(g), _p(out), _p(dx), g.numel(), act, slope, _stream()), "act_bwd")
@@ -472,6 +605,7 @@ class _ConvF(torch.autograd.Function):
         x, w = _req(x, "x"), _req(w, "w")
         ctx.geom, ctx.act, ctx.slope = geom, act, slope
         ctx.has_bias = bias is not None
+        _sink_note_use(w)
         if want_stats:          # BatchNorm follows: no bias, no activation; second output = partial statistics
             y, stats = _conv_fwd_stats_raw(x, w, geom)
             ctx.save_for_backward(x, w, None)
@@ -505,6 +639,8 @@ class _ConvF(torch.autograd.Function):
             dw = _ConvWg.apply(x, gy, geom)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _ChannelSum.apply(gy)
+        if ctx.needs_input_grad[1]:
+            _sink_done(w)
         return dx, dw, db, None, None, None, None
 
     @staticmethod
@@ -518,8 +654,10 @@ class _ConvF(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if want_b:
                 dw, db = _conv_wgrad_raw(x, gy, geom, with_bias=True)
-            else:
+                _sink_done(w)
+            elif not _sink_conv_wgrad(w, x, gy, geom):
                 dw = _conv_wgrad_raw(x, gy, geom)
+                _sink_done(w)
         elif want_b:
             db = _channel_sum_raw(gy)
         return dx, dw, db, None, None, None, None
@@ -533,6 +671,7 @@ class _ConvDg(torch.autograd.Function):
         g, w = _req(g, "g"), _req(w, "w")
         ctx.geom, ctx.act, ctx.slope = geom, act, slope
         ctx.has_bias = bias is not None
+        _sink_note_use(w)
         if want_stats:
             x, stats = _conv_dgrad_stats_raw(g, w, geom, hw)
             ctx.save_for_backward(g, w, None)
@@ -556,7 +695,10 @@ class _ConvDg(torch.autograd.Function):
         if not torch.is_grad_enabled() and _WG_SIDE_FLOPS <= 0:      # no graph is being recorded: raw launches
             v = _req(v)
             dg = _conv_fwd_raw(v, w, None, geom, ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
-            dw = _conv_wgrad_raw(v, g, geom) if ctx.needs_input_grad[1] else None
+            dw = None
+            if ctx.needs_input_grad[1] and not _sink_conv_wgrad(w, v, g, geom):
+                dw = _conv_wgrad_raw(v, g, geom)
+                _sink_done(w)
             db = _channel_sum_raw(v) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
             return dg, dw, db, None, None, None, None, None
         dg = dw = db = None
@@ -569,6 +711,8 @@ class _ConvDg(torch.autograd.Function):
             dw = _ConvWg.apply(v, g, geom)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _ChannelSum.apply(v)
+        if ctx.needs_input_grad[1]:
+            _sink_done(w)
         return dg, dw, db, None, None, None, None, None
 
 

@@ -129,12 +129,19 @@ class Trainer:
     ``grad_sync`` (optional, see ddp.GradSync) averages the active network's gradients over the
     data-parallel ranks between backward and the optimizer step."""
 
-    def __init__(self, module, grad_sync=None):
+    def __init__(self, module, grad_sync=None, grad_sinks=True):
         self.module = module
         self.optim = module.configure_optimizers()
         self.order = optimizer_schedule([o["frequency"] for o in self.optim])
         self.grad_sync = grad_sync
         self.batch_idx = 0
+        # weight gradients straight into p.grad (functional.set_grad_sinks): on for the duration of each step on the
+        # GPU path -- ONE slab-reduction launch per backward pass (per gradient bucket under data parallelism) instead
+        # of one per layer plus autograd's `grad += new` launches
+        self._F = None
+        if grad_sinks and any(p.is_cuda for p in module.parameters()):
+            from . import functional as F
+            self._F = F
 
     def active_optimizer(self, batch_idx=None):
         i = self.batch_idx if batch_idx is None else batch_idx
@@ -146,8 +153,17 @@ class Trainer:
         toggle_optimizer(m, idx)
         if self.grad_sync is not None:
             self.grad_sync.before_step(idx)
-        loss = m.training_step(batch, self.batch_idx, idx)
-        loss.backward()
+        F = self._F
+        if F is not None:
+            prev = F.set_grad_sinks(True, getattr(self.grad_sync, "sink_listener", None))
+        try:
+            loss = m.training_step(batch, self.batch_idx, idx)
+            loss.backward()
+            if F is not None:
+                F.flush_grad_sinks()
+        finally:
+            if F is not None:
+                F.set_grad_sinks(*prev)
         opt = self.optim[idx]["optimizer"]
         if self.grad_sync is not None:
             self.grad_sync.after_backward(idx, opt)
@@ -240,8 +256,13 @@ class GraphedTrainer(Trainer):
 
     def _body(self, idx):
         m = self.module
-        loss = m.training_step(self.static_batch, self.batch_idx, idx)
-        loss.backward()
+        prev = self._F.set_grad_sinks(True)
+        try:
+            loss = m.training_step(self.static_batch, self.batch_idx, idx)
+            loss.backward()
+            self._F.flush_grad_sinks()
+        finally:
+            self._F.set_grad_sinks(*prev)
         self.optim[idx]["optimizer"].step()
         return loss
 

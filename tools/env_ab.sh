@@ -3,6 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 var=$1; shift
+export GZ_EXPERIMENTS=1      # the GZ_* switches are only read then (csrc/gz_knobs.h)
 for v in "$@"; do
   export $var=$v
   timeout 250 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_$v -- python3 bench.py --steps 10 --warmup 2 --reps 1 --no-cpu-baseline --no-sub-configs > gpurun_out/pf_$v.json 2>/dev/null

@@ -1,5 +1,5 @@
 """Host-side cost of one optimizer cycle: enqueue time (no sync inside) vs GPU time, plus a cProfile of the
-enqueue loop.   python tools/host_profile.py <expt> [batch]"""
+enqueue loop.   python tools/host_profile.py <expt> [batch] [img] [--brief]   (--brief: the two timings only)"""
 import cProfile
 import os
 import pstats
@@ -12,9 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-expt = sys.argv[1] if len(sys.argv) > 1 else "wgan_gp"
-batch = int(sys.argv[2]) if len(sys.argv) > 2 else bench.DEFAULT_BATCH[expt]
-img = bench.NATIVE_IMG_SIZE.get(expt, 64)
+brief = "--brief" in sys.argv
+argv = [a for a in sys.argv if a != "--brief"]
+expt = argv[1] if len(argv) > 1 else "wgan_gp"
+batch = int(argv[2]) if len(argv) > 2 else bench.DEFAULT_BATCH[expt]
+img = int(argv[3]) if len(argv) > 3 else bench.NATIVE_IMG_SIZE.get(expt, 64)
 torch.set_num_threads(min(8, torch.get_num_threads()))
 dev = torch.device("cuda", 0)
 module, trainer = bench.build_trainer(expt, batch, dev, 1, False, img)
@@ -24,7 +26,10 @@ for _ in range(3 * per):
     trainer.step(data)
 trainer.finish()
 torch.cuda.synchronize()
-n = 10
+import gc  # noqa: E402
+gc.collect()
+gc.freeze()
+n = 20
 t0 = time.perf_counter()
 for _ in range(n * per):
     trainer.step(data)
@@ -32,7 +37,12 @@ trainer.finish()
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print("%s bs %d: enqueue %.2f ms/cycle, enqueue+drain %.2f ms/cycle" % (expt, batch, (t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3))
+print("%s bs %d img %d: host enqueue %.3f ms/cycle, enqueue + drain %.3f ms/cycle (%s)"
+      % (expt, batch, img, (t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3,
+         "the host runs ahead of the GPU: idle gaps are dependent-dispatch latency, not an empty queue"
+         if (t1 - t0) < 0.9 * (t2 - t0) else "the host is the limit"))
+if brief:
+    sys.exit(0)
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(5 * per):
