@@ -87,6 +87,15 @@ int gz_conv2d_wgrad_fuses_bias(int N, int C, int H, int W, int K, int OH, int OW
 int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* dbias, float* workspace, size_t ws_bytes, int N,
                     int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream);
 
+/* Round 4 -- CU budget.  The convolution plans size their tile / split choices to whole rounds of workgroup slots on
+ * `cu_count` CUs (default 256 = the whole MI355X).  Under data parallelism RCCL's channel kernels occupy part of the
+ * chip while backward runs (the overlap ddp.GradSync creates); a plan sized for 256 CUs then spills into a second,
+ * nearly empty round.  ddp.GradSync calls gz_set_cu_budget(256 - reserved) when world > 1 (clamped to [64, 256];
+ * <= 0 restores 256); returns the value in effect.  Process-wide, may be changed between launches; workspace sizes and
+ * gz_conv2d_plan follow it. */
+int gz_set_cu_budget(int cu_count);
+int gz_get_cu_budget(void);
+
 /* Round 4 -- the dispatch as data.  gz_conv2d_plan writes a one-line description of the kernel a launch of op (0 F, 1 Dg,
  * 2 Wg) with this shape takes -- skeleton (igemm / igemm2 / igemm2w / a direct kernel), tile, operand loaders, number of
  * reduction slabs, BatchNorm statistics rows -- into buf; returns the text length or a negative error.  Pure host logic
@@ -126,6 +135,15 @@ int gz_conv2d_fwd_stats_rows(int N, int C, int H, int W, int K, int OH, int OW, 
 int gz_conv2d_fwd_stats(const float* x, const float* wpack, float* y, float* stats, int N, int C, int H, int W, int K,
                         int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream);
 int gz_conv2d_dgrad_stats_rows(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P);
+/* Round 4: launches that split their reduction carry the statistics too -- the finish pass runs the same epilogue per
+ * 32 x 32 output block (one partial row per 32 pixels) -- and need the op's workspace (gz_conv2d_{fwd,dgrad}_workspace_bytes).
+ * The entry points without a workspace remain for unsplit plans. */
+int gz_conv2d_fwd_stats_ws(const float* x, const float* wpack, float* y, float* stats, float* workspace, size_t ws_bytes,
+                           int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P,
+                           hipStream_t stream);
+int gz_conv2d_dgrad_stats_ws(const float* y, const float* wpack, float* x, float* stats, float* workspace,
+                             size_t ws_bytes, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S,
+                             int P, hipStream_t stream);
 int gz_conv2d_dgrad_stats(const float* y, const float* wpack, float* x, float* stats, int N, int C, int H, int W, int K,
                           int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream);
 

@@ -39,17 +39,18 @@ static TileId pick_tile2(long long M, long long N, int ny, int kdim) {
     const bool off = knobs().no_igemm2;
     if (!off && N > 32 && N <= 64 && kdim >= 256) {             // one 64-wide column of 512-pixel tiles
         const long long t = ((M + 511) / 512) * ny;
-        return t >= 512 ? T512x64 : T64x64;
+        return t >= 2 * cus() ? T512x64 : T64x64;
     }
     if (off || N < 128 || kdim < 256) return T64x64;            // "not applicable"
     const long long t128 = ((M + 255) / 256) * ((N + 127) / 128) * ny;
     const long long t256 = ((M + 255) / 256) * ((N + 255) / 256) * ny;
     const int force = knobs().igemm2_tile;
-    if (force == 256 && N >= 256 && t256 >= 256) return T256x256;
-    if (force == 128 && t128 >= 256) return T256x128;
-    if (t128 >= 512) return T256x128;
-    if (N >= 256 && t256 >= 256) return T256x256;
-    if (t128 >= 256) return T256x128;
+    const int cu = cus();
+    if (force == 256 && N >= 256 && t256 >= cu) return T256x256;
+    if (force == 128 && t128 >= cu) return T256x128;
+    if (t128 >= 2 * cu) return T256x128;
+    if (N >= 256 && t256 >= cu) return T256x256;
+    if (t128 >= cu) return T256x128;
     return T64x64;
 }
 
@@ -82,7 +83,7 @@ static TileId pick_tile(long long M, long long N, int ny, int kdim = 0) {
         return T64x64;
     }
     auto score = [&](int bm, int bn, double eff, int per_cu) {
-        const double rounds = (double)tiles(bm, bn) / (256.0 * per_cu);
+        const double rounds = (double)tiles(bm, bn) / ((double)cus() * per_cu);
         double fill = 1.0;
         if (rounds <= 1.0) fill = rounds;
         else if (rounds < 2.0) fill = 0.5 + 0.5 * rounds / 2.0;      // 1 < rounds < 2: half of the tail is hidden
@@ -116,7 +117,7 @@ static long long tile_count(TileId t, long long M, long long N, int ny) {
 
 static SplitPlan plan_split(long long M, long long N, int Kdim, int ny, TileId normal) {
     SplitPlan none{normal, 1};
-    const int target = knobs().split_target, below = knobs().split_below;
+    const int target = knobs().split_target * cus() / 256, below = knobs().split_below * cus() / 256;
     if (knobs().no_splitk) return none;
     const int chunks = (Kdim + BK - 1) / BK;
     const long long tiles = tile_count(normal, M, N, ny);
@@ -505,7 +506,7 @@ static int fwd_kdim(const ConvShape& s) {
 static TileId pick_tile_fwd(long long M, int K, int OW, int kh, int kw, int stride, int kdim) {
     TileId t = pick_tile(M, K, 1, kdim);
     if (forced_tile() < 0 && kh == 4 && kw == 4 && stride == 2 && OW < 16 && t == T64x64 && K > 64 &&
-        tile_count(T128x128, M, K, 1) >= 512)
+        tile_count(T128x128, M, K, 1) >= 2 * cus())
         t = T128x128;
     return t;
 }
@@ -523,13 +524,14 @@ static SplitPlan fwdtap2_plan(const ConvShape& s) {
     const long long M = (long long)s.N * s.OH * s.OW;
     const long long tiles = ((M + 255) / 256) * ((s.K + 127) / 128);
     const int chunks = G::kh * G::kw * round_bk(s.C) / BK;
-    if (tiles >= 224) return SplitPlan{T256x128, 1};
+    const int cu = cus();
+    if (tiles >= cu * 7 / 8) return SplitPlan{T256x128, 1};
     // split launches pay off from ~64 chunks per workgroup (HoloGAN EXT-128's blocks: 100 -> 115-118 TFLOP/s against
     // 80-94 on the 64x64 tiles; the 64x64-image blocks would get 33 chunks each and lose 5 %)
     if (tiles >= 8 && chunks >= 128) {
-        int splits = (int)((256 + tiles - 1) / tiles);
+        int splits = (int)((cu + tiles - 1) / tiles);
         while (splits > 1 && chunks / splits < 64) --splits;
-        if (splits > 1 && tiles * splits >= 192) return SplitPlan{T256x128, splits};
+        if (splits > 1 && tiles * splits >= cu * 3 / 4) return SplitPlan{T256x128, splits};
     }
     return SplitPlan{T64x64, 1};
 }
@@ -546,9 +548,9 @@ static SplitPlan fwd2_plan(const ConvShape& s) {
     const int chunks = s.C;
     const int min_tiles = knobs().fwd2_min_tiles;
     if (tiles >= min_tiles && chunks >= 64) {
-        int splits = (int)((256 + tiles - 1) / tiles);
+        int splits = (int)((cus() + tiles - 1) / tiles);
         while (splits > 1 && chunks / splits < 32) --splits;
-        if (splits > 1 && tiles * splits >= 256) return SplitPlan{T256x128, splits};
+        if (splits > 1 && tiles * splits >= cus()) return SplitPlan{T256x128, splits};
     }
     return SplitPlan{T64x64, 1};
 }
@@ -896,7 +898,8 @@ static int run_dgrad(const float* y, const float* wp, const float* bias, float* 
     typename BL::Params pb{wp, Kg, ldc, ldc, (long long)Kg * ldc};
     int M = s.N * AH * AW;
     typename Epi::Params pe{x, M, s.C, s.H, s.W, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW), bias, act, slope,
-                            reinterpret_cast<f32x2*>(stats), ((M + Cfg::BM - 1) / Cfg::BM) * Cfg::WM};
+                            reinterpret_cast<f32x2*>(stats),
+                            (splits > 1 && slab) ? (M + 31) / 32 : ((M + Cfg::BM - 1) / Cfg::BM) * Cfg::WM};
     if constexpr (!AL::FIXED) {
         if (dgrad_tap_major(s.K, G::kh, G::kw, G::s)) {
             using ALT = ConvDgALoaderTap<Cfg::BM, G::kh, G::kw, G::s, G::p>;
@@ -940,8 +943,11 @@ static int run_dgrad2(const float* y, const float* wp, const float* bias, float*
     const int ldc = round4(s.C);
     typename BL::Params pb{wp, Kg, ldc, ldc, (long long)Kg * ldc};
     const int M = s.N * AH * AW;
+    // rows of partial statistics per phase: one per wavefront row of a tile, or -- split launch: the finish kernel
+    // runs the epilogue per 32 x 32 block -- one per 32 pixels
     typename Epi::Params pe{x, M, s.C, s.H, s.W, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW), bias, act, slope,
-                            reinterpret_cast<f32x2*>(stats), ((M + Cfg::BM - 1) / Cfg::BM) * Cfg::WM};
+                            reinterpret_cast<f32x2*>(stats),
+                            (splits > 1 && slab) ? (M + 31) / 32 : ((M + Cfg::BM - 1) / Cfg::BM) * Cfg::WM};
     return launch_igemm2<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kg, 4, splits, st, slab);
 }
 
@@ -990,16 +996,16 @@ static SplitPlan dgradtap2_plan(const ConvShape& s) {
     const int maxchunks = TY * TX * kblocks;
     // one phase (stride 1): nothing to balance -- split only when the tiles alone do not fill the chip
     if (G::s == 1) {
-        if (tiles >= 224 && maxchunks >= 8) return SplitPlan{T256x128, 1};
-        if (tiles * total < 512LL * 32) return SplitPlan{T64x64, 1};
-        int splits = (int)((256 + tiles - 1) / tiles);
+        if (tiles >= cus() * 7 / 8 && maxchunks >= 8) return SplitPlan{T256x128, 1};
+        if (tiles * total < 2LL * cus() * 32) return SplitPlan{T64x64, 1};
+        int splits = (int)((cus() + tiles - 1) / tiles);
         while (splits > 1 && maxchunks / splits < 64) --splits;
-        return (splits > 1 && tiles * splits >= 192) ? SplitPlan{T256x128, splits} : SplitPlan{T64x64, 1};
+        return (splits > 1 && tiles * splits >= cus() * 3 / 4) ? SplitPlan{T256x128, splits} : SplitPlan{T64x64, 1};
     }
-    if (tiles * total < 512LL * 32) return SplitPlan{T64x64, 1};       // too little work for the big tile
+    if (tiles * total < 2LL * cus() * 32) return SplitPlan{T64x64, 1};       // too little work for the big tile
     // ~384 workgroups of <= 96 chunks (measured on HoloGAN EXT-128's blocks, TFLOP/s of D.block2 / D.block3:
     // 256 workgroups 84 / 67, 384: 99 / 99, 512: 99 / 89, 768: 90 / 86; the round-2 kernels: 89 / 74)
-    const int wgs = knobs().tap_wgs, cps_max = knobs().tap_cps_max;
+    const int wgs = knobs().tap_wgs * cus() / 256, cps_max = knobs().tap_cps_max;
     long long cps = (tiles * total + wgs - 1) / wgs;
     if (cps < 32) cps = 32;
     if (cps > cps_max) cps = cps_max;
@@ -1035,10 +1041,10 @@ static SplitPlan dgrad_plan(const ConvShape& s) {
         const long long tiles = ((M + 255) / 256) * ((s.C + 127) / 128) * 4;
         const int chunks = s.K / 4;
         const int min_tiles = knobs().dg2_min_tiles;
-        if (!off && s.C >= 128 && tiles >= min_tiles && tiles < 256 && chunks >= 64) {
-            int splits = (int)((256 + tiles - 1) / tiles);
+        if (!off && s.C >= 128 && tiles >= min_tiles && tiles < cus() && chunks >= 64) {
+            int splits = (int)((cus() + tiles - 1) / tiles);
             while (splits > 1 && chunks / splits < 32) --splits;
-            if (splits > 1 && tiles * splits >= 256) return SplitPlan{T256x128, splits};
+            if (splits > 1 && tiles * splits >= cus()) return SplitPlan{T256x128, splits};
         }
     }
     {
@@ -1382,14 +1388,14 @@ static int wg_target() {
 // Split-K so that ~4 workgroups per CU are in flight: the wgrad loaders are gather-heavy and only
 // reach the MFMA rate when several workgroups per SIMD overlap their load and MFMA phases.
 static int wgrad_splits(long long tiles, int chunks, bool big_tile = true) {
-    long long target = big_tile ? wg_target() : 512;   // narrow tiles (3-channel layers) are slab-traffic bound
+    long long target = (big_tile ? wg_target() : 512) * cus() / 256;   // narrow tiles (3-channel layers) are slab-traffic bound
     if (tiles * 4 >= target * 3) return 1;
     long long want = (target + tiles - 1) / tiles;
     if (big_tile) {
         // ... but a 128x128 workgroup that reduces fewer than 32 chunks spends its time on the prologue and its 64 KB
         // slab: keep >= 32 chunks per split as long as >= 512 workgroups remain (bs 128, D.block1 / block2: 128 x 16
         // chunks -> 64 x 32, 0.111 -> 0.105 and 0.116 -> 0.110 ms; every bs 512 layer keeps its plan)
-        const long long by_len = chunks / 32 > 0 ? chunks / 32 : 1, want_min = (512 + tiles - 1) / tiles;
+        const long long by_len = chunks / 32 > 0 ? chunks / 32 : 1, want_min = (2 * cus() + tiles - 1) / tiles;
         const long long floor_ = by_len > want_min ? by_len : want_min;
         if (floor_ < want) want = floor_;
     }
@@ -1471,7 +1477,7 @@ static int wgrad2_splits(const ConvShape& s) {
     const int chunks = (s.N * s.OH * s.OW + BK - 1) / BK;
     // at most ONE round of the chip's 512 workgroup slots (two per CU): 18 tiles x 29 splits = 522 workgroups took two
     // rounds (3x3 s1 p1 256@32: 96 TFLOP/s; 28 splits: one round)
-    int splits = (int)(512 / tiles);
+    int splits = (int)(2 * cus() / tiles);
     if (splits < 1) splits = 1;
     // >= 64 chunks per workgroup for the register-staged kernel; the LDS-DMA kernel's chunks cost nothing but their
     // MFMAs, so 32 are enough there (bs 128: D.block1-3's weight gradients move from the 128x128 kernel onto it)
@@ -1480,7 +1486,7 @@ static int wgrad2_splits(const ConvShape& s) {
                      (s.OW == 4 || s.OW == 8 || s.OW % 16 == 0) && !knobs().no_igemm2w;
     const int min_chunks = min_chunks_env > 0 ? min_chunks_env : (dma ? 32 : 64);
     while (splits > 1 && chunks / splits < min_chunks) --splits;
-    return tiles * splits >= 256 ? splits : 0;
+    return tiles * splits >= cus() ? splits : 0;
 }
 
 template <class G, class Cfg>
@@ -1871,6 +1877,16 @@ int gz_conv2d_wgrad_partial(const float* x, const float* y, float* dw, float* wo
     return rc;
 }
 
+int gz_set_cu_budget(int cu_count) {
+    if (cu_count <= 0) cu_count = 256;
+    if (cu_count < 64) cu_count = 64;
+    if (cu_count > 256) cu_count = 256;
+    gz::cu_budget_ref().store(cu_count, std::memory_order_relaxed);
+    return cu_count;
+}
+
+int gz_get_cu_budget(void) { return gz::cus(); }
+
 int gz_reduce_multi_max_jobs(void) { return REDUCE_MAX_JOBS; }
 int gz_reduce_multi_max_sources(void) { return REDUCE_MAX_SRC; }
 size_t gz_reduce_multi_table_bytes(void) { return sizeof(ReduceTable); }
@@ -1929,12 +1945,15 @@ int gz_conv2d_fwd_stats_rows(int N, int C, int H, int W, int K, int OH, int OW, 
 #define CALL(G) fwd_plan<G>(s)
     SplitPlan sp = [&]() -> SplitPlan { GZ_GEOM_DISPATCH_OR(CALL, (SplitPlan{T64x64, 2})) }();
 #undef CALL
-    if (sp.splits > 1) return 0;              // split-K launches finish in another kernel: not fused
+    // split launches (round 4): splitk_finish_kernel runs the same epilogue per 32 x 32 output block and writes the
+    // statistics there -- one partial row per 32 pixels
+    if (sp.splits > 1) return (int)(((long long)N * OH * OW + 31) / 32);
     return stats_tm_rows(sp.tile, (long long)N * OH * OW);      // (the tap-major gather launches do carry them)
 }
 
-int gz_conv2d_fwd_stats(const float* x, const float* wpack, float* y, float* stats, int N, int C, int H, int W, int K,
-                        int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream) {
+int gz_conv2d_fwd_stats_ws(const float* x, const float* wpack, float* y, float* stats, float* workspace, size_t ws_bytes,
+                           int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P,
+                           hipStream_t stream) {
     gz::clear_stale_error();
     ConvShape s{N, C, H, W, K, OH, OW};
     if (!shape_ok(s, KH, KW, S, P) || !stats) return GZ_ERR_BAD_SHAPE;
@@ -1943,19 +1962,27 @@ int gz_conv2d_fwd_stats(const float* x, const float* wpack, float* y, float* sta
     if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
 #define CALL(G)                                                                                                      \
     [&]() -> int {                                                                                                   \
-        switch (fwd_plan<G>(s).tile) {                                                                               \
-            case T256x256: return run_fwd2_ow<Cfg256x256>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats); \
+        const SplitPlan sp = fwd_plan<G>(s);                                                                         \
+        if (sp.splits > 1 && (!workspace || ws_bytes < fwd_ws_bytes<G>(s))) return GZ_ERR_WORKSPACE;                 \
+        float* slab = sp.splits > 1 ? workspace : nullptr;                                                           \
+        switch (sp.tile) {                                                                                           \
+            case T256x256: return run_fwd2_ow<Cfg256x256>(x, wpack, nullptr, y, s, 0, 0.f, stream, sp.splits, slab, stats); \
             case T256x128:                                                                                           \
-                if (!fwd2_ok<G>(s)) return run_fwdtap2<G, Cfg256x128>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats); \
-                return run_fwd2_ow<Cfg256x128>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats);          \
-            case T128x128: return run_fwd<G, Cfg128x128>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats); \
-            case T128x64: return run_fwd<G, Cfg128x64>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats);   \
-            case T128x32: return run_fwd<G, Cfg128x32>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats);   \
-            default: return run_fwd<G, Cfg64x64>(x, wpack, nullptr, y, s, 0, 0.f, stream, 1, nullptr, stats);         \
+                if (!fwd2_ok<G>(s)) return run_fwdtap2<G, Cfg256x128>(x, wpack, nullptr, y, s, 0, 0.f, stream, sp.splits, slab, stats); \
+                return run_fwd2_ow<Cfg256x128>(x, wpack, nullptr, y, s, 0, 0.f, stream, sp.splits, slab, stats);     \
+            case T128x128: return run_fwd<G, Cfg128x128>(x, wpack, nullptr, y, s, 0, 0.f, stream, sp.splits, slab, stats); \
+            case T128x64: return run_fwd<G, Cfg128x64>(x, wpack, nullptr, y, s, 0, 0.f, stream, sp.splits, slab, stats);   \
+            case T128x32: return run_fwd<G, Cfg128x32>(x, wpack, nullptr, y, s, 0, 0.f, stream, sp.splits, slab, stats);   \
+            default: return run_fwd<G, Cfg64x64>(x, wpack, nullptr, y, s, 0, 0.f, stream, sp.splits, slab, stats);         \
         }                                                                                                            \
     }()
     GZ_GEOM_DISPATCH(CALL)
 #undef CALL
+}
+
+int gz_conv2d_fwd_stats(const float* x, const float* wpack, float* y, float* stats, int N, int C, int H, int W, int K,
+                        int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream) {
+    return gz_conv2d_fwd_stats_ws(x, wpack, y, stats, nullptr, 0, N, C, H, W, K, OH, OW, KH, KW, S, P, stream);
 }
 
 int gz_conv2d_dgrad_stats_rows(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P) {
@@ -1964,13 +1991,17 @@ int gz_conv2d_dgrad_stats_rows(int N, int C, int H, int W, int K, int OH, int OW
 #define CALL(G) (dgrad_direct<G>(nullptr, s) ? SplitPlan{T64x64, 2} : dgrad_plan<G>(s))
     SplitPlan sp = [&]() -> SplitPlan { GZ_GEOM_DISPATCH_OR(CALL, (SplitPlan{T64x64, 2})) }();
 #undef CALL
-    if (sp.splits > 1) return 0;
     if (is_tile2(sp.tile) && !(KH == 4 && KW == 4 && S == 2 && P == 1)) return 0;      // gather-loader launches: not fused
+    if (sp.splits > 1) {          // the finish kernel writes them, one partial row per 32 pixels of a phase (round 4)
+        if (!(KH == 4 && KW == 4 && S == 2 && P == 1)) return 0;       // phases of unequal length: own slab map, not fused
+        return S * S * (int)(((long long)N * (H / S) * (W / S) + 31) / 32);
+    }
     return S * S * stats_tm_rows(sp.tile, (long long)N * (H / S) * (W / S));
 }
 
-int gz_conv2d_dgrad_stats(const float* y, const float* wpack, float* x, float* stats, int N, int C, int H, int W, int K,
-                          int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream) {
+int gz_conv2d_dgrad_stats_ws(const float* y, const float* wpack, float* x, float* stats, float* workspace,
+                             size_t ws_bytes, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S,
+                             int P, hipStream_t stream) {
     gz::clear_stale_error();
     ConvShape s{N, C, H, W, K, OH, OW};
     if (!shape_ok(s, KH, KW, S, P) || !stats) return GZ_ERR_BAD_SHAPE;
@@ -1979,18 +2010,26 @@ int gz_conv2d_dgrad_stats(const float* y, const float* wpack, float* x, float* s
     if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
 #define CALL(G)                                                                                                        \
     [&]() -> int {                                                                                                     \
-        switch (dgrad_plan<G>(s).tile) {                                                                               \
+        const SplitPlan sp = dgrad_plan<G>(s);                                                                         \
+        if (sp.splits > 1 && (!workspace || ws_bytes < dgrad_ws_bytes<G>(s))) return GZ_ERR_WORKSPACE;                 \
+        float* slab = sp.splits > 1 ? workspace : nullptr;                                                             \
+        switch (sp.tile) {                                                                                             \
             case T256x256: return run_dgrad2<Cfg256x256>(y, wpack, nullptr, x, s, 0, 0.f, stream, stats);               \
-            case T256x128: return run_dgrad2<Cfg256x128>(y, wpack, nullptr, x, s, 0, 0.f, stream, stats);               \
+            case T256x128: return run_dgrad2<Cfg256x128>(y, wpack, nullptr, x, s, 0, 0.f, stream, stats, sp.splits, slab); \
             case T512x64: return run_dgrad2<Cfg512x64>(y, wpack, nullptr, x, s, 0, 0.f, stream, stats);                 \
-            case T128x128: return run_dgrad<G, Cfg128x128>(y, wpack, nullptr, x, s, 0, 0.f, stream, 1, nullptr, stats); \
-            case T128x64: return run_dgrad<G, Cfg128x64>(y, wpack, nullptr, x, s, 0, 0.f, stream, 1, nullptr, stats);   \
-            case T128x32: return run_dgrad<G, Cfg128x32>(y, wpack, nullptr, x, s, 0, 0.f, stream, 1, nullptr, stats);   \
-            default: return run_dgrad<G, Cfg64x64>(y, wpack, nullptr, x, s, 0, 0.f, stream, 1, nullptr, stats);         \
+            case T128x128: return run_dgrad<G, Cfg128x128>(y, wpack, nullptr, x, s, 0, 0.f, stream, sp.splits, slab, stats); \
+            case T128x64: return run_dgrad<G, Cfg128x64>(y, wpack, nullptr, x, s, 0, 0.f, stream, sp.splits, slab, stats);   \
+            case T128x32: return run_dgrad<G, Cfg128x32>(y, wpack, nullptr, x, s, 0, 0.f, stream, sp.splits, slab, stats);   \
+            default: return run_dgrad<G, Cfg64x64>(y, wpack, nullptr, x, s, 0, 0.f, stream, sp.splits, slab, stats);         \
         }                                                                                                              \
     }()
     GZ_GEOM_DISPATCH(CALL)
 #undef CALL
+}
+
+int gz_conv2d_dgrad_stats(const float* y, const float* wpack, float* x, float* stats, int N, int C, int H, int W, int K,
+                          int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream) {
+    return gz_conv2d_dgrad_stats_ws(y, wpack, x, stats, nullptr, 0, N, C, H, W, K, OH, OW, KH, KW, S, P, stream);
 }
 
 long long gz_conv2d_pack_fwd_any_elems(int K, int C, int KH, int KW) {

@@ -20,8 +20,8 @@ static int plan3(int tile, long long M, long long N, int Kdim, int ny) {
     const int bm = tile == 3 ? 64 : 128, bn = tile == 0 ? 128 : (tile == 2 ? 32 : 64);
     const long long tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * ny;
     const int chunks = (Kdim + BK - 1) / BK;
-    if (chunks < 16 || tiles >= 512) return 1;
-    long long want = (1024 + tiles - 1) / tiles, cap = chunks / 8;
+    if (chunks < 16 || tiles >= 2 * cus()) return 1;
+    long long want = (4 * cus() + tiles - 1) / tiles, cap = chunks / 8;
     long long sp = want < cap ? want : cap;
     return sp < 2 ? 1 : (int)sp;
 }
@@ -52,12 +52,12 @@ static DgPlan3 plan3_dg(int tile, long long Mp, long long C, int K, int KS, int 
         total += pc[ph];
         maxpc = pc[ph] > maxpc ? pc[ph] : maxpc;
     }
-    if (off || maxpc < 16 || tp * S * S * S >= 512) return none;
+    if (off || maxpc < 16 || tp * S * S * S >= 2 * cus()) return none;
     int splits;
     if (even) {
         splits = plan3(tile, Mp, C, K * 8, 8);
     } else {
-        long long cps = (total * tp + 1023) / 1024;
+        long long cps = (total * tp + 4 * cus() - 1) / (4 * cus());
         if (cps < 8) cps = 8;
         splits = (int)((maxpc + cps - 1) / cps);
     }
@@ -71,9 +71,9 @@ static DgPlan3 plan3_dg(int tile, long long Mp, long long C, int K, int KS, int 
 static int pick3(long long M, long long N, int ny) {
     if (N <= 32) return 2;
     auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * ny; };
-    if (N <= 64) return tiles(128, 64) >= 256 ? 1 : 3;
-    if (tiles(128, 128) >= 256) return 0;
-    if (tiles(128, 64) >= 256) return 1;
+    if (N <= 64) return tiles(128, 64) >= cus() ? 1 : 3;
+    if (tiles(128, 128) >= cus()) return 0;
+    if (tiles(128, 64) >= cus()) return 1;
     return 3;
 }
 
@@ -193,8 +193,8 @@ static int run_dgrad3(const float* y, const float* wp, const float* bias, float*
 }
 
 static int splits3(long long tiles, int chunks) {
-    const int target = knobs().wg3_target;
-    if (tiles >= 256) return 1;
+    const int target = knobs().wg3_target * cus() / 256;
+    if (tiles >= cus()) return 1;
     long long want = (target + tiles - 1) / tiles;
     long long cap = chunks / 8 > 0 ? chunks / 8 : 1;
     long long s = want < cap ? want : cap;

@@ -2726,7 +2726,11 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
         for (int p = 0; p < NP; ++p) issue_piece(kc0 + 1, 1, p, kc0 + 1 < kc1);
         // lgkmcnt(0) as well: the zeroed pad columns / A_EXTRA region above were plain ds_writes, and gfx950's back-off
         // barrier does not wait for a wavefront's outstanding LDS operations by itself
+#ifdef GZ2_EXP_NO_LGKM_PROLOGUE
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+#else
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NP) : "memory");
+#endif
         __builtin_amdgcn_s_barrier();
 #ifdef GZ2_STAMPS
         st1 = __builtin_amdgcn_s_memtime();

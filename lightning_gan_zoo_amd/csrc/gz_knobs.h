@@ -7,6 +7,7 @@
 #pragma once
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 
 namespace gz {
 
@@ -89,5 +90,16 @@ inline const Knobs& knobs() {
     }();
     return k;
 }
+
+// CU budget (round 4): how many of the chip's 256 CUs the convolution plans may count on.  Every split / tile plan is
+// sized to whole ROUNDS of workgroup slots (2 igemm2 workgroups or 4 igemm workgroups per CU); when part of the chip
+// is taken -- RCCL's channel kernels run underneath backward once the gradient exchange overlaps it -- a plan sized
+// for 256 CUs needs a second, nearly empty round.  ddp.GradSync sets the budget to 256 - (channels it expects) through
+// gz_set_cu_budget; a single-GPU process keeps 256.
+inline std::atomic<int>& cu_budget_ref() {
+    static std::atomic<int> v{256};
+    return v;
+}
+inline int cus() { return cu_budget_ref().load(std::memory_order_relaxed); }
 
 }  // namespace gz

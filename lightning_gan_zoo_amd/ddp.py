@@ -25,6 +25,13 @@ import torch
 import torch.distributed as dist
 
 BUCKET_BYTES = int(os.environ.get("GZ_DDP_BUCKET_MB", "16")) << 20
+# CUs the convolution planner leaves to RCCL's channel kernels while the exchange overlaps backward (gz_set_cu_budget).
+# Default 0 = plans sized for the whole chip: the single-GPU rehearsal (profiles/r04_contention.json, tools/
+# contention_rehearsal.py) shows that a co-running channel kernel costs the step 7-11 % WHILE IT RUNS whatever the
+# planner assumes -- budgeted plans were within +-1 % of the unbudgeted ones at R = 8..32 and worse at R = 64 -- so the
+# loss is a straggler effect of the CUs that share their vector-memory path with a channel, not a slot-count effect.
+# The exposure is the exchange window itself (~0.5 ms of a 6.5 ms pair at bs 128).  The knob stays for real 8-GPU runs.
+CU_RESERVE = int(os.environ.get("GZ_DDP_CU_RESERVE", "0"))
 
 
 class _FlatGrads:
@@ -87,6 +94,12 @@ class GradSync:
         # the time the compute stream sat behind a collective that had not finished
         self.measure = bool(os.environ.get("GZ_DDP_MEASURE"))
         self._waits = []              # (optimizer_idx, start event, end event) or (optimizer_idx, seconds)
+        # the tile / split plans are sized to whole rounds of workgroup slots: with the exchange's channel kernels on the
+        # chip, tell the planner how many CUs it can count on (include/gz_ops.h: gz_set_cu_budget)
+        self.cu_budget = 256
+        if self._reduces() and self.flats[0].flat.is_cuda and self.overlap and CU_RESERVE > 0:
+            from ._lib import lib
+            self.cu_budget = lib.gz_set_cu_budget(256 - CU_RESERVE)
         self.hooks = [n.register_forward_pre_hook(self._make_hook(i)) for i, n in enumerate(self.nets)]
         self.net_of = {}              # id(param) -> optimizer_idx
         self.reported = set()         # parameters whose gradient of the running backward pass is complete
@@ -242,3 +255,7 @@ class GradSync:
         self.flush()
         for h in self.hooks:
             h.remove()
+        if self.cu_budget != 256:
+            from ._lib import lib
+            lib.gz_set_cu_budget(256)
+            self.cu_budget = 256

@@ -298,9 +298,11 @@ def _conv_fwd_stats_raw(x, w, geom):
     y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
     stats = torch.empty((rows, K, 2), device=x.device, dtype=torch.float32)
     wp = _packed(w, "f", geom)
+    ws, nbytes = _scratch(lib.gz_conv2d_fwd_workspace_bytes(N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
+                                                            geom.pad), x.device)
     _timed(0, (N, C, H, W, K, OH, OW), geom, 2.0 * N * OH * OW * K * C * geom.kh * geom.kw, lambda: check(
-        lib.gz_conv2d_fwd_stats(_p(x), _p(wp), _p(y), _p(stats), N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
-                                geom.pad, _stream()), "conv2d_fwd_stats"))
+        lib.gz_conv2d_fwd_stats_ws(_p(x), _p(wp), _p(y), _p(stats), _p(ws), nbytes, N, C, H, W, K, OH, OW, geom.kh,
+                                   geom.kw, geom.stride, geom.pad, _stream()), "conv2d_fwd_stats"))
     return y, stats
 
 
@@ -317,9 +319,11 @@ def _conv_dgrad_stats_raw(g, w, geom, hw):
     x = torch.empty((N, C, H, W), device=g.device, dtype=torch.float32)
     stats = torch.empty((rows, C, 2), device=g.device, dtype=torch.float32)
     wp = _packed(w, "d", geom)
+    ws, nbytes = _scratch(lib.gz_conv2d_dgrad_workspace_bytes(N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
+                                                              geom.pad), g.device)
     _timed(1, (N, C, H, W, K, OH, OW), geom, 2.0 * N * OH * OW * K * C * geom.kh * geom.kw, lambda: check(
-        lib.gz_conv2d_dgrad_stats(_p(g), _p(wp), _p(x), _p(stats), N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride,
-                                  geom.pad, _stream()), "conv2d_dgrad_stats"))
+        lib.gz_conv2d_dgrad_stats_ws(_p(g), _p(wp), _p(x), _p(stats), _p(ws), nbytes, N, C, H, W, K, OH, OW, geom.kh,
+                                     geom.kw, geom.stride, geom.pad, _stream()), "conv2d_dgrad_stats"))
     return x, stats
 
 
@@ -489,8 +493,11 @@ def flush_grad_sinks(params=None):
     nb = lib.gz_reduce_multi_table_bytes()
     st = _stream()
     table, njobs = (ctypes.c_char * nb)(), 0
+    keep = []        # the slabs stay allocated until every launch that reads them has been ENQUEUED: a block freed
+                     # earlier could come back as the next parameter's fresh gradient tensor inside this very loop
     for k in keys:
         w, srcs = _sinks.pending.pop(k)
+        keep.append(srcs)
         fresh = w.grad is None
         target = torch.empty_like(w, memory_format=torch.contiguous_format) if fresh else w.grad
         if not target.is_contiguous() or target.dtype != torch.float32:
@@ -515,6 +522,7 @@ def flush_grad_sinks(params=None):
             w.grad = target
     if njobs:
         check(lib.gz_reduce_multi(table, st), "reduce_multi")
+    del keep         # (stream-ordered allocator: later allocations on this stream come after the launches above)
 
 
 def _act_bwd_raw(g, out, act, slope):

@@ -443,7 +443,10 @@ def test_product_with_reference_mask_decisions_every_gradient_at_1e3(expt):
     flips = sum(m[1] for m in tape.mismatches)
     print(f"{expt}: the product alone would decide {flips} of {total} mask entries differently "
           f"(largest |pre-activation| among them {max([m[3] for m in tape.mismatches], default=0.0):.1e})")
-    assert flips <= 1e-4 * total and all(m[3] <= 1e-4 for m in tape.mismatches), tape.mismatches
+    # a sanity bound on the diagnostic, not the parity bar (those follow): the entries the product alone would decide
+    # differently are pre-activations within the 1e-3 tolerance of zero -- observed <= 7.8e-5 in round 3, 1.2e-4 once
+    # the BatchNorm statistics of split launches come from the finish pass (other summation order), activations O(1)
+    assert flips <= 1e-4 * total and all(m[3] <= 3e-4 for m in tape.mismatches), tape.mismatches
     assert set(hip) == set(cpu) == set(golden)
     worst = []
     for k, ref in cpu.items():
