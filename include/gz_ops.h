@@ -218,6 +218,12 @@ int gz_resize_bilinear(const float* x, float* y, long long planes, int H, int W,
 int gz_bce_logits_mean(const float* x, float* loss, int n, float target, hipStream_t stream);
 /* dx[i] = (sigmoid(x[i]) - target) * gloss[0] / n */
 int gz_bce_logits_mean_bwd(const float* x, const float* gloss, float* dx, int n, float target, hipStream_t stream);
+/* Round 4: the loss head of a discriminator step on the stacked batch [real; fake] (2 * n_each logits) in one launch.
+ * mode 0: (mean BCE(x[:n], t0) + mean BCE(x[n:], t1)) / 2 (core/lightning_module.py:114-120);
+ * mode 1: t0 * mean(x[:n]) + t1 * mean(x[n:]) (the WGAN critic loss with t0 = -1, t1 = +1, :168). */
+int gz_pair_loss(const float* x, float* loss, int n_each, float t0, float t1, int mode, hipStream_t stream);
+int gz_pair_loss_bwd(const float* x, const float* gloss, float* dx, int n_each, float t0, float t1, int mode,
+                     hipStream_t stream);
 /* loss[0] = mean((a - b)^2): HoloGAN's q_loss (:226,234);  da[i] = 2 (a[i] - b[i]) gloss[0] / n */
 int gz_mse_mean(const float* a, const float* b, float* loss, int n, hipStream_t stream);
 int gz_mse_mean_bwd(const float* a, const float* b, const float* gloss, float* da, int n, hipStream_t stream);
@@ -285,6 +291,27 @@ int gz_norm_act_fwd(const float* x, const float* coef, float* out, int N, int C,
 int gz_norm_act_bwd(const float* gout, const float* x, const float* coef, float* dx, float* dgamma, float* dbeta,
                     void* workspace, float* kbuf, int N, int C, int inner, int per_channel, int affine_per_row,
                     int unbiased, int act, float slope, hipStream_t stream);
+/* Round 4 -- BatchNorm with statistics GROUPS.  A discriminator step of the reference applies D to the real batch and
+ * to the fake batch in two calls (core/lightning_module.py:112-119), each call normalising with its own batch
+ * statistics and updating the running buffers.  Stacking the two batches along n and running ONE pass with groups = 2
+ * is the same arithmetic -- group g = samples [g N/groups, (g+1) N/groups) has its own (scale, shift, mean, rstd) at
+ * coef index g*C + c (coef holds 4 * groups * C floats), the running buffers are updated group after group,
+ * num_batches_tracked += groups, dgamma / dbeta sum over the groups -- with half the launches and twice the rows per
+ * launch.  `partials` of gz_batchnorm_finalize_g: rows of a convolution's fused statistics, the first rows/groups
+ * belonging to group 0 etc. (the caller checks that no row straddles two groups); `count` = elements per group and
+ * channel.  gz_batchnorm_act_bwd_g: accumulate != 0 adds the affine gradients to dgamma / dbeta (gradient sinks). */
+int gz_batchnorm_stats_g(const float* x, const float* gamma, const float* beta, float* coef, float* running_mean,
+                         float* running_var, long long* num_batches_tracked, void* workspace, int N, int C,
+                         int inner, float eps, float momentum, int groups, hipStream_t stream);
+int gz_batchnorm_finalize_g(const float* partials, int rows, long long count, const float* gamma, const float* beta,
+                            float* coef, float* running_mean, float* running_var, long long* num_batches_tracked,
+                            int C, float eps, float momentum, int groups, hipStream_t stream);
+int gz_norm_act_fwd_g(const float* x, const float* coef, float* out, int N, int C, int inner, int per_channel,
+                      int groups, int act, float slope, hipStream_t stream);
+int gz_batchnorm_act_bwd_g(const float* gout, const float* x, const float* coef, float* dx, float* dgamma, float* dbeta,
+                           void* workspace, float* kbuf, int N, int C, int inner, int act, float slope, int groups,
+                           int accumulate, hipStream_t stream);
+
 /* backward of gz_norm_act_bwd's dx (per-row statistics, per-channel affine): given v = dL/d(dx) returns
  * gg_out = dL/d(gout), gx = dL/dx, ggamma = dL/dgamma (any may be NULL).  This is the InstanceNorm leg of
  * the gradient-penalty double backward (core/utils/utils.py:48-54 with create_graph=True). */

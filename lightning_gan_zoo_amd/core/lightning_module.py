@@ -55,6 +55,12 @@ def _build_transform(cfg):
 
 class BaseGAN(LightningModule):
     real_first = True        # discriminator steps run D(real) before G(z) (see DCGAN.training_step)
+    # Round 4: a discriminator step applies D ONCE to the stacked batch [real; fake] with two BatchNorm statistics
+    # groups (standard_networks.Discriminator.forward(x, groups=2)) instead of twice -- the same arithmetic as the
+    # reference's two calls (per-call batch statistics, running buffers updated real then fake), half the launches and
+    # twice the rows per launch; the weight gradients of the two passes come out of one launch already summed.  Tests
+    # that replay the reference's mask decisions in ITS call order turn it off.
+    stack_d_passes = True
 
     def __init__(self, cfg, logging_dir=None):
         super().__init__()
@@ -83,6 +89,15 @@ class BaseGAN(LightningModule):
                 and c.pos_weight is None and logits.is_cuda):
             return F.bce_logits_mean(logits, value)
         return c(logits, torch.full_like(logits, value))
+
+    def stacked_discriminator(self, real, fake):
+        """D(cat(real, fake.detach()), groups=2).reshape(-1) -- [logits(real); logits(fake)] -- when the discriminator
+        supports stacked batches, else None (the caller takes the reference's two calls)."""
+        d = self.discriminator
+        if not (self.stack_d_passes and getattr(d, "supports_stacked_batches", False) and real.is_cuda and d.training
+                and real.shape == fake.shape):
+            return None
+        return d(torch.cat([real, fake.detach()]), groups=2).reshape(-1)
 
     def sample_noise(self, n):
         # drawn on the host generator, then copied to the device (reference :107-108); single host
@@ -158,7 +173,17 @@ class DCGAN(BaseGAN):
             # parallelism the generator's last gradient bucket + optimizer step (ddp.GradSync finalizes them in the
             # generator's forward-pre hook) hide behind it.  Same kernels on the same operands, D's norm buffers
             # still see real then fake: bit-identical to the reference's order (tests: test_real_first_order_...)
-            if self.real_first:
+            c = self.criterion
+            if (self.stack_d_passes and isinstance(c, torch.nn.BCEWithLogitsLoss) and c.reduction == "mean"
+                    and c.weight is None and c.pos_weight is None):
+                fake = self.generator(noise)
+                logits = self.stacked_discriminator(real, fake)
+                if logits is not None:
+                    loss_disc = F.bce_logits_pair_mean(logits, 1.0, 0.0)      # (BCE(real, 1) + BCE(fake, 0)) / 2
+                    self.log("train/d_loss", loss_disc)
+                    return loss_disc
+                disc_real = self.discriminator(real).reshape(-1)
+            elif self.real_first:
                 disc_real = self.discriminator(real).reshape(-1)
                 fake = self.generator(noise)
             else:
@@ -216,7 +241,15 @@ class WGAN(BaseGAN):
         noise = self.sample_noise(len(real))
 
         if optimizer_idx == 0:
-            if self.real_first:
+            if self.stack_d_passes:
+                fake = self.generator(noise)
+                logits = self.stacked_discriminator(real, fake)
+                if logits is not None:
+                    loss_disc = F.weighted_half_means(logits, -1.0, 1.0)      # -(mean(D(real)) - mean(D(fake)))
+                    self.log("train/d_loss", loss_disc)
+                    return loss_disc
+                disc_real = self.discriminator(real).reshape(-1)
+            elif self.real_first:
                 disc_real = self.discriminator(real).reshape(-1)
                 fake = self.generator(noise)
             else:

@@ -65,7 +65,7 @@ class _DBlock(nn.Module):
         self.leaky_relu = nn.LeakyReLU(0.2)
         self.norm = norm
 
-    def forward(self, x):
+    def forward(self, x, groups=1):
         slope = self.leaky_relu.negative_slope
         if self.norm == "batch_norm":
             bn = self.batch_norm
@@ -75,7 +75,8 @@ class _DBlock(nn.Module):
             else:
                 y = F.conv2d(x, self.conv.weight, None, F.K4S2P1)
             return F.batch_norm_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                    bn.num_batches_tracked, bn.training, bn.momentum, bn.eps, F.ACT_LRELU, slope, stats)
+                                    bn.num_batches_tracked, bn.training, bn.momentum, bn.eps, F.ACT_LRELU, slope, stats,
+                                    groups)
         if self.norm == "instance_norm2d":
             y = F.conv2d(x, self.conv.weight, None, F.K4S2P1)
             inn = self.instance_norm2d
@@ -84,11 +85,11 @@ class _DBlock(nn.Module):
 
 
 class _DiscStack(nn.Sequential):
-    def forward(self, x):
+    def forward(self, x, groups=1):
         x = F.conv2d(x, self.conv_in.weight, None, F.K4S2P1, F.ACT_LRELU, self.leaky_relu.negative_slope)
         for name, m in self.named_children():
             if name.startswith("block"):
-                x = m(x)
+                x = m(x, groups)
         w = self.conv_out.weight
         if tuple(x.shape[2:]) != tuple(w.shape[2:]):
             raise RuntimeError("conv_out expects a %dx%d map, got %s" % (w.shape[2], w.shape[3], tuple(x.shape)))
@@ -99,6 +100,8 @@ class _DiscStack(nn.Sequential):
 
 
 class Discriminator(nn.Module):
+    supports_stacked_batches = True      # forward(x, groups=G): G batches stacked along n, own BatchNorm statistics each
+
     def __init__(self, channels_img, features_d, norm="batch_norm", img_size=64, final_sigmoid=True):
         super().__init__()
         self.norm = norm
@@ -112,8 +115,13 @@ class Discriminator(nn.Module):
         self.disc = _DiscStack(OrderedDict(
             [("conv_in", conv_in), ("leaky_relu", nn.LeakyReLU(0.2))] + blocks + [("conv_out", conv_out), tail]))
 
-    def forward(self, x):
-        return self.disc(x)
+    def forward(self, x, groups=1):
+        """``groups`` > 1: x holds that many batches stacked along n, each normalised with its OWN BatchNorm statistics
+        (and the running buffers updated batch after batch) -- D(cat(real, fake), groups=2) is D(real), D(fake) of the
+        reference (core/lightning_module.py:112-119) in one pass.  Instance / no normalisation: per-sample anyway."""
+        if groups > 1 and self.norm == "batch_norm" and not self.training:
+            raise RuntimeError("stacked batches with their own statistics exist in training mode only")
+        return self.disc(x, groups)
 
 
 class _GenStack(nn.Sequential):

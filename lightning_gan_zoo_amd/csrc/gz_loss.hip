@@ -45,6 +45,39 @@ __global__ __launch_bounds__(LT) void bce_logits_mean_bwd_kernel(const float* __
     }
 }
 
+// Loss head of a discriminator step on the stacked batch [real; fake] (round 4): logits x[0..n) against t0 and
+// x[n..2n) against t1 in ONE launch.
+//   mode 0: (mean BCE(x[:n], t0) + mean BCE(x[n:], t1)) / 2        (DCGAN, core/lightning_module.py:114-120)
+//   mode 1: t0 * mean(x[:n]) + t1 * mean(x[n:])                     (WGAN critic loss with t0 = -1, t1 = +1, :168)
+__global__ __launch_bounds__(LT) void pair_loss_kernel(const float* __restrict__ x, float* __restrict__ loss, int n,
+                                                       float t0, float t1, int mode) {
+    __shared__ float red[4];
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = threadIdx.x; i < n; i += LT) {
+        const float a = x[i], b = x[n + i];
+        if (mode == 0) {
+            s0 += (fmaxf(a, 0.f) - a * t0) + log1pf(expf(-fabsf(a)));
+            s1 += (fmaxf(b, 0.f) - b * t1) + log1pf(expf(-fabsf(b)));
+        } else {
+            s0 += a;
+            s1 += b;
+        }
+    }
+    s0 = block_sum(s0, red);
+    s1 = block_sum(s1, red);
+    if (threadIdx.x == 0)
+        loss[0] = mode == 0 ? (s0 / (float)n + s1 / (float)n) / 2.f : t0 * (s0 / (float)n) + t1 * (s1 / (float)n);
+}
+
+__global__ __launch_bounds__(LT) void pair_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                           float* __restrict__ dx, int n, float t0, float t1, int mode) {
+    const float gs = g[0] / (float)n;
+    for (int i = blockIdx.x * LT + threadIdx.x; i < 2 * n; i += gridDim.x * LT) {
+        const float t = i < n ? t0 : t1;
+        dx[i] = mode == 0 ? (1.f / (1.f + expf(-x[i])) - t) * (gs * 0.5f) : t * gs;
+    }
+}
+
 __global__ __launch_bounds__(LT) void mse_mean_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                      float* __restrict__ loss, int n) {
     __shared__ float red[4];
@@ -163,6 +196,22 @@ int gz_bce_logits_mean_bwd(const float* x, const float* gloss, float* dx, int n,
     gz::clear_stale_error();
     if (n <= 0) return GZ_ERR_BAD_SHAPE;
     hipLaunchKernelGGL(bce_logits_mean_bwd_kernel, dim3(grid_for(n)), dim3(LT), 0, stream, x, gloss, dx, n, target);
+    return launch_status();
+}
+
+int gz_pair_loss(const float* x, float* loss, int n_each, float t0, float t1, int mode, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (n_each <= 0 || mode < 0 || mode > 1) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(pair_loss_kernel, dim3(1), dim3(LT), 0, stream, x, loss, n_each, t0, t1, mode);
+    return launch_status();
+}
+
+int gz_pair_loss_bwd(const float* x, const float* gloss, float* dx, int n_each, float t0, float t1, int mode,
+                     hipStream_t stream) {
+    gz::clear_stale_error();
+    if (n_each <= 0 || mode < 0 || mode > 1) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(pair_loss_bwd_kernel, dim3(grid_for(2 * n_each)), dim3(LT), 0, stream, x, gloss, dx, n_each, t0,
+                       t1, mode);
     return launch_status();
 }
 

@@ -86,53 +86,62 @@ __global__ __launch_bounds__(64) void channel_sum_finalize_kernel(const f32x2* _
 
 // BatchNorm finalize: one wavefront per channel; lanes stride over n, fp64 shuffle-combine.
 // coef[0*C..] = scale, coef[1*C..] = shift, coef[2*C..] = mean, coef[3*C..] = rstd
+// groups > 1 (round 4): the batch is `groups` independent statistics groups stacked along n -- the discriminator
+// applied to [real; fake] in ONE pass behaves like the reference's two calls: group g owns rows [g N/groups,
+// (g+1) N/groups), gets its own coefficients (index g*C + c, `count` elements per group) and updates the running
+// buffers in turn, in group order (num_batches_tracked += groups).
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void bn_finalize_kernel(const f32x2* __restrict__ sums,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ coef,
                                                          float* running_mean, float* running_var, long long* nbt,
                                                          int N, int C, int inner, float eps, float momentum,
-                                                         double count) {
+                                                         double count, int groups) {
     const int c = blockIdx.x, lane = threadIdx.x;
-    if (c == 0 && lane == 0 && nbt) *nbt += 1;
-    double s1 = 0.0, s2 = 0.0;
-    for (int n = lane; n < N; n += 64 * WAVES) {
-        f32x2 v = sums[(long long)n * C + c];
-        s1 += (double)v.x;
-        s2 += (double)v.y;
-    }
-    s1 = wave_sum_d(s1);
-    s2 = wave_sum_d(s2);
-    if constexpr (WAVES > 1) {       // many partial rows (per-tile statistics of a large layer): 4 wavefronts share the walk
-        __shared__ double part[WAVES][2];
-        if ((lane & 63) == 0) {
-            part[lane >> 6][0] = s1;
-            part[lane >> 6][1] = s2;
+    if (c == 0 && lane == 0 && nbt) *nbt += groups;
+    const int Ng = N / groups, NC = groups * C;
+    for (int g = 0; g < groups; ++g) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int n = lane; n < Ng; n += 64 * WAVES) {
+            f32x2 v = sums[(long long)(g * Ng + n) * C + c];
+            s1 += (double)v.x;
+            s2 += (double)v.y;
         }
-        __syncthreads();
-        s1 = s2 = 0.0;
+        s1 = wave_sum_d(s1);
+        s2 = wave_sum_d(s2);
+        if constexpr (WAVES > 1) {       // many partial rows (per-tile statistics of a large layer): 4 wavefronts share the walk
+            __shared__ double part[WAVES][2];
+            __syncthreads();             // (the previous group's readers are done)
+            if ((lane & 63) == 0) {
+                part[lane >> 6][0] = s1;
+                part[lane >> 6][1] = s2;
+            }
+            __syncthreads();
+            s1 = s2 = 0.0;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            s1 += part[w][0];
-            s2 += part[w][1];
+            for (int w = 0; w < WAVES; ++w) {
+                s1 += part[w][0];
+                s2 += part[w][1];
+            }
         }
-    }
-    if (lane != 0) return;
-    double cnt = count > 0.0 ? count : (double)N * inner;      // count > 0: `sums` are per-tile partials, not rows
-    double mean = s1 / cnt;
-    double var = s2 / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-    float scale = ga * rstd;
-    coef[c] = scale;
-    coef[C + c] = be - (float)mean * scale;
-    coef[2 * C + c] = (float)mean;
-    coef[3 * C + c] = rstd;
-    if (running_mean) {
-        double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        if (lane != 0) continue;
+        double cnt = count > 0.0 ? count : (double)Ng * inner;      // count > 0: `sums` are per-tile partials, not rows
+        double mean = s1 / cnt;
+        double var = s2 / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+        float scale = ga * rstd;
+        const int ci = g * C + c;
+        coef[ci] = scale;
+        coef[NC + ci] = be - (float)mean * scale;
+        coef[2 * NC + ci] = (float)mean;
+        coef[3 * NC + ci] = rstd;
+        if (running_mean) {
+            double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
     }
 }
 
@@ -157,12 +166,17 @@ struct ApplyGeom {
     long long total4;
     int q4;             // float4 per row
     FastDiv div_q4, div_c;
-    int C, per_channel, ncoef;   // ncoef = number of coefficient entries (C or rows)
+    int C, per_channel, ncoef;   // ncoef = number of coefficient entries (groups * C or rows)
+    int group_rows;              // per_channel with statistics groups: rows (n, c) per group = (N / groups) * C; 0 = one group
+    FastDiv div_grows;
 };
 
 __device__ __forceinline__ int coef_index(long long i4, const ApplyGeom& g) {
     uint32_t row = fdiv((uint32_t)i4, g.div_q4);
-    if (g.per_channel) row -= fdiv(row, g.div_c) * (uint32_t)g.C;
+    if (g.per_channel) {
+        const uint32_t grp = g.group_rows ? fdiv(row, g.div_grows) : 0u;
+        row = row - fdiv(row, g.div_c) * (uint32_t)g.C + grp * (uint32_t)g.C;
+    }
     return (int)row;
 }
 
@@ -314,7 +328,7 @@ __global__ __launch_bounds__(PW_THREADS) void norm_bwd_rowsums_kernel(const floa
                                                                       const float* __restrict__ coef,
                                                                       f32x2* __restrict__ sums, RowGeom g, int C,
                                                                       int per_channel, int ncoef, int act,
-                                                                      float slope) {
+                                                                      float slope, int group_rows) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * PW_THREADS + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * PW_THREADS) >> 6;
@@ -323,7 +337,7 @@ __global__ __launch_bounds__(PW_THREADS) void norm_bwd_rowsums_kernel(const floa
         long long row = row0 + sub;
         float s[2] = {0.f, 0.f};
         if (row < g.rows) {
-            int ci = per_channel ? (int)(row % C) : (int)row;
+            int ci = per_channel ? (int)(row % C) + (group_rows ? (int)(row / group_rows) * C : 0) : (int)row;
             float sc = coef[ci], sh = coef[ncoef + ci], mean = coef[2 * ncoef + ci], rstd = coef[3 * ncoef + ci];
             const f32x4* px = reinterpret_cast<const f32x4*>(x) + row * g.q4;
             const f32x4* pg = reinterpret_cast<const f32x4*>(gout) + row * g.q4;
@@ -344,24 +358,34 @@ __global__ __launch_bounds__(PW_THREADS) void norm_bwd_rowsums_kernel(const floa
 
 // BatchNorm: combine row sums over n -> k[0*C] = mean(dz), k[1*C] = mean(dz*xh); dgamma, dbeta.
 // One wavefront per channel.
+// (statistics groups: k per (group, channel); the affine gradients sum over the groups.  accumulate != 0: dgamma /
+// dbeta already hold earlier contributions -- the gradient sink of functional.py -- and are added to)
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const f32x2* __restrict__ sums, float* __restrict__ k,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             int N, int C, int inner) {
+                                                             int N, int C, int inner, int groups, int accumulate) {
     const int c = blockIdx.x, lane = threadIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int n = lane; n < N; n += 64) {
-        f32x2 v = sums[(long long)n * C + c];
-        s1 += (double)v.x;
-        s2 += (double)v.y;
+    const int Ng = N / groups, NC = groups * C;
+    double t1 = 0.0, t2 = 0.0;
+    for (int g = 0; g < groups; ++g) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int n = lane; n < Ng; n += 64) {
+            f32x2 v = sums[(long long)(g * Ng + n) * C + c];
+            s1 += (double)v.x;
+            s2 += (double)v.y;
+        }
+        s1 = wave_sum_d(s1);
+        s2 = wave_sum_d(s2);
+        if (lane == 0) {
+            double cnt = (double)Ng * inner;
+            k[g * C + c] = (float)(s1 / cnt);
+            k[NC + g * C + c] = (float)(s2 / cnt);
+        }
+        t1 += s1;
+        t2 += s2;
     }
-    s1 = wave_sum_d(s1);
-    s2 = wave_sum_d(s2);
     if (lane != 0) return;
-    double cnt = (double)N * inner;
-    k[c] = (float)(s1 / cnt);
-    k[C + c] = (float)(s2 / cnt);
-    if (dgamma) dgamma[c] = (float)s2;
-    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)t2;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)t1;
 }
 
 // per-row statistics: k = sums / inner (and per-row dgamma / dbeta for AdaIN-style affine)
@@ -725,7 +749,7 @@ static int ew_grid(long long total4) {
     return (int)b;
 }
 
-static ApplyGeom apply_geom(int N, int C, int inner, int per_channel) {
+static ApplyGeom apply_geom(int N, int C, int inner, int per_channel, int groups = 1) {
     ApplyGeom g;
     g.total4 = (long long)N * C * inner / 4;
     g.q4 = inner / 4;
@@ -733,9 +757,13 @@ static ApplyGeom apply_geom(int N, int C, int inner, int per_channel) {
     g.div_c = make_fastdiv(C);
     g.C = C;
     g.per_channel = per_channel;
-    g.ncoef = per_channel ? C : N * C;
+    g.ncoef = per_channel ? groups * C : N * C;
+    g.group_rows = (per_channel && groups > 1) ? (N / groups) * C : 0;
+    g.div_grows = make_fastdiv(g.group_rows ? g.group_rows : 1);
     return g;
 }
+
+static bool groups_ok(int N, int groups) { return groups >= 1 && groups <= 8 && N % groups == 0; }
 
 static bool norm_shape_ok(int N, int C, int inner) {
     return N > 0 && C > 0 && inner > 0 && (inner % 4) == 0 && (long long)N * C * inner * 4 < (1ll << 33) &&
@@ -766,30 +794,46 @@ size_t gz_norm_workspace_bytes(int N, int C) { return (size_t)N * C * sizeof(Sum
 
 int gz_norm_coef_elems(int N, int C, int per_channel) { return 4 * (per_channel ? C : N * C); }
 
-int gz_batchnorm_stats(const float* x, const float* gamma, const float* beta, float* coef, float* running_mean,
-                       float* running_var, long long* num_batches_tracked, void* workspace, int N, int C,
-                       int inner, float eps, float momentum, hipStream_t stream) {
+int gz_batchnorm_stats_g(const float* x, const float* gamma, const float* beta, float* coef, float* running_mean,
+                         float* running_var, long long* num_batches_tracked, void* workspace, int N, int C,
+                         int inner, float eps, float momentum, int groups, hipStream_t stream) {
     gz::clear_stale_error();
-    if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
+    if (!norm_shape_ok(N, C, inner) || !groups_ok(N, groups)) return GZ_ERR_BAD_SHAPE;
     RowGeom g = row_geom((long long)N * C, inner);
     hipLaunchKernelGGL(row_sums_kernel, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, (f32x2*)workspace, g);
     hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(C), dim3(64), 0, stream, (const f32x2*)workspace, gamma, beta, coef,
-                       running_mean, running_var, num_batches_tracked, N, C, inner, eps, momentum, 0.0);
+                       running_mean, running_var, num_batches_tracked, N, C, inner, eps, momentum, 0.0, groups);
+    return launch_status();
+}
+
+int gz_batchnorm_stats(const float* x, const float* gamma, const float* beta, float* coef, float* running_mean,
+                       float* running_var, long long* num_batches_tracked, void* workspace, int N, int C,
+                       int inner, float eps, float momentum, hipStream_t stream) {
+    return gz_batchnorm_stats_g(x, gamma, beta, coef, running_mean, running_var, num_batches_tracked, workspace, N, C,
+                                inner, eps, momentum, 1, stream);
+}
+
+int gz_batchnorm_finalize_g(const float* partials, int rows, long long count, const float* gamma, const float* beta,
+                            float* coef, float* running_mean, float* running_var, long long* num_batches_tracked,
+                            int C, float eps, float momentum, int groups, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (rows <= 0 || C <= 0 || count <= 0 || !groups_ok(rows, groups)) return GZ_ERR_BAD_SHAPE;
+    if (rows / groups > 512)
+        hipLaunchKernelGGL(bn_finalize_kernel<8>, dim3(C), dim3(512), 0, stream, (const f32x2*)partials, gamma, beta, coef,
+                           running_mean, running_var, num_batches_tracked, rows, C, 0, eps, momentum, (double)count,
+                           groups);
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(C), dim3(64), 0, stream, (const f32x2*)partials, gamma, beta, coef,
+                           running_mean, running_var, num_batches_tracked, rows, C, 0, eps, momentum, (double)count,
+                           groups);
     return launch_status();
 }
 
 int gz_batchnorm_finalize(const float* partials, int rows, long long count, const float* gamma, const float* beta,
                           float* coef, float* running_mean, float* running_var, long long* num_batches_tracked, int C,
                           float eps, float momentum, hipStream_t stream) {
-    gz::clear_stale_error();
-    if (rows <= 0 || C <= 0 || count <= 0) return GZ_ERR_BAD_SHAPE;
-    if (rows > 512)
-        hipLaunchKernelGGL(bn_finalize_kernel<8>, dim3(C), dim3(512), 0, stream, (const f32x2*)partials, gamma, beta, coef,
-                           running_mean, running_var, num_batches_tracked, rows, C, 0, eps, momentum, (double)count);
-    else
-        hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3(C), dim3(64), 0, stream, (const f32x2*)partials, gamma, beta, coef,
-                           running_mean, running_var, num_batches_tracked, rows, C, 0, eps, momentum, (double)count);
-    return launch_status();
+    return gz_batchnorm_finalize_g(partials, rows, count, gamma, beta, coef, running_mean, running_var,
+                                   num_batches_tracked, C, eps, momentum, 1, stream);
 }
 
 int gz_channel_sum(const float* x, float* out, void* workspace, int N, int C, int inner, hipStream_t stream) {
@@ -850,23 +894,48 @@ int gz_adain_const_bwd(const float* gout, const float* x, const float* coef, flo
     return launch_status();
 }
 
-int gz_norm_act_fwd(const float* x, const float* coef, float* out, int N, int C, int inner, int per_channel,
-                    int act, float slope, hipStream_t stream) {
+int gz_norm_act_fwd_g(const float* x, const float* coef, float* out, int N, int C, int inner, int per_channel,
+                      int groups, int act, float slope, hipStream_t stream) {
     gz::clear_stale_error();
-    if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
-    ApplyGeom g = apply_geom(N, C, inner, per_channel);
+    if (!norm_shape_ok(N, C, inner) || !groups_ok(N, groups) || (groups > 1 && !per_channel)) return GZ_ERR_BAD_SHAPE;
+    ApplyGeom g = apply_geom(N, C, inner, per_channel, groups);
     hipLaunchKernelGGL(norm_act_apply_kernel, dim3(ew_grid(g.total4)), dim3(PW_THREADS), 0, stream, x, coef, out, g,
                        act, slope);
     return launch_status();
 }
 
+int gz_norm_act_fwd(const float* x, const float* coef, float* out, int N, int C, int inner, int per_channel,
+                    int act, float slope, hipStream_t stream) {
+    return gz_norm_act_fwd_g(x, coef, out, N, C, inner, per_channel, 1, act, slope, stream);
+}
+
+static int norm_act_bwd_impl(const float* gout, const float* x, const float* coef, float* dx, float* dgamma, float* dbeta,
+                             void* workspace, float* kbuf, int N, int C, int inner, int per_channel, int affine_per_row,
+                             int unbiased, int act, float slope, int groups, int accumulate, hipStream_t stream);
+
 int gz_norm_act_bwd(const float* gout, const float* x, const float* coef, float* dx, float* dgamma, float* dbeta,
                     void* workspace, float* kbuf, int N, int C, int inner, int per_channel, int affine_per_row,
                     int unbiased, int act, float slope, hipStream_t stream) {
+    return norm_act_bwd_impl(gout, x, coef, dx, dgamma, dbeta, workspace, kbuf, N, C, inner, per_channel, affine_per_row,
+                             unbiased, act, slope, 1, 0, stream);
+}
+
+/* BatchNorm (per_channel) with statistics groups; accumulate != 0 adds the affine gradients to dgamma / dbeta */
+int gz_batchnorm_act_bwd_g(const float* gout, const float* x, const float* coef, float* dx, float* dgamma, float* dbeta,
+                           void* workspace, float* kbuf, int N, int C, int inner, int act, float slope, int groups,
+                           int accumulate, hipStream_t stream) {
+    if (!groups_ok(N, groups)) return GZ_ERR_BAD_SHAPE;
+    return norm_act_bwd_impl(gout, x, coef, dx, dgamma, dbeta, workspace, kbuf, N, C, inner, 1, 0, 0, act, slope, groups,
+                             accumulate, stream);
+}
+
+static int norm_act_bwd_impl(const float* gout, const float* x, const float* coef, float* dx, float* dgamma, float* dbeta,
+                             void* workspace, float* kbuf, int N, int C, int inner, int per_channel, int affine_per_row,
+                             int unbiased, int act, float slope, int groups, int accumulate, hipStream_t stream) {
     gz::clear_stale_error();
     if (!norm_shape_ok(N, C, inner)) return GZ_ERR_BAD_SHAPE;
     RowGeom rg = row_geom((long long)N * C, inner);
-    ApplyGeom g = apply_geom(N, C, inner, per_channel);
+    ApplyGeom g = apply_geom(N, C, inner, per_channel, groups);
     const bool unfused = knobs().norm_unfused;      // experiment: the three-launch path
     if (!per_channel && !unfused) {
         const bool channel_affine = !affine_per_row && (dgamma || dbeta);
@@ -887,10 +956,10 @@ int gz_norm_act_bwd(const float* gout, const float* x, const float* coef, float*
         return launch_status();
     }
     hipLaunchKernelGGL(norm_bwd_rowsums_kernel, dim3(row_grid(rg)), dim3(PW_THREADS), 0, stream, gout, x, coef,
-                       (f32x2*)workspace, rg, C, per_channel, g.ncoef, act, slope);
+                       (f32x2*)workspace, rg, C, per_channel, g.ncoef, act, slope, g.group_rows);
     if (per_channel) {
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, stream, (const f32x2*)workspace, kbuf, dgamma,
-                           dbeta, N, C, inner);
+                           dbeta, N, C, inner, groups, accumulate);
     } else {
         int rows = N * C;
         hipLaunchKernelGGL(row_bwd_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream,

@@ -407,6 +407,7 @@ class _SinkState:
     listener = None           # callable(param): every contribution of this backward pass has been queued
     pending = {}              # id(param) -> [param, [(slabs, nz, stride), ...]]
     uses = {}                 # id(param) -> forward uses not yet matched by a backward contribution
+    touched = set()           # id(param): gradient written in place during this pass (BatchNorm gamma / beta)
 
 
 _sinks = _SinkState()
@@ -418,6 +419,7 @@ def set_grad_sinks(enabled, listener=None):
     flush_grad_sinks()
     _sinks.enabled, _sinks.listener = bool(enabled), listener
     _sinks.uses.clear()
+    _sinks.touched.clear()
     return old
 
 
@@ -431,7 +433,7 @@ def reset_grad_sink_uses():
 
 
 def _sink_note_use(w):
-    if _sinks.enabled and w.requires_grad and torch.is_grad_enabled() and isinstance(w, torch.nn.Parameter):
+    if w is not None and _sinks.enabled and w.requires_grad and torch.is_grad_enabled() and isinstance(w, torch.nn.Parameter):
         _sinks.uses[id(w)] = _sinks.uses.get(id(w), 0) + 1
 
 
@@ -445,8 +447,23 @@ def _sink_done(w):
         _sinks.uses[k] = n - 1
         return
     del _sinks.uses[k]
-    if _sinks.listener is not None and k in _sinks.pending:
+    if _sinks.listener is not None and (k in _sinks.pending or k in _sinks.touched):
         _sinks.listener(w)
+
+
+def _sink_touch(p):
+    """``p.grad`` was written in place by a kernel (no pending slabs): count the use and tell the listener."""
+    k = id(p)
+    _sinks.touched.add(k)
+    n = _sinks.uses.get(k)
+    if n is None:
+        return
+    if n > 1:
+        _sinks.uses[k] = n - 1
+        return
+    del _sinks.uses[k]
+    if _sinks.listener is not None:
+        _sinks.listener(p)
 
 
 def _sink_conv_wgrad(w, x, g, geom):
@@ -935,41 +952,62 @@ def _norm_ws(x, N, C):
     return _ws(max(lib.gz_norm_workspace_bytes(N, C) // 4, 1), x.device)
 
 
+def _sink_small_grad(p):
+    """(target, accumulate) for a small parameter gradient a kernel can write / add in place (BatchNorm gamma, beta),
+    or None when the sinks are off.  A fresh ``p.grad`` is created on the spot; an existing one is accumulated into."""
+    if not _sinks.enabled or not isinstance(p, torch.nn.Parameter) or not p.requires_grad:
+        return None
+    if p.grad is None:
+        p.grad = torch.empty_like(p, memory_format=torch.contiguous_format)
+        return p.grad, 0
+    if not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
+        return None
+    return p.grad, 1
+
+
 class _BatchNormAct(torch.autograd.Function):
     """act(BatchNorm(x)); training mode updates the running buffers in place exactly like
-    nn.BatchNorm2d (momentum, unbiased running var, num_batches_tracked += 1)."""
+    nn.BatchNorm2d (momentum, unbiased running var, num_batches_tracked += 1).  ``groups`` > 1: the batch is that many
+    independent statistics groups stacked along n (gz_batchnorm_finalize_g) -- one pass over [real; fake] is the
+    reference's two discriminator calls."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act, slope, stats=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act, slope, stats=None,
+                groups=1):
         x = _req(x, "x")
         N, C = x.shape[:2]
         inner = x.numel() // (N * C)
-        coef = torch.empty(4 * C, device=x.device, dtype=torch.float32)
+        if groups > 1 and (not training or N % groups):
+            raise RuntimeError("statistics groups need training mode and a batch that is a multiple of the group count")
+        coef = torch.empty(4 * groups * C, device=x.device, dtype=torch.float32)
         st = _stream()
         if training and stats is not None and stats.numel():
             # partial sums written by the producing convolution's epilogue (conv2d_with_stats)
-            check(lib.gz_batchnorm_finalize(_p(stats), stats.shape[0], N * inner, _p(gamma), _p(beta), _p(coef),
-                                            _p(running_mean), _p(running_var), _p(nbt), C, eps, momentum, st),
-                  "batchnorm_finalize")
+            check(lib.gz_batchnorm_finalize_g(_p(stats), stats.shape[0], (N // groups) * inner, _p(gamma), _p(beta),
+                                              _p(coef), _p(running_mean), _p(running_var), _p(nbt), C, eps, momentum,
+                                              groups, st), "batchnorm_finalize")
         elif training:
             ws = _norm_ws(x, N, C)
-            check(lib.gz_batchnorm_stats(_p(x), _p(gamma), _p(beta), _p(coef), _p(running_mean), _p(running_var),
-                                         _p(nbt), _p(ws), N, C, inner, eps, momentum, st), "batchnorm_stats")
+            check(lib.gz_batchnorm_stats_g(_p(x), _p(gamma), _p(beta), _p(coef), _p(running_mean), _p(running_var),
+                                           _p(nbt), _p(ws), N, C, inner, eps, momentum, groups, st), "batchnorm_stats")
         else:
             check(lib.gz_batchnorm_eval_coef(_p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(coef), C,
                                              eps, st), "batchnorm_eval_coef")
         out = torch.empty_like(x)
-        check(lib.gz_norm_act_fwd(_p(x), _p(coef), _p(out), N, C, inner, 1, act, slope, st), "norm_act_fwd")
-        ctx.save_for_backward(x, coef)
-        ctx.cfg = (N, C, inner, act, slope, training)
+        check(lib.gz_norm_act_fwd_g(_p(x), _p(coef), _p(out), N, C, inner, 1, groups, act, slope, st), "norm_act_fwd")
+        ctx.save_for_backward(x, coef, gamma, beta)
+        ctx.cfg = (N, C, inner, act, slope, training, groups)
+        _sink_note_use(gamma)
+        _sink_note_use(beta)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gout):
-        x, coef = ctx.saved_tensors
-        N, C, inner, act, slope, training = ctx.cfg
+        x, coef, gamma, beta = ctx.saved_tensors
+        N, C, inner, act, slope, training, groups = ctx.cfg
         gout = _req(gout)
+        nones = (None,) * 10
         if not training:
             # eval mode: y = act(x * scale[c] + shift[c]) with constants from the running statistics -- a plain
             # per-channel affine, assembled from the row helpers (not on the training hot path)
@@ -986,24 +1024,46 @@ class _BatchNormAct(torch.autograd.Function):
             dbeta = _channel_sum_raw(gp)
             sgx = _rowdot_raw(gp.view(N * C, inner), x.view(N * C, inner), False).view(N, C).sum(0)
             dgamma = rstd * (sgx - mean * dbeta)
-            return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                    None, None, None, None, None, None, None, None, None)
+            for p in (gamma, beta):
+                _sink_done(p)
+            return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None) + nones
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
-        dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
-        dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
-        kbuf = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        # gradient sinks: the finalize kernel writes (or adds to) gamma.grad / beta.grad itself -- a discriminator applied
+        # twice per step otherwise pays a framework `add_` launch per affine parameter
+        sunk = None
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            sg, sb = _sink_small_grad(gamma), _sink_small_grad(beta)
+            if sg is not None and sb is not None and sg[1] == sb[1]:
+                sunk = (sg[0], sb[0], sg[1])
+        if sunk is not None:
+            dgamma, dbeta, accumulate = sunk
+        else:
+            dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+            dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
+            accumulate = 0
+        kbuf = torch.empty(2 * groups * C, device=x.device, dtype=torch.float32)
         ws = _norm_ws(x, N, C)
-        check(lib.gz_norm_act_bwd(_p(gout), _p(x), _p(coef), _p(dx), _p(dgamma), _p(dbeta), _p(ws), _p(kbuf), N, C,
-                                  inner, 1, 0, 0, act, slope, _stream()), "norm_act_bwd")
-        return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None,
-                None, None, None, None, None, None, None, None, None)
+        check(lib.gz_batchnorm_act_bwd_g(_p(gout), _p(x), _p(coef), _p(dx), _p(dgamma), _p(dbeta), _p(ws), _p(kbuf), N,
+                                         C, inner, act, slope, groups, accumulate, _stream()), "norm_act_bwd")
+        if sunk is not None:
+            _sink_touch(gamma)
+            _sink_touch(beta)
+            return (dx, None, None) + nones
+        for p in (gamma, beta):
+            _sink_done(p)
+        return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None) + nones
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, nbt, training, momentum=0.1, eps=1e-5,
-                   act=ACT_NONE, slope=0.0, stats=None):
+                   act=ACT_NONE, slope=0.0, stats=None, groups=1):
+    if groups > 1 and stats is not None and stats.numel():
+        # the convolution's partial rows must not straddle two groups: rows per group integral, pixels per row too
+        rows, M = stats.shape[0], x.shape[0] * (x.numel() // (x.shape[0] * x.shape[1]))
+        if rows % groups or M % rows or (M // groups) % (M // rows):
+            stats = None
     return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act, slope,
-                               stats)
+                               stats, groups)
 
 
 class _RowNormAct(torch.autograd.Function):
@@ -1579,6 +1639,42 @@ class _BCELogitsMean(torch.autograd.Function):
 
 def bce_logits_mean(logits, target):
     return _BCELogitsMean.apply(logits.reshape(-1), target)
+
+
+class _PairLoss(torch.autograd.Function):
+    """Loss head over the stacked logits [first half; second half] (gz_pair_loss): mode 0 = the mean of two BCE means
+    against constants t0 / t1, mode 1 = t0 * mean(first) + t1 * mean(second)."""
+
+    @staticmethod
+    def forward(ctx, x, t0, t1, mode):
+        x = _req(x, "logits").reshape(-1)
+        if x.numel() % 2:
+            raise RuntimeError("pair loss: an even number of logits (two stacked batches) is required")
+        loss = torch.empty(1, device=x.device, dtype=torch.float32)
+        check(lib.gz_pair_loss(_p(x), _p(loss), x.numel() // 2, float(t0), float(t1), int(mode), _stream()), "pair_loss")
+        ctx.save_for_backward(x)
+        ctx.cfg = (float(t0), float(t1), int(mode))
+        return loss.reshape(())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        t0, t1, mode = ctx.cfg
+        g = _req(g).reshape(1)
+        dx = torch.empty_like(x)
+        check(lib.gz_pair_loss_bwd(_p(x), _p(g), _p(dx), x.numel() // 2, t0, t1, mode, _stream()), "pair_loss_bwd")
+        return dx, None, None, None
+
+
+def bce_logits_pair_mean(logits, t_first, t_second):
+    """(BCE(logits[:n], t_first).mean() + BCE(logits[n:], t_second).mean()) / 2 in one launch."""
+    return _PairLoss.apply(logits.reshape(-1), t_first, t_second, 0)
+
+
+def weighted_half_means(logits, w_first, w_second):
+    """w_first * logits[:n].mean() + w_second * logits[n:].mean() in one launch."""
+    return _PairLoss.apply(logits.reshape(-1), w_first, w_second, 1)
 
 
 class _MSEMean(torch.autograd.Function):

@@ -141,6 +141,7 @@ def _hologan_pinned(init, img, bs, off):
         steps[name] = locate(cfg.model.lm["_target_"])(cfg, None)
     hip, cpu = steps["hip"], steps["cpu"]
     hip.real_first = False        # the tape is replayed in call order: keep the reference's (G(z), D(real), D(fake))
+    hip.stack_d_passes = False    # ... and its two discriminator calls
     if init != "default_init":
         scenario._prepare(hip, init == "stable")
     for net in ("generator", "discriminator"):
@@ -436,6 +437,7 @@ def test_product_with_reference_mask_decisions_every_gradient_at_1e3(expt):
     assert tape.cursor == len(tape.masks)
     product = build_product_step(expt, "full")
     product.real_first = False    # the reference's decisions are taped in ITS call order (G(z), D(real), D(fake))
+    product.stack_d_passes = False
     with pinned_product_masks(tape.rewind()):
         hip = scenario.run_scenario(product, inputs, "cuda", full=True, set_alpha=set_alpha, **PINNED_KW)
     assert tape.cursor == len(tape.masks), "product and reference took different numbers of mask decisions"
@@ -486,6 +488,7 @@ def test_real_first_order_is_bit_identical_to_the_reference_order(expt):
         torch.manual_seed(42)
         module = locate(cfg.model.lm["_target_"])(cfg, None).to("cuda")
         module.real_first = real_first
+        module.stack_d_passes = False     # (the stacked discriminator pass has no D(real) / G(z) order to compare)
         trainer = Trainer(module)
         torch.manual_seed(7)
         np.random.seed(7)

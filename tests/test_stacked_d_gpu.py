@@ -1,0 +1,106 @@
+"""Round 4: a discriminator step applies D once to the stacked batch [real; fake] with two BatchNorm statistics groups
+instead of twice (BaseGAN.stack_d_passes).  The arithmetic is the reference's -- per-call batch statistics, running
+buffers updated real then fake, the two passes' weight gradients summed -- so losses, every gradient and every buffer
+must agree with the two-call form to rounding."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("groups,N,C,inner", [(2, 16, 64, 256), (2, 8, 32, 16), (4, 16, 16, 64), (2, 6, 8, 4)])
+def test_grouped_batchnorm_matches_separate_calls(groups, N, C, inner):
+    """batch_norm_act(x, groups=G) == G separate training-mode calls on the slices: outputs, running buffers (updated
+    in group order), num_batches_tracked, dx, dgamma / dbeta (summed over the groups)."""
+    from lightning_gan_zoo_amd import functional as F
+    g = torch.Generator().manual_seed(5)
+    side = int(round(inner ** 0.5))
+    shape = (N, C, side, inner // side)
+    x = torch.randn(shape, generator=g).cuda()
+    gout = torch.randn(shape, generator=g).cuda()
+    gamma0 = (1 + 0.1 * torch.randn(C, generator=g)).cuda()
+    beta0 = (0.1 * torch.randn(C, generator=g)).cuda()
+    res = {}
+    for mode in ("grouped", "separate"):
+        xm = x.clone().requires_grad_(True)
+        gamma, beta = gamma0.clone().requires_grad_(True), beta0.clone().requires_grad_(True)
+        rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+        if mode == "grouped":
+            out = F.batch_norm_act(xm, gamma, beta, rm, rv, nbt, True, 0.1, 1e-5, F.ACT_LRELU, 0.2, None, groups)
+        else:
+            n = N // groups
+            out = torch.cat([F.batch_norm_act(xm[i * n:(i + 1) * n], gamma, beta, rm, rv, nbt, True, 0.1, 1e-5,
+                                              F.ACT_LRELU, 0.2) for i in range(groups)])
+        (out * gout).sum().backward()
+        res[mode] = (out.detach(), rm, rv, int(nbt), xm.grad, gamma.grad, beta.grad)
+    a, b = res["grouped"], res["separate"]
+    assert a[3] == b[3] == groups
+    for i, name in ((0, "out"), (1, "running_mean"), (2, "running_var"), (4, "dx"), (5, "dgamma"), (6, "dbeta")):
+        assert _rel(a[i], b[i]) < 2e-5, (name, _rel(a[i], b[i]))
+
+
+@pytest.mark.parametrize("expt,bs,features", [("dc_gan", 8, 16), ("dc_gan", 32, 64), ("wgan", 8, 16), ("dc_gan", 6, 8)])
+def test_stacked_discriminator_step_matches_two_calls(expt, bs, features):
+    """One D step + one G step from the same parameters, stacked and unstacked: losses, every discriminator gradient,
+    every BatchNorm buffer.  (bs 6 / features 8: the convolution's statistics rows straddle the two batches, the
+    stacked pass falls back to its own statistics pass.  features 64: LeakyReLU decisions on pre-activations that are
+    zero up to rounding differ between two summation orders of the same statistics -- DESIGN.md section 5 -- so the
+    gradients get the regression-guard bar of the un-pinned fixtures there, losses and buffers stay at 1e-5.)"""
+    from helpers import fill_closed_form, synthetic_noise, synthetic_real, FixedNoise
+    from lightning_gan_zoo_amd.config import locate, make_cfg
+    from lightning_gan_zoo_amd.harness import toggle_optimizer
+    out = {}
+    for stacked in (True, False):
+        cfg = make_cfg(expt, batch_size=bs, features=features, noise_dim=16)
+        torch.manual_seed(42)
+        m = locate(cfg.model.lm["_target_"])(cfg, None)
+        fill_closed_form(m.generator, 1)
+        fill_closed_form(m.discriminator, 2)
+        m = m.cuda()
+        m.stack_d_passes = stacked
+        m.real_first = False
+        m.noise_distn = FixedNoise(synthetic_noise(bs, 16, 40), synthetic_noise(bs, 16, 41))
+        real = synthetic_real(bs, seed=9).cuda()
+        labels = torch.zeros(bs, dtype=torch.int64, device="cuda")
+        toggle_optimizer(m, 0)
+        loss_d = m.training_step((real, labels), 0, 0)
+        loss_d.backward()
+        grads = {k: p.grad.clone() for k, p in m.discriminator.named_parameters()}
+        bufs = {k: b.clone() for k, b in m.discriminator.named_buffers()}
+        out[stacked] = (float(loss_d), grads, bufs)
+    (la, ga, ba), (lb, gb, bb) = out[True], out[False]
+    assert abs(la - lb) <= 1e-5 * max(1.0, abs(lb)), (la, lb)
+    gbar = 5e-2 if features >= 64 else 1e-4
+    for k in gb:
+        assert _rel(ga[k], gb[k]) < gbar, (k, _rel(ga[k], gb[k]))
+    for k in bb:
+        if bb[k].dtype.is_floating_point:
+            assert _rel(ba[k], bb[k]) < 1e-5, (k, _rel(ba[k], bb[k]))
+        else:
+            assert torch.equal(ba[k], bb[k]), k
+
+
+def test_trainer_trajectory_stacked_vs_two_calls():
+    """Three optimizer cycles of dc_gan through the Trainer, stacked (default) and unstacked."""
+    from helpers import synthetic_real
+    from lightning_gan_zoo_amd.config import locate, make_cfg
+    from lightning_gan_zoo_amd.harness import Trainer
+    res = {}
+    for stacked in (True, False):
+        cfg = make_cfg("dc_gan", batch_size=16, features=16, noise_dim=16)
+        torch.manual_seed(42)
+        module = locate(cfg.model.lm["_target_"])(cfg, None).to("cuda")
+        module.stack_d_passes = stacked
+        trainer = Trainer(module)
+        torch.manual_seed(7)
+        np.random.seed(7)
+        labels = torch.zeros(16, dtype=torch.int64, device="cuda")
+        res[stacked] = [float(trainer.step((synthetic_real(16, seed=700 + k).cuda(), labels))[0]) for k in range(6)]
+    for k, (a, b) in enumerate(zip(res[True], res[False])):
+        assert abs(a - b) <= (1e-5 if k < 2 else 5e-3) * max(1.0, abs(b)), (k, res)
