@@ -74,8 +74,17 @@ class _FlatGrads:
 class GradSync:
     """Plugs into harness.Trainer: ``before_step``, ``after_backward``, ``flush``."""
 
-    def __init__(self, module, process_group=None, overlap=True, bucket_bytes=BUCKET_BYTES):
+    def __init__(self, module, process_group=None, overlap=True, bucket_bytes=BUCKET_BYTES, broadcast_buffers=False):
         self.module = module
+        # torch DDP (the reference's accelerator="ddp", run_network.py:66) broadcasts rank 0's buffers -- the BatchNorm
+        # running statistics, num_batches_tracked, spectral norm's u / v -- to every rank at the top of EVERY forward
+        # (broadcast_buffers=True is its default).  Training-mode BatchNorm never reads the running statistics, so for
+        # the standard networks the losses and parameters do not depend on it; what does is (a) in-training evaluation
+        # on ranks > 0 and (b) HoloGAN's spectral-norm power iteration, which continues from u / v.  Default here:
+        # per-rank buffers during training, rank 0's at every checkpoint (sync_buffers) -- one collective per
+        # checkpoint instead of one per step; ``broadcast_buffers=True`` reproduces DDP's per-step broadcast (one
+        # coalesced broadcast per dtype at the top of each training_step).  tests/test_ddp_gloo.py states both.
+        self.broadcast_buffers = broadcast_buffers
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.overlap = overlap
@@ -159,7 +168,24 @@ class GradSync:
         self.works[idx].append(dist.all_reduce(fg.flat[start:end], op=dist.ReduceOp.SUM, group=self.group,
                                                async_op=True))
 
+    @torch.no_grad()
+    def _broadcast_all_buffers(self, src=0):
+        """DDP's ``_sync_buffers`` at the top of a forward: every buffer of the module takes rank ``src``'s value."""
+        by_dtype = {}
+        for b in self.module.buffers():
+            by_dtype.setdefault(b.dtype, []).append(b)
+        for bufs in by_dtype.values():
+            flat = torch.cat([b.reshape(-1) for b in bufs])
+            dist.broadcast(flat, src=src, group=self.group)
+            off = 0
+            for b in bufs:
+                n = b.numel()
+                b.copy_(flat[off:off + n].view_as(b))
+                off += n
+
     def before_step(self, optimizer_idx):
+        if self.broadcast_buffers and self.world > 1:
+            self._broadcast_all_buffers()
         if getattr(self.module, "mutates_discriminator_before_forward", False):
             self.finalize(0)     # WGAN clamps D's weights at the top of training_step
         self.finalize(optimizer_idx)     # a pending step of the SAME network must land before its next backward

@@ -194,6 +194,67 @@ def test_two_ranks_checkpoint_without_deadlock(tmp_path):
     assert blob["global_step"] == 5 and blob["epoch"] == 2
 
 
+def _buffer_worker(rank, world, port, broadcast, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from helpers import FixedNoise, synthetic_noise, synthetic_real
+        from lightning_gan_zoo_amd.config import locate, make_cfg
+        from lightning_gan_zoo_amd.ddp import GradSync
+        from lightning_gan_zoo_amd.harness import Trainer
+        cfg = make_cfg("dc_gan", module_root="oracle.reference_cpu", batch_size=4, features=8, noise_dim=16)
+        torch.manual_seed(42)
+        step = locate(cfg.model.lm["_target_"])(cfg, None)
+        sync = GradSync(step, broadcast_buffers=broadcast)
+        tr = Trainer(step, grad_sync=sync)
+        labels = torch.zeros(4, dtype=torch.int64)
+        for k in range(4):
+            step.noise_distn = FixedNoise(synthetic_noise(4, 16, 50 + 10 * k + rank))
+            tr.step((synthetic_real(4, seed=10 * k + rank), labels))         # every rank its own shard
+        tr.finish()
+
+        def same_as_rank0():
+            mine = torch.cat([b.detach().double().reshape(-1) for b in step.buffers()])
+            ref = mine.clone()
+            dist.broadcast(ref, src=0)
+            return float((mine - ref).abs().max())
+
+        before = same_as_rank0()
+        if broadcast:                    # DDP's broadcast happens at the TOP of a step: the last step's own update is
+            sync._broadcast_all_buffers()    # still local; one more forward (or a checkpoint) would broadcast it
+        sync.sync_buffers()
+        after = same_as_rank0()
+        params = torch.cat([p.detach().reshape(-1) for p in step.parameters()])
+        other = params.clone()
+        dist.broadcast(other, src=0)
+        ret[rank] = (before, after, bool(torch.equal(params, other)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("broadcast", [False, True])
+def test_batchnorm_buffers_under_data_parallelism(broadcast):
+    """States the one deviation from torch DDP: DDP broadcasts rank 0's buffers at the top of every
+    forward; GradSync keeps the BatchNorm running statistics per rank during training (training-mode BatchNorm never
+    reads them: parameters stay identical on all ranks either way) and broadcasts rank 0's at every checkpoint.
+    ``broadcast_buffers=True`` reproduces DDP: at most the last step's own update separates a rank from rank 0."""
+    world = 2
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_buffer_worker, args=(world, _free_port(), broadcast, ret), nprocs=world, join=True)
+    assert ret[0][2] and ret[1][2], "parameters diverged"
+    assert ret[0][0] == 0.0 and ret[0][1] == 0.0                 # rank 0 is the reference
+    assert ret[1][1] == 0.0                                      # after sync_buffers (what a checkpoint does): equal
+    drift = ret[1][0]
+    assert drift > 0.0                                           # rank 1's own statistics differ from rank 0's ...
+    if broadcast:
+        # ... but only by the last step's momentum-0.1 update of rank 1's own batch statistics on top of rank 0's
+        # buffers, not by four steps of independent history
+        mp_ret = mp.get_context("spawn").Manager().dict()
+        mp.spawn(_buffer_worker, args=(world, _free_port(), False, mp_ret), nprocs=world, join=True)
+        assert drift < mp_ret[1][0], (drift, mp_ret[1][0])
+
+
 def test_optimizer_schedule_follows_frequencies():
     from lightning_gan_zoo_amd.harness import optimizer_schedule
     assert optimizer_schedule([1, 1]) == [0, 1]

@@ -26,10 +26,13 @@ LR = {"dc_gan": 2e-4, "wgan": 5e-5, "wgan_gp": 1e-4, "hologan": 1e-4, "gan_stabi
 
 @pytest.mark.parametrize("size", ["tiny", "full"])
 @pytest.mark.parametrize("expt", scenario.ALL_EXPTS)
-def test_product_matches_reference_fixture(expt, size):
-    """Forward quantities at 1e-3 max-norm; gradient-side quantities at max(5e-3, 10 x the
-    reference's own fp32-vs-fp64 discrepancy) in relative L2 -- see compare().  The plain 1e-3 bar
-    on gradients is asserted on the stable-mask fixtures below."""
+def test_regression_guard_product_vs_unpinned_reference_fixture(expt, size):
+    """REGRESSION GUARD, not the parity statement for gradients.  Forward quantities at 1e-3 max-norm
+    -- that part IS the parity bar -- and gradient-side quantities at max(5e-3, 10 x the reference's own
+    fp32-vs-fp64 discrepancy) in relative L2 (see compare()): on these un-pinned fixtures a ReLU / LeakyReLU decision
+    on a pre-activation that is zero up to rounding lands on either side in two fp32 implementations.  The plain
+    1e-3 statements on every gradient are test_product_with_reference_mask_decisions_every_gradient_at_1e3 (the
+    reference's own decisions replayed) and test_product_matches_stable_mask_fixture below."""
     inputs, golden, cond = load_golden(expt, size)
     step = build_product_step(expt, size)
     full = size == "tiny"
@@ -265,6 +268,9 @@ def test_loss_trajectory_tracks_oracle(expt):
     2e-2 (observed over the pool's boxes: 3e-7 .. 9e-3 dc_gan, 1e-3 .. 1e-2 wgan_gp with a 5e-2 bar, 2e-7 R1), and the generator's eval-mode output (BatchNorm running statistics) is compared at
     the end with the oracle carrying the product's state."""
     from helpers import FixedNoise, synthetic_noise, synthetic_real
+    # the CPU oracle's summation order depends on the intra-op thread count (oneDNN partitions its reductions by
+    # thread): pinned, so that a box with another core count does not move the oracle's trajectory (VERDICT r3 8c)
+    torch.set_num_threads(8)
     kw = dict(batch_size=8, features=8, noise_dim=16)
     if expt == scenario.R1_EXPT:
         kw.update(features=4, img_size=32)
