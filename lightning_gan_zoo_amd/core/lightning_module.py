@@ -276,16 +276,28 @@ class WGANGP(BaseGAN):
         noise = self.sample_noise(len(real))
 
         if optimizer_idx == 0:
-            if self.real_first:
+            logits = None
+            if self.stack_d_passes:
+                # D(real) and D(fake.detach()) in one pass over the stacked batch (InstanceNorm: per-sample statistics,
+                # nothing couples the two halves); the penalty's D(x_hat) below stays a pass of its own
+                fake = self.generator(noise)
+                logits = self.stacked_discriminator(real, fake)
+                if logits is None:
+                    disc_real = self.discriminator(real).reshape(-1)
+            elif self.real_first:
                 disc_real = self.discriminator(real).reshape(-1)
                 fake = self.generator(noise)
             else:
                 fake = self.generator(noise)
                 disc_real = self.discriminator(real).reshape(-1)
-            disc_fake = self.discriminator(fake.detach()).reshape(-1)
+            if logits is None:
+                disc_fake = self.discriminator(fake.detach()).reshape(-1)
             # `fake` is NOT detached here, as in the reference (:195-196)
             gp = gradient_penalty(self.discriminator, real, fake, device=self.device, alpha=self.gp_alpha)
-            loss_disc = (self.cfg.loss_weight.lambda_gp * gp) - (torch.mean(disc_real) - torch.mean(disc_fake))
+            if logits is not None:
+                loss_disc = (self.cfg.loss_weight.lambda_gp * gp) + F.weighted_half_means(logits, -1.0, 1.0)
+            else:
+                loss_disc = (self.cfg.loss_weight.lambda_gp * gp) - (torch.mean(disc_real) - torch.mean(disc_fake))
             self.log("train/d_loss", loss_disc)
             return loss_disc
 

@@ -45,7 +45,8 @@ def test_grouped_batchnorm_matches_separate_calls(groups, N, C, inner):
         assert _rel(a[i], b[i]) < 2e-5, (name, _rel(a[i], b[i]))
 
 
-@pytest.mark.parametrize("expt,bs,features", [("dc_gan", 8, 16), ("dc_gan", 32, 64), ("wgan", 8, 16), ("dc_gan", 6, 8)])
+@pytest.mark.parametrize("expt,bs,features", [("dc_gan", 8, 16), ("dc_gan", 32, 64), ("wgan", 8, 16), ("dc_gan", 6, 8),
+                                              ("wgan_gp", 8, 16)])
 def test_stacked_discriminator_step_matches_two_calls(expt, bs, features):
     """One D step + one G step from the same parameters, stacked and unstacked: losses, every discriminator gradient,
     every BatchNorm buffer.  (bs 6 / features 8: the convolution's statistics rows straddle the two batches, the
@@ -66,6 +67,8 @@ def test_stacked_discriminator_step_matches_two_calls(expt, bs, features):
         m.stack_d_passes = stacked
         m.real_first = False
         m.noise_distn = FixedNoise(synthetic_noise(bs, 16, 40), synthetic_noise(bs, 16, 41))
+        if expt == "wgan_gp":
+            m.gp_alpha = torch.rand(bs, 1, 1, 1, generator=torch.Generator().manual_seed(3)).cuda()
         real = synthetic_real(bs, seed=9).cuda()
         labels = torch.zeros(bs, dtype=torch.int64, device="cuda")
         toggle_optimizer(m, 0)
