@@ -308,6 +308,9 @@ int gz_batchnorm_finalize_g(const float* partials, int rows, long long count, co
                             int C, float eps, float momentum, int groups, hipStream_t stream);
 int gz_norm_act_fwd_g(const float* x, const float* coef, float* out, int N, int C, int inner, int per_channel,
                       int groups, int act, float slope, hipStream_t stream);
+int gz_rownorm_act_bwd_acc(const float* gout, const float* x, const float* coef, float* dx, float* dgamma, float* dbeta,
+                           void* workspace, float* kbuf, int N, int C, int inner, int act, float slope, int accumulate,
+                           hipStream_t stream);       /* InstanceNorm(affine) first-order backward, same option */
 int gz_batchnorm_act_bwd_g(const float* gout, const float* x, const float* coef, float* dx, float* dgamma, float* dbeta,
                            void* workspace, float* kbuf, int N, int C, int inner, int act, float slope, int groups,
                            int accumulate, hipStream_t stream);

@@ -411,7 +411,7 @@ __global__ void row_bwd_finalize_kernel(const f32x2* __restrict__ sums, float* _
 // per-channel affine over per-row statistics (InstanceNorm): dgamma[c] = sum_n s2[n,c], dbeta[c] = sum_n s1[n,c]
 __global__ __launch_bounds__(64) void row_bwd_affine_kernel(const f32x2* __restrict__ sums,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int N, int C) {
+                                                            int N, int C, int accumulate = 0) {
     const int c = blockIdx.x, lane = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
     for (int n = lane; n < N; n += 64) {
@@ -422,8 +422,8 @@ __global__ __launch_bounds__(64) void row_bwd_affine_kernel(const f32x2* __restr
     s1 = wave_sum_d(s1);
     s2 = wave_sum_d(s2);
     if (lane != 0) return;
-    if (dgamma) dgamma[c] = (float)s2;
-    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
 }
 
 __global__ __launch_bounds__(PW_THREADS) void norm_bwd_apply_kernel(const float* __restrict__ gout,
@@ -920,6 +920,15 @@ int gz_norm_act_bwd(const float* gout, const float* x, const float* coef, float*
                              unbiased, act, slope, 1, 0, stream);
 }
 
+/* InstanceNorm with per-channel affine (per_channel = 0, affine_per_row = 0): accumulate != 0 adds the affine gradients
+ * to dgamma / dbeta (gradient sinks; first-order backward only) */
+int gz_rownorm_act_bwd_acc(const float* gout, const float* x, const float* coef, float* dx, float* dgamma, float* dbeta,
+                           void* workspace, float* kbuf, int N, int C, int inner, int act, float slope, int accumulate,
+                           hipStream_t stream) {
+    return norm_act_bwd_impl(gout, x, coef, dx, dgamma, dbeta, workspace, kbuf, N, C, inner, 0, 0, 0, act, slope, 1,
+                             accumulate, stream);
+}
+
 /* BatchNorm (per_channel) with statistics groups; accumulate != 0 adds the affine gradients to dgamma / dbeta */
 int gz_batchnorm_act_bwd_g(const float* gout, const float* x, const float* coef, float* dx, float* dgamma, float* dbeta,
                            void* workspace, float* kbuf, int N, int C, int inner, int act, float slope, int groups,
@@ -952,7 +961,7 @@ static int norm_act_bwd_impl(const float* gout, const float* x, const float* coe
 #undef GZ_RB
         if (channel_affine)
             hipLaunchKernelGGL(row_bwd_affine_kernel, dim3(C), dim3(64), 0, stream, (const f32x2*)workspace, dgamma,
-                               dbeta, N, C);
+                               dbeta, N, C, accumulate);
         return launch_status();
     }
     hipLaunchKernelGGL(norm_bwd_rowsums_kernel, dim3(row_grid(rg)), dim3(PW_THREADS), 0, stream, gout, x, coef,
@@ -966,7 +975,7 @@ static int norm_act_bwd_impl(const float* gout, const float* x, const float* coe
                            (const f32x2*)workspace, kbuf, dgamma, dbeta, N, C, inner, affine_per_row, unbiased);
         if (!affine_per_row && (dgamma || dbeta))
             hipLaunchKernelGGL(row_bwd_affine_kernel, dim3(C), dim3(64), 0, stream, (const f32x2*)workspace, dgamma,
-                               dbeta, N, C);
+                               dbeta, N, C, accumulate);
     }
     if (dx)
         hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(ew_grid(g.total4)), dim3(PW_THREADS), 0, stream, gout, x, coef,

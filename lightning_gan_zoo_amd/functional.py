@@ -952,17 +952,25 @@ def _norm_ws(x, N, C):
     return _ws(max(lib.gz_norm_workspace_bytes(N, C) // 4, 1), x.device)
 
 
-def _sink_small_grad(p):
-    """(target, accumulate) for a small parameter gradient a kernel can write / add in place (BatchNorm gamma, beta),
-    or None when the sinks are off.  A fresh ``p.grad`` is created on the spot; an existing one is accumulated into."""
-    if not _sinks.enabled or not isinstance(p, torch.nn.Parameter) or not p.requires_grad:
+def _sink_small_pair(a, b):
+    """(a.grad, b.grad, accumulate) for two small parameter gradients one kernel writes / adds in place (a norm's
+    gamma and beta), or None when the sinks are off or the pair cannot be taken TOGETHER (nothing is touched then).
+    Fresh gradients are created on the spot (accumulate 0); existing ones are accumulated into (1)."""
+    if not _sinks.enabled:
         return None
-    if p.grad is None:
-        p.grad = torch.empty_like(p, memory_format=torch.contiguous_format)
-        return p.grad, 0
-    if not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
+    for p in (a, b):
+        if not isinstance(p, torch.nn.Parameter) or not p.requires_grad:
+            return None
+    if (a.grad is None) != (b.grad is None):
         return None
-    return p.grad, 1
+    if a.grad is None:
+        a.grad = torch.empty_like(a, memory_format=torch.contiguous_format)
+        b.grad = torch.empty_like(b, memory_format=torch.contiguous_format)
+        return a.grad, b.grad, 0
+    for p in (a, b):
+        if not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
+            return None
+    return a.grad, b.grad, 1
 
 
 class _BatchNormAct(torch.autograd.Function):
@@ -1031,11 +1039,7 @@ class _BatchNormAct(torch.autograd.Function):
         dx = torch.empty_like(x) if need_dx else None
         # gradient sinks: the finalize kernel writes (or adds to) gamma.grad / beta.grad itself -- a discriminator applied
         # twice per step otherwise pays a framework `add_` launch per affine parameter
-        sunk = None
-        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
-            sg, sb = _sink_small_grad(gamma), _sink_small_grad(beta)
-            if sg is not None and sb is not None and sg[1] == sb[1]:
-                sunk = (sg[0], sb[0], sg[1])
+        sunk = _sink_small_pair(gamma, beta) if (ctx.needs_input_grad[1] and ctx.needs_input_grad[2]) else None
         if sunk is not None:
             dgamma, dbeta, accumulate = sunk
         else:
@@ -1079,14 +1083,34 @@ class _RowNormAct(torch.autograd.Function):
         out = torch.empty_like(x)
         check(lib.gz_rownorm_act_fwd(_p(x), _p(gamma), _p(beta), _p(coef), _p(out), N, C, inner, eps, 0, 0, act, slope,
                                      _stream()), "rownorm_act_fwd")
-        ctx.save_for_backward(x, gamma, coef)
+        ctx.save_for_backward(x, gamma, coef, beta)
         ctx.cfg = (N, C, inner, act, slope)
+        _sink_note_use(gamma)
+        _sink_note_use(beta)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        x, gamma, coef = ctx.saved_tensors
+        x, gamma, coef, beta = ctx.saved_tensors
+        if (not torch.is_grad_enabled() and gamma is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]):
+            # first-order backward under gradient sinks: the affine gradients are written / added in place
+            sunk = _sink_small_pair(gamma, beta)
+            if sunk is not None:
+                N, C, inner, act, slope = ctx.cfg
+                gout = _req(gout)
+                dx = torch.empty_like(x)
+                kbuf = torch.empty(2 * N * C, device=x.device, dtype=torch.float32)
+                ws = _norm_ws(x, N, C)
+                check(lib.gz_rownorm_act_bwd_acc(_p(gout), _p(x), _p(coef), _p(dx), _p(sunk[0]), _p(sunk[1]), _p(ws),
+                                                 _p(kbuf), N, C, inner, act, slope, sunk[2], _stream()),
+                      "rownorm_act_bwd")
+                _sink_touch(gamma)
+                _sink_touch(beta)
+                return (dx if ctx.needs_input_grad[0] else None), None, None, None, None, None
         dx, dgamma, dbeta = _RowNormActBwd.apply(gout, x, gamma, coef, ctx.cfg)
+        for p in (gamma, beta):
+            if p is not None:
+                _sink_done(p)
         return (dx if ctx.needs_input_grad[0] else None,
                 dgamma if (gamma is not None and ctx.needs_input_grad[1]) else None,
                 dbeta if (gamma is not None and ctx.needs_input_grad[2]) else None, None, None, None)

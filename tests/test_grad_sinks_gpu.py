@@ -117,3 +117,38 @@ def test_trainer_with_and_without_sinks_tracks(expt):
     for k, (a, b) in enumerate(zip(res[True], res[False])):
         bar = 1e-5 if k < 2 else (5e-2 if expt == "wgan_gp" else 2e-3)
         assert abs(a - b) <= bar * max(1.0, abs(b)), (k, res[True], res[False])
+
+
+@pytest.mark.parametrize("norm", ["batch", "instance"])
+def test_norm_affine_gradients_are_written_in_place(norm):
+    """BatchNorm / InstanceNorm(affine) gamma and beta: under sinks the finalize kernel writes the first contribution
+    into a fresh ``p.grad`` and ADDS the second (a discriminator applied twice) -- equal to autograd's accumulation."""
+    from lightning_gan_zoo_amd import functional as F
+    g = torch.Generator().manual_seed(2)
+    C = 32
+    xs = [torch.randn(8, C, 16, 16, generator=g).cuda() for _ in range(2)]
+    gamma = torch.nn.Parameter((1 + 0.1 * torch.randn(C, generator=g)).cuda())
+    beta = torch.nn.Parameter((0.1 * torch.randn(C, generator=g)).cuda())
+
+    def loss():
+        tot = 0.0
+        for x in xs:
+            if norm == "batch":
+                rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+                nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+                y = F.batch_norm_act(x, gamma, beta, rm, rv, nbt, True, 0.1, 1e-5, F.ACT_LRELU, 0.2)
+            else:
+                y = F.instance_norm_act(x, gamma, beta, 1e-5, F.ACT_LRELU, 0.2)
+            tot = tot + (y * y).mean()
+        return tot
+
+    loss().backward()
+    plain = (gamma.grad.clone(), beta.grad.clone())
+    gamma.grad = beta.grad = None
+    prev = F.set_grad_sinks(True)
+    try:
+        loss().backward()
+        F.flush_grad_sinks()
+    finally:
+        F.set_grad_sinks(*prev)
+    assert _rel(gamma.grad, plain[0]) < 1e-5 and _rel(beta.grad, plain[1]) < 1e-5
