@@ -27,8 +27,12 @@ using Cfg256x256 = TileCfg2<2, 2, 4, 1>;
 using Cfg256x128 = TileCfg2<2, 2, 2, 2>;
 using Cfg512x64 = TileCfg2<4, 1, 2, 2>;       // 64 output channels in all (D.block1-size input gradients)
 using Cfg128x256 = TileCfg2<1, 4, 2, 2>;      // weight gradient with 128 output channels
+// round 4: 256 x 64 (wavefronts 2 x 2 of 128 x 32, 64 accumulator registers): twice the tiles of 256x128 for launches
+// that would otherwise put one workgroup on a CU or split their reduction; three workgroups per CU (37-42 KB of LDS)
+using Cfg256x64 = TileCfg2<2, 2, 1, 3>;
 
-enum TileId { T128x128 = 0, T128x64 = 1, T128x32 = 2, T64x64 = 3, T256x256 = 4, T256x128 = 5, T512x64 = 6, T128x256 = 7 };
+enum TileId { T128x128 = 0, T128x64 = 1, T128x32 = 2, T64x64 = 3, T256x256 = 4, T256x128 = 5, T512x64 = 6, T128x256 = 7,
+              T256x64 = 8 };
 static bool is_tile2(TileId t) { return t >= T256x256; }
 
 // Which launches take the igemm2 skeleton: its workgroup is a whole CU's worth of matrix pipes (one wavefront per
@@ -46,11 +50,24 @@ static TileId pick_tile2(long long M, long long N, int ny, int kdim) {
     const long long t256 = ((M + 255) / 256) * ((N + 255) / 256) * ny;
     const int force = knobs().igemm2_tile;
     const int cu = cus();
+    // round 4: 256x64 tiles (three workgroups per CU) where 256x128 would put fewer than two workgroups on a CU and
+    // 256x64 gives every CU at least one: bs 128, D.block1 forward 95 -> 115 TFLOP/s, D.block2's input gradient 92 ->
+    // 111; bs 256 (the stacked discriminator pass of bs 128): D.block2 forward 114 -> 124, D.block3's input gradient
+    // 107 -> 119; every launch with >= 512 tiles of 256x128 keeps them (tools/conv_bench2.py, GZ_NO_TILE64=1)
     if (force == 256 && N >= 256 && t256 >= cu) return T256x256;
     if (force == 128 && t128 >= cu) return T256x128;
     if (t128 >= 2 * cu) return T256x128;
-    if (N >= 256 && t256 >= cu) return T256x256;
+    if (N >= 256 && t256 >= cu) return T256x256;        // (round 3's choice where it applies: kept)
     if (t128 >= cu) return T256x128;
+    // round 4: 256x64 tiles (three workgroups per CU) where 256x128 tiles would not give every CU a workgroup and the
+    // launch would split its reduction instead: bs 128, D.block1 forward 95 -> 115 TFLOP/s, D.block2's input gradient
+    // 92 -> 111; bs 256 (the stacked discriminator pass of bs 128): D.block2 forward 114 -> 124, D.block3's input
+    // gradient 107 -> 119.  Launches with 256-511 tiles of 256x128 keep them (bs 512: 256x64 measured 2-5 % slower
+    // there).  tools/conv_bench2.py, GZ_NO_TILE64=1.
+    if (!knobs().no_tile64 && force == 0 && (N & 63) == 0) {
+        const long long t64 = ((M + 255) / 256) * ((N + 63) / 64) * ny;
+        if (t64 >= cu) return T256x64;
+    }
     return T64x64;
 }
 
@@ -110,6 +127,7 @@ struct SplitPlan {
 static long long tile_count(TileId t, long long M, long long N, int ny) {
     if (t == T256x256 || t == T256x128) return ((M + 255) / 256) * ((N + (t == T256x256 ? 255 : 127)) / (t == T256x256 ? 256 : 128)) * ny;
     if (t == T512x64) return ((M + 511) / 512) * ((N + 63) / 64) * ny;
+    if (t == T256x64) return ((M + 255) / 256) * ((N + 63) / 64) * ny;
     const int bm = t == T64x64 ? 64 : 128;
     const int bn = t == T128x128 ? 128 : (t == T128x32 ? 32 : 64);
     return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * ny;
@@ -541,16 +559,18 @@ static SplitPlan fwd2_plan(const ConvShape& s) {
     if (!fwd2_ok<G>(s)) return fwdtap2_plan<G>(s);
     const long long M = (long long)s.N * s.OH * s.OW;
     TileId t = s.K > 64 ? pick_tile2(M, s.K, 1, s.C * 16) : T64x64;
-    if (t == T256x256 || t == T256x128) return SplitPlan{t, 1};
+    if (t == T256x256 || t == T256x128 || t == T256x64) return SplitPlan{t, 1};
     const bool off = knobs().no_igemm2;
     if (off || s.K < 128) return SplitPlan{T64x64, 1};
-    const long long tiles = ((M + 255) / 256) * ((s.K + 127) / 128);
+    // split launches take the 256x64 tile when the channel count allows: twice the tiles, half the slabs
+    const bool t64 = !knobs().no_tile64 && (s.K & 63) == 0;
+    const long long tiles = ((M + 255) / 256) * (t64 ? (s.K + 63) / 64 : (s.K + 127) / 128);
     const int chunks = s.C;
-    const int min_tiles = knobs().fwd2_min_tiles;
+    const int min_tiles = knobs().fwd2_min_tiles * (t64 ? 2 : 1);
     if (tiles >= min_tiles && chunks >= 64) {
         int splits = (int)((cus() + tiles - 1) / tiles);
         while (splits > 1 && chunks / splits < 32) --splits;
-        if (splits > 1 && tiles * splits >= cus()) return SplitPlan{T256x128, splits};
+        if (splits > 1 && tiles * splits >= cus()) return SplitPlan{t64 ? T256x64 : T256x128, splits};
     }
     return SplitPlan{T64x64, 1};
 }
@@ -560,7 +580,7 @@ static SplitPlan fwd_plan(const ConvShape& s) {
     long long M = (long long)s.N * s.OH * s.OW;
     {
         const SplitPlan p2 = fwd2_plan<G>(s);
-        if (p2.tile == T256x256 || p2.tile == T256x128) return p2;
+        if (p2.tile == T256x256 || p2.tile == T256x128 || p2.tile == T256x64) return p2;
     }
     return plan_split(M, s.K, fwd_kdim<G>(s), 1, pick_tile_fwd(M, s.K, s.OW, G::kh, G::kw, G::s, fwd_kdim<G>(s)));
 }
@@ -578,12 +598,13 @@ static int dispatch_fwd(const float* x, const float* wp, const float* bias, floa
     if (sp.splits > 1 && (!ws || ws_bytes < fwd_ws_bytes<G>(s)))
         sp = SplitPlan{pick_tile_fwd(M, s.K, s.OW, G::kh, G::kw, G::s, 0), 1};
     float* slab = sp.splits > 1 ? ws : nullptr;
-    if ((sp.tile == T256x256 || sp.tile == T256x128) && fwd2_ok<G>(s) && (((uintptr_t)x) & 15) != 0) {
+    if (is_tile2(sp.tile) && fwd2_ok<G>(s) && (((uintptr_t)x) & 15) != 0) {
         sp = SplitPlan{pick_tile_fwd(M, s.K, s.OW, G::kh, G::kw, G::s, 0), 1};      // unaligned tensor
         slab = nullptr;
     }
     switch (sp.tile) {
         case T256x256: return run_fwd2_ow<Cfg256x256>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
+        case T256x64: return run_fwd2_ow<Cfg256x64>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
         case T256x128:
             if (!fwd2_ok<G>(s)) return run_fwdtap2<G, Cfg256x128>(x, wp, bias, y, s, act, slope, st, sp.splits, slab, nullptr);
             return run_fwd2_ow<Cfg256x128>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
@@ -1038,13 +1059,14 @@ static SplitPlan dgrad_plan(const ConvShape& s) {
         // 64-255 tiles of 256x128 (small batches, deep layers): cut the reduction so that >= 256 workgroups exist,
         // each with >= 32 chunks (as the forward convolution does)
         const bool off = knobs().no_igemm2;
-        const long long tiles = ((M + 255) / 256) * ((s.C + 127) / 128) * 4;
+        const bool t64 = !knobs().no_tile64 && (s.C & 63) == 0;
+        const long long tiles = ((M + 255) / 256) * (t64 ? (s.C + 63) / 64 : (s.C + 127) / 128) * 4;
         const int chunks = s.K / 4;
-        const int min_tiles = knobs().dg2_min_tiles;
+        const int min_tiles = knobs().dg2_min_tiles * (t64 ? 2 : 1);
         if (!off && s.C >= 128 && tiles >= min_tiles && tiles < cus() && chunks >= 64) {
             int splits = (int)((cus() + tiles - 1) / tiles);
             while (splits > 1 && chunks / splits < 32) --splits;
-            if (splits > 1 && tiles * splits >= cus()) return SplitPlan{T256x128, splits};
+            if (splits > 1 && tiles * splits >= cus()) return SplitPlan{t64 ? T256x64 : T256x128, splits};
         }
     }
     {
@@ -1096,6 +1118,7 @@ static int dispatch_dgrad(const float* y, const float* wp, const float* bias, fl
             if (!dgrad2_ok<G>(s)) return run_dgradtap2<G, Cfg256x128>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
             return run_dgrad2<Cfg256x128>(y, wp, bias, x, s, act, slope, st, nullptr, sp.splits, slab);
         case T512x64: return run_dgrad2<Cfg512x64>(y, wp, bias, x, s, act, slope, st);
+        case T256x64: return run_dgrad2<Cfg256x64>(y, wp, bias, x, s, act, slope, st, nullptr, sp.splits, slab);
         case T128x128: return run_dgrad<G, Cfg128x128>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
         case T128x64: return run_dgrad<G, Cfg128x64>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
         case T128x32: return run_dgrad<G, Cfg128x32>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
@@ -1935,6 +1958,7 @@ static int stats_wm(TileId t) { return t == T128x32 ? 4 : 2; }
 static int stats_tm_rows(TileId t, long long M) {       // partial rows per phase: tiles_m * WM
     if (t == T256x256 || t == T256x128) return (int)((M + 255) / 256) * 2;
     if (t == T512x64) return (int)((M + 511) / 512) * 4;
+    if (t == T256x64) return (int)((M + 255) / 256) * 2;
     const int bm = t == T64x64 ? 64 : 128;
     return (int)((M + bm - 1) / bm) * stats_wm(t);
 }
@@ -1967,6 +1991,7 @@ int gz_conv2d_fwd_stats_ws(const float* x, const float* wpack, float* y, float* 
         float* slab = sp.splits > 1 ? workspace : nullptr;                                                           \
         switch (sp.tile) {                                                                                           \
             case T256x256: return run_fwd2_ow<Cfg256x256>(x, wpack, nullptr, y, s, 0, 0.f, stream, sp.splits, slab, stats); \
+            case T256x64: return run_fwd2_ow<Cfg256x64>(x, wpack, nullptr, y, s, 0, 0.f, stream, sp.splits, slab, stats); \
             case T256x128:                                                                                           \
                 if (!fwd2_ok<G>(s)) return run_fwdtap2<G, Cfg256x128>(x, wpack, nullptr, y, s, 0, 0.f, stream, sp.splits, slab, stats); \
                 return run_fwd2_ow<Cfg256x128>(x, wpack, nullptr, y, s, 0, 0.f, stream, sp.splits, slab, stats);     \
@@ -2017,6 +2042,7 @@ int gz_conv2d_dgrad_stats_ws(const float* y, const float* wpack, float* x, float
             case T256x256: return run_dgrad2<Cfg256x256>(y, wpack, nullptr, x, s, 0, 0.f, stream, stats);               \
             case T256x128: return run_dgrad2<Cfg256x128>(y, wpack, nullptr, x, s, 0, 0.f, stream, stats, sp.splits, slab); \
             case T512x64: return run_dgrad2<Cfg512x64>(y, wpack, nullptr, x, s, 0, 0.f, stream, stats);                 \
+            case T256x64: return run_dgrad2<Cfg256x64>(y, wpack, nullptr, x, s, 0, 0.f, stream, stats, sp.splits, slab); \
             case T128x128: return run_dgrad<G, Cfg128x128>(y, wpack, nullptr, x, s, 0, 0.f, stream, sp.splits, slab, stats); \
             case T128x64: return run_dgrad<G, Cfg128x64>(y, wpack, nullptr, x, s, 0, 0.f, stream, sp.splits, slab, stats);   \
             case T128x32: return run_dgrad<G, Cfg128x32>(y, wpack, nullptr, x, s, 0, 0.f, stream, sp.splits, slab, stats);   \
@@ -2097,7 +2123,7 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
         if (KH == 4 && KW == 4 && S == 2) {
             ConvShape s{N, C, H, W, K, OH, OW};
             const SplitPlan p2 = fwd2_plan<G4421>(s);
-            if (p2.tile == T256x256 || p2.tile == T256x128) return p2.tile;
+            if (p2.tile == T256x256 || p2.tile == T256x128 || p2.tile == T256x64) return p2.tile;
         }
         if ((KH == 5 && KW == 5 && S == 2) || (KH == 3 && KW == 3 && S == 1) || (KH == 1 && KW == 1 && S == 1)) {
             ConvShape s{N, C, H, W, K, OH, OW};
@@ -2162,6 +2188,7 @@ static const char* tile_text(TileId t) {
         case T256x256: return "256x256";
         case T256x128: return "256x128";
         case T512x64: return "512x64";
+        case T256x64: return "256x64";
         default: return "128x256";
     }
 }

@@ -2534,6 +2534,12 @@ __device__ __forceinline__ void mfma_row(f32x16 (&c)[2], float a, const float (&
                  : "+a"(c[0]), "+a"(c[1])
                  : "v"(a), "v"(b[0]), "v"(b[1]));
 }
+__device__ __forceinline__ void mfma_row(f32x16 (&c)[1], float a, const float (&b)[1]) {
+    asm volatile(GZ2_NOP
+                 "v_mfma_f32_32x32x2_f32 %0, %2, %1, %0"
+                 : "+a"(c[0])
+                 : "v"(a), "v"(b[0]));
+}
 // D[m][n] order (lanes along n): row-major outputs (weight gradient slabs)
 __device__ __forceinline__ void mfma_row_mn(f32x16 (&c)[4], float a, const float (&b)[4]) {
     asm volatile(GZ2_NOP
@@ -2557,6 +2563,9 @@ __device__ __forceinline__ void lgkm_done(float (&a)[4], float (&b)[4]) {
 __device__ __forceinline__ void lgkm_done(float (&a)[4], float (&b)[2]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]));
 }
+__device__ __forceinline__ void lgkm_done(float (&a)[4], float (&b)[1]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]));
+}
 
 template <class AL, class = void>
 struct a_extra_of { static constexpr int value = 0; };
@@ -2576,7 +2585,7 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
                                                               typename Epi::Params pe, GridMap gm) {
     constexpr int LDA = AL::LD, LDB = BL::LD;
     constexpr int TM = Cfg::TM, TN = Cfg::TN;
-    static_assert(TM == 4 && (TN == 2 || TN == 4), "fragment registers of the hand-ordered k-step");
+    static_assert(TM == 4 && (TN == 1 || TN == 2 || TN == 4), "fragment registers of the hand-ordered k-step");
     constexpr bool RS = is_rowshare<AL>::value;
     constexpr bool FR = is_fwdrows<AL>::value;
     constexpr int A_EXTRA = igemm2_a_extra<AL>();
@@ -2710,7 +2719,7 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
         }
         {
         bf[0] = lds_rd<BO>(b_addr + so);
-        bf[1] = lds_rd<BO + 128>(b_addr + so);
+        if constexpr (TN >= 2) bf[1] = lds_rd<BO + 128>(b_addr + so);
         if constexpr (TN == 4) {
             bf[2] = lds_rd<BO + 256>(b_addr + so);
             bf[3] = lds_rd<BO + 384>(b_addr + so);
@@ -2901,7 +2910,7 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2r_kernel(typename AL::Para
         af[2] = lds_rd<AO + 256>(a_addr + so);
         af[3] = lds_rd<AO + 384>(a_addr + so);
         bf[0] = lds_rd<BO>(b_addr + so);
-        bf[1] = lds_rd<BO + 128>(b_addr + so);
+        if constexpr (TN >= 2) bf[1] = lds_rd<BO + 128>(b_addr + so);
         if constexpr (TN == 4) {
             bf[2] = lds_rd<BO + 256>(b_addr + so);
             bf[3] = lds_rd<BO + 384>(b_addr + so);

@@ -879,7 +879,9 @@ IGEMM2_DG_CASES = [
     (512, 72, 4, 512, "256x128"),        # 4x4 feature maps: 64 image rows per tile; 18 chunks
     (52, 64, 16, 384, "256x128"),        # ragged pixel tail (13312 = 52 * 256) and 3 N tiles
     (67, 68, 16, 160, "256x128"),
-    (64, 256, 8, 256, "256x128"),        # 128 tiles: the reduction (64 chunks) is split in two, slabs + finish kernel
+    (64, 256, 8, 256, "256x64"),         # round 4: 128 tiles of 256x128 -> 256 tiles of 256x64, unsplit
+    (32, 256, 8, 256, "256x64"),         # ... and with half the batch: 128 tiles of 256x64, the reduction split in two
+    (64, 256, 8, 160, "256x128"),        # 160 channels (not a multiple of 64): 256x128, reduction split in two
     (8, 64, 64, 128, "256x128"),         # 64-pixel feature rows: four image rows per tile
     (64, 64, 32, 64, "512x64"),          # D.block1-size: 64 output channels, 512-pixel tiles (two 256-pixel pieces per row)
     (272, 68, 16, 48, "512x64"),         # 48 channels: the general epilogue; 17 chunks        # pixel tail inside a tile (67 * 256 = 17152 = 67 tiles), channel tail 160 = 128 + 32
@@ -919,13 +921,22 @@ def test_igemm2_transposed_conv_matches_torch(case):
 
 IGEMM2_F_CASES = [
     # N, C (input channels), H (input side), K (output channels), expected label
-    (64, 64, 64, 128, "256x128"),        # OW = 32: 8 output rows per tile, 256 tiles
-    (128, 64, 32, 128, "256x128"),       # D.block1-like: OW = 16
-    (512, 72, 16, 256, "256x128"),       # OW = 8, 72 chunks
-    (512, 64, 8, 512, "256x128"),        # OW = 4 (64 output rows per tile)
+    # round 4: launches whose 256x128 tiles would not give every CU a workgroup take 256x64 tiles (three per CU) ...
+    (32, 64, 64, 128, "256x64"),         # OW = 32: 8 output rows per tile
+    (128, 64, 32, 128, "256x64"),        # D.block1-like: OW = 16
+    (256, 72, 16, 256, "256x64"),        # OW = 8, 72 chunks
+    (512, 64, 8, 512, "256x64"),         # OW = 4 (64 output rows per tile)
+    (50, 68, 32, 384, "256x64"),         # ragged pixel tail (12800 = 50 tiles), 6 column tiles
+    (512, 256, 8, 512, "256x64"),        # 32 row tiles x 8 column tiles = 256 tiles, unsplit
+    (128, 256, 8, 512, "256x64"),        # 64 tiles of 256x64: reduction split in four (slabs + finish kernel)
+    # ... and the same geometries with >= 256 tiles of 256x128 keep those
+    (64, 64, 64, 128, "256x128"),        # OW = 32, 256 tiles
+    (512, 64, 32, 128, "256x128"),       # OW = 16
+    (512, 72, 16, 256, "256x128"),       # OW = 8
+    (2048, 64, 8, 512, "256x128"),       # OW = 4
     (100, 68, 32, 384, "256x128"),       # ragged pixel tail (25600 = 100 tiles), 3 column tiles
-    (512, 256, 8, 512, "256x128"),       # 32 row tiles x 4 column tiles = 128 tiles: reduction split in two
     (32, 64, 128, 128, "256x128"),       # OW = 64: four output rows per tile
+    (128, 256, 8, 416, "256x128"),       # 416 channels (not a multiple of 64): 32 tiles, reduction split in eight
 ]
 
 
