@@ -551,6 +551,16 @@ static SplitPlan fwdtap2_plan(const ConvShape& s) {
         while (splits > 1 && chunks / splits < 64) --splits;
         if (splits > 1 && tiles * splits >= cu * 3 / 4) return SplitPlan{T256x128, splits};
     }
+    // round 4: 256x64 tiles for the launches too small for the rule above (HoloGAN's 5x5 s2 p2 critic blocks at 64x64,
+    // 6.7 GFLOP each, bs 64: 76 / 77 / 65 -> 92 / 92 / 76 TFLOP/s; 16, 32 or 48 chunks per piece measure the same)
+    const int mc = knobs().tap64_min_chunks;
+    if (mc > 0 && !knobs().no_tile64 && (s.K & 63) == 0 && chunks >= mc) {
+        const long long t64 = ((M + 255) / 256) * ((s.K + 63) / 64);
+        if (t64 >= cu * 7 / 8) return SplitPlan{T256x64, 1};
+        int splits = (int)((cu + t64 - 1) / t64);
+        while (splits > 1 && chunks / splits < mc) --splits;
+        if (t64 >= 8 && t64 * splits >= cu * 3 / 4) return SplitPlan{T256x64, splits};
+    }
     return SplitPlan{T64x64, 1};
 }
 
@@ -604,7 +614,9 @@ static int dispatch_fwd(const float* x, const float* wp, const float* bias, floa
     }
     switch (sp.tile) {
         case T256x256: return run_fwd2_ow<Cfg256x256>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
-        case T256x64: return run_fwd2_ow<Cfg256x64>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
+        case T256x64:
+            if (!fwd2_ok<G>(s)) return run_fwdtap2<G, Cfg256x64>(x, wp, bias, y, s, act, slope, st, sp.splits, slab, nullptr);
+            return run_fwd2_ow<Cfg256x64>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
         case T256x128:
             if (!fwd2_ok<G>(s)) return run_fwdtap2<G, Cfg256x128>(x, wp, bias, y, s, act, slope, st, sp.splits, slab, nullptr);
             return run_fwd2_ow<Cfg256x128>(x, wp, bias, y, s, act, slope, st, sp.splits, slab);
@@ -1005,8 +1017,12 @@ static SplitPlan dgradtap2_plan(const ConvShape& s) {
     constexpr bool one_by_one = G::kh * G::kw == 1;
     if constexpr (G::s * G::s > 8 || (!one_by_one && G::kh % G::s == 0 && G::kw % G::s == 0 && BK % (TY * TX) == 0))
         return SplitPlan{T64x64, 1};        // (k4 s2 p1 has its own loaders)
-    if (off || !(one_by_one ? s.K >= BK : dgrad_tap_major(s.K, G::kh, G::kw, G::s)) || s.C < 128 || (s.C & 3) ||
-        s.H % G::s || s.W % G::s)
+    // round 4: 256x64 tiles for the launches too small for 256x128; they also admit 64 image-side channels (tools/
+    // tap_bench.py 64, TFLOP/s: HoloGAN 64x64 D.block2 / D.block3 input gradients 60 / 52 -> 77 / 67; EXT-128's
+    // D.block1, 64 channels, 102 -> 123; with 48 instead of 32 chunks per piece 57 / 53 -- worse than the old kernel)
+    const int mc64 = (!knobs().no_tile64 && G::s != 1 && (s.C & 63) == 0) ? knobs().tap64_min_chunks : 0;
+    if (off || !(one_by_one ? s.K >= BK : dgrad_tap_major(s.K, G::kh, G::kw, G::s)) || s.C < (mc64 > 0 ? 64 : 128) ||
+        (s.C & 3) || s.H % G::s || s.W % G::s)
         return SplitPlan{T64x64, 1};
     const long long M = (long long)s.N * (s.H / G::s) * (s.W / G::s);
     const long long tiles = ((M + 255) / 256) * ((s.C + 127) / 128);
@@ -1023,7 +1039,22 @@ static SplitPlan dgradtap2_plan(const ConvShape& s) {
         while (splits > 1 && maxchunks / splits < 64) --splits;
         return (splits > 1 && tiles * splits >= cus() * 3 / 4) ? SplitPlan{T256x128, splits} : SplitPlan{T64x64, 1};
     }
-    if (tiles * total < 2LL * cus() * 32) return SplitPlan{T64x64, 1};       // too little work for the big tile
+    if (tiles * total < 2LL * cus() * 32 || s.C < 128) {       // too little work for the big tile
+        if (mc64 > 0) {
+            const long long t64 = ((M + 255) / 256) * (s.C / 64);
+            // (64 channels = one column of tiles: only with enough of them -- the 64x64-image D.block1 has 64 tiles and
+            // loses, 84 -> 76, on this skeleton)
+            if (t64 * total >= 1LL * cus() * mc64 && (s.C >= 128 || t64 >= cus() * 3 / 4)) {
+                const int wgs64 = knobs().tap_wgs * cus() / 256;
+                long long cps = (t64 * total + wgs64 - 1) / wgs64;
+                if (cps < mc64) cps = mc64;
+                if (cps > knobs().tap_cps_max) cps = knobs().tap_cps_max;
+                const int splits = (int)((maxchunks + cps - 1) / cps);
+                return SplitPlan{T256x64, splits < 1 ? 1 : splits};
+            }
+        }
+        return SplitPlan{T64x64, 1};
+    }
     // ~384 workgroups of <= 96 chunks (measured on HoloGAN EXT-128's blocks, TFLOP/s of D.block2 / D.block3:
     // 256 workgroups 84 / 67, 384: 99 / 99, 512: 99 / 89, 768: 90 / 86; the round-2 kernels: 89 / 74)
     const int wgs = knobs().tap_wgs * cus() / 256, cps_max = knobs().tap_cps_max;
@@ -1071,7 +1102,7 @@ static SplitPlan dgrad_plan(const ConvShape& s) {
     }
     {
         const SplitPlan pt = dgradtap2_plan<G>(s);
-        if (pt.tile == T256x128) return pt;
+        if (pt.tile == T256x128 || pt.tile == T256x64) return pt;
     }
     return plan_split(M, s.C, kk * TAPS, G::s * G::s, pick_tile(M, s.C, G::s * G::s, kk * TAPS));
 }
@@ -1118,7 +1149,9 @@ static int dispatch_dgrad(const float* y, const float* wp, const float* bias, fl
             if (!dgrad2_ok<G>(s)) return run_dgradtap2<G, Cfg256x128>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
             return run_dgrad2<Cfg256x128>(y, wp, bias, x, s, act, slope, st, nullptr, sp.splits, slab);
         case T512x64: return run_dgrad2<Cfg512x64>(y, wp, bias, x, s, act, slope, st);
-        case T256x64: return run_dgrad2<Cfg256x64>(y, wp, bias, x, s, act, slope, st, nullptr, sp.splits, slab);
+        case T256x64:
+            if (!dgrad2_ok<G>(s)) return run_dgradtap2<G, Cfg256x64>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
+            return run_dgrad2<Cfg256x64>(y, wp, bias, x, s, act, slope, st, nullptr, sp.splits, slab);
         case T128x128: return run_dgrad<G, Cfg128x128>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
         case T128x64: return run_dgrad<G, Cfg128x64>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
         case T128x32: return run_dgrad<G, Cfg128x32>(y, wp, bias, x, s, act, slope, st, sp.splits, slab);
@@ -1991,7 +2024,9 @@ int gz_conv2d_fwd_stats_ws(const float* x, const float* wpack, float* y, float* 
         float* slab = sp.splits > 1 ? workspace : nullptr;                                                           \
         switch (sp.tile) {                                                                                           \
             case T256x256: return run_fwd2_ow<Cfg256x256>(x, wpack, nullptr, y, s, 0, 0.f, stream, sp.splits, slab, stats); \
-            case T256x64: return run_fwd2_ow<Cfg256x64>(x, wpack, nullptr, y, s, 0, 0.f, stream, sp.splits, slab, stats); \
+            case T256x64:                                                                                            \
+                if (!fwd2_ok<G>(s)) return run_fwdtap2<G, Cfg256x64>(x, wpack, nullptr, y, s, 0, 0.f, stream, sp.splits, slab, stats); \
+                return run_fwd2_ow<Cfg256x64>(x, wpack, nullptr, y, s, 0, 0.f, stream, sp.splits, slab, stats);      \
             case T256x128:                                                                                           \
                 if (!fwd2_ok<G>(s)) return run_fwdtap2<G, Cfg256x128>(x, wpack, nullptr, y, s, 0, 0.f, stream, sp.splits, slab, stats); \
                 return run_fwd2_ow<Cfg256x128>(x, wpack, nullptr, y, s, 0, 0.f, stream, sp.splits, slab, stats);     \
@@ -2128,7 +2163,7 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
         if ((KH == 5 && KW == 5 && S == 2) || (KH == 3 && KW == 3 && S == 1) || (KH == 1 && KW == 1 && S == 1)) {
             ConvShape s{N, C, H, W, K, OH, OW};
             const SplitPlan p2 = KH == 5 ? fwdtap2_plan<G5522>(s) : KH == 3 ? fwdtap2_plan<G3311>(s) : fwdtap2_plan<G1110>(s);
-            if (p2.tile == T256x128) return p2.tile;
+            if (p2.tile == T256x128 || p2.tile == T256x64) return p2.tile;
         }
         return pick_tile_fwd((long long)N * OH * OW, K, OW, KH, KW, S, C * KH * KW);
     }
@@ -2143,7 +2178,7 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
         if ((KH == 5 && KW == 5 && S == 2) || (KH == 3 && KW == 3 && S == 1) || (KH == 1 && KW == 1 && S == 1)) {
             ConvShape s{N, C, H, W, K, OH, OW};
             const SplitPlan pt = KH == 5 ? dgradtap2_plan<G5522>(s) : KH == 3 ? dgradtap2_plan<G3311>(s) : dgradtap2_plan<G1110>(s);
-            if (pt.tile == T256x128) return T256x128;
+            if (pt.tile == T256x128 || pt.tile == T256x64) return pt.tile;
         }
         return pick_tile((long long)N * (H / S) * (W / S), C, S * S, K * ((KH + S - 1) / S) * ((KW + S - 1) / S));
     }
