@@ -50,8 +50,14 @@ def test_train_mode_batchnorm_at_bs512(shape, act):
     assert int(nbt) == int(bn.num_batches_tracked) == 1
 
 
-@pytest.mark.parametrize("expt,bs,idx", [("dc_gan", 512, 0), ("dc_gan", 512, 1), ("wgan_gp", 256, 0), ("wgan_gp", 256, 1)])
-def test_baseline_size_step_matches_cpu_oracle(expt, bs, idx):
+@pytest.mark.parametrize("expt,bs,idx,sinks", [("dc_gan", 512, 0, False), ("dc_gan", 512, 1, False),
+                                               ("wgan_gp", 256, 0, False), ("wgan_gp", 256, 1, False),
+                                               # round 4: the metric string's own batch, and the Trainer's gradient
+                                               # path (weight-gradient slabs summed into p.grad by gz_reduce_multi,
+                                               # norm affine gradients written in place)
+                                               ("dc_gan", 128, 0, True), ("dc_gan", 128, 1, True),
+                                               ("dc_gan", 512, 0, True), ("wgan_gp", 256, 0, True)])
+def test_baseline_size_step_matches_cpu_oracle(expt, bs, idx, sinks):
     """BASELINE configs 2 and 3 at their own sizes (features 64; dc_gan bs 512, wgan_gp bs 256), one whole
     ``training_step`` + backward per case against the CPU oracle on the same inputs, norm layers in TRAIN mode:
 
@@ -79,8 +85,18 @@ def test_baseline_size_step_matches_cpu_oracle(expt, bs, idx):
         if expt == "wgan_gp":
             step.gp_alpha = alpha
         real = (synthetic_real(bs, seed=4243).abs() * 0.9 + 0.1).to(dev)
-        loss = step.training_step((real, torch.zeros(bs, dtype=torch.int64, device=dev)), 0, idx)
-        loss.backward()
+        use_sinks = sinks and root is None
+        if use_sinks:
+            from lightning_gan_zoo_amd import functional as F
+            prev = F.set_grad_sinks(True)
+        try:
+            loss = step.training_step((real, torch.zeros(bs, dtype=torch.int64, device=dev)), 0, idx)
+            loss.backward()
+            if use_sinks:
+                F.flush_grad_sinks()
+        finally:
+            if use_sinks:
+                F.set_grad_sinks(*prev)
         net = step.discriminator if idx == 0 else step.generator
         extra = {}
         if expt == "wgan_gp" and idx == 0:      # the penalty on its own (the loss is lambda * gp - a difference of means)
