@@ -58,6 +58,15 @@ size_t gz_conv2d_pack_job_bytes(void);
 int gz_conv2d_pack_job(void* job_out, const float* w, float* wp, int is_dgrad, int K, int C, int KH, int KW, int S, int P,
                        int block0);
 int gz_conv2d_pack_multi(const void* jobs_dev, int njobs, int total_blocks, hipStream_t stream);
+/* Packed images with the job table passed by value and an optional scale 1 / sigma[0] (sigma on the device, may be
+ * NULL): spectral normalisation's w = weight_orig / sigma is a new tensor at every call; one launch writes w (what = 2:
+ * plain scaled copy) and the forward (what = 0) and dgrad (what = 1) images of every such layer.  table_host:
+ * gz_conv2d_pack_table_bytes() zeroed host bytes, at most gz_conv2d_pack_table_max_jobs() jobs. */
+int gz_conv2d_pack_table_max_jobs(void);
+size_t gz_conv2d_pack_table_bytes(void);
+int gz_conv2d_pack_table_add(void* table_host, const float* w, float* wp, const float* sigma, int what, int K, int C, int KH,
+                             int KW, int S, int P);
+int gz_conv2d_pack_table_launch(void* table_host, hipStream_t stream);
 
 /* y = act(conv2d(x, w) + bias).  Replaces aten::convolution for nn.Conv2d forward
  * (standard_networks.py:20-24,36-43) and the input gradient of nn.ConvTranspose2d. */
@@ -237,6 +246,17 @@ int gz_vec_normalize(const float* x, float* out, float* out2, float* norm_out, i
 int gz_vec_normalize_dot(const float* x, float* out, float* out2, float* dot_out, int n, float eps,
                          hipStream_t stream);
 int gz_vec_dot(const float* a, const float* b, float* out, int n, hipStream_t stream);
+/* The power iteration of SEVERAL spectral-normalised weights in four launches (every spectral-norm layer of one
+ * discriminator call, core/models/hologan_discriminator.py:15,32): per job v <- normalise(W^T u), u <- normalise(W v),
+ * sigma = u^T W v; u, v are the module's buffers (updated in place), us / vs / sigma the copies the autograd node keeps.
+ * table_host: gz_sn_table_bytes() zeroed host bytes filled by gz_sn_add (at most gz_sn_max_jobs()); workspace:
+ * gz_sn_workspace_floats(R, L) floats per job.  L % 4 == 0; W, v, vs, workspace 16-byte aligned. */
+int gz_sn_max_jobs(void);
+size_t gz_sn_table_bytes(void);
+long long gz_sn_workspace_floats(int R, int L);
+int gz_sn_add(void* table_host, const float* W, float* u, float* v, float* us, float* vs, float* sigma, float* workspace,
+              int R, int L);
+int gz_sn_power_iteration(void* table_host, float eps, hipStream_t stream);
 int gz_div_scalar(const float* x, const float* sigma, float* out, long long count, hipStream_t stream);
 int gz_spectral_norm_bwd(const float* g, const float* rowdots, const float* u, const float* v, const float* sigma,
                          float* out, int R, int L, hipStream_t stream);
@@ -335,6 +355,19 @@ int gz_rowdot(const float* a, const float* b, float* y, int R, int L, int b_broa
 /* out[r][:] = s[r] * x[r][:] (+ t[r] * x2[r][:], t = 1 - s when one_minus_s else s2); x_broadcast: x is [L] */
 int gz_rowscale(const float* x, const float* s, const float* x2, const float* s2, float* out, int R, int L,
                 int x_broadcast, int one_minus_s, hipStream_t stream);
+/* ---- several small Linear layers over ONE input in one launch ------------------------------------------------
+ * HoloGAN's five ZMapping layers, Linear(z_dim -> 2C) + ReLU each on the same z (core/models/hologan_generator.py:7-19,
+ * called at :33/:57/:141).  table_host: gz_linear_multi_table_bytes() zeroed bytes of host memory filled through
+ * gz_linear_multi_add (at most gz_linear_multi_max_jobs() layers; copied into the kernel argument).
+ *   fwd: out_j[N][J_j] = act(x[N][K] . weight_j[J_j][K]^T + bias_j)          (g, dw, db unused: pass NULL)
+ *   bwd: dw_j = (g_j * act'(out_j))^T . x,  db_j = its column sums (db NULL: skipped); weight/bias unused.
+ * Any N, K, J (scalar loads); rows are summed in a fixed order. */
+int gz_linear_multi_max_jobs(void);
+size_t gz_linear_multi_table_bytes(void);
+int gz_linear_multi_add(void* table_host, const float* weight, const float* bias, float* out, const float* g, float* dw,
+                        float* db, int J);
+int gz_linear_multi_fwd(void* table_host, const float* x, int N, int K, int act, float slope, hipStream_t stream);
+int gz_linear_multi_bwd(void* table_host, const float* x, int N, int K, int act, float slope, hipStream_t stream);
 /* out[l] = sum_r x[r][l]  (nn.Linear's bias gradient: core/models/hologan_discriminator.py:41-50, hologan_generator.py:11) */
 int gz_colsum(const float* x, float* out, int R, int L, hipStream_t stream);
 /* out[l] = sum_r g[r] * x[r][l] */

@@ -33,9 +33,12 @@ class BasicBlock(nn.Module):
         self.instance_norm = nn.InstanceNorm2d(out_planes)
         self.lrelu = nn.LeakyReLU(0.2)
 
-    def forward(self, x):
+    def forward(self, x, w=None):
+        """w: this call's spectral-normalised weight when the caller already has it (Discriminator.forward runs the
+        power iteration of all three blocks in one set of launches)."""
         c = self.conv2d
-        w = F.spectral_normalize(c.weight_orig, c.weight_u, c.weight_v, self.training)
+        if w is None:
+            w = F.spectral_normalize(c.weight_orig, c.weight_u, c.weight_v, self.training)
         y = F.conv2d(x, w, c.bias, K5S2P2)
         return F.instance_norm_act(y, None, None, self.instance_norm.eps, F.ACT_LRELU, self.lrelu.negative_slope)
 
@@ -75,8 +78,12 @@ class Discriminator(nn.Module):
         batch_size = x.size(0)
         slope = self.lrelu.negative_slope
         h = F.conv2d(x, self.conv2d.weight, self.conv2d.bias, K5S2P2, F.ACT_LRELU, slope)
-        for blk in self.blocks:
-            h = blk(h)
+        # torch.nn.utils.spectral_norm's pre-forward hook of each block (reference :15,32) depends only on the block's
+        # own weight and buffers: the three power iterations share their launches
+        convs = [blk.conv2d for blk in self.blocks]
+        ws = F.spectral_normalize_multi([(c.weight_orig, c.weight_u, c.weight_v) for c in convs], self.training, K5S2P2)
+        for blk, w in zip(self.blocks, ws):
+            h = blk(h, w)
         h = h.reshape(batch_size, -1)
         logit = F.linear_act(h, self.linear1.weight, self.linear1.bias)
         enc = F.linear_act(h, self.linear2.weight, self.linear2.bias, F.ACT_LRELU, slope)

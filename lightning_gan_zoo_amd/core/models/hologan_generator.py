@@ -52,13 +52,15 @@ class BasicBlock(nn.Module):
         self.relu = nn.ReLU()
         self.transpose_dim = transpose_dim
 
-    def forward(self, h, z):
+    def forward(self, h, z, style=None):
+        """style: this block's zMapping(z) when the caller already has it (Generator.forward maps z through all five
+        ZMapping layers in one launch)."""
         ct = self.convTranspose
         if self.transpose_dim == 2:
             h = F.conv_transpose2d(h, ct.weight, ct.bias, F.K4S2P1)
         else:
             h = F.conv_transpose3d(h, ct.weight, ct.bias)
-        return F.adain_act_packed(h, self.zMapping(z), 1e-8, F.ACT_RELU)
+        return F.adain_act_packed(h, self.zMapping(z) if style is None else style, 1e-8, F.ACT_RELU)
 
 
 def _mat(rows):
@@ -149,14 +151,17 @@ class Generator(nn.Module):
                 view_in = self.sample_view(n)
             minv = draw_on_host(lambda: view_inverse_matrices(view_in).reshape(n, 16).contiguous(), dev)
 
-        h = F.adain_const_act(self.x, self.zMapping(z), 1e-8, F.ACT_RELU)     # = AdaIN(self.x.repeat(n, ...)), reference :141
-        h = self.block1(h, z)
-        h = self.block2(h, z)
+        # the five ZMapping layers (reference :33, :57, :141) read the same z: one launch, [N, 2C] each
+        maps = (self.zMapping, self.block1.zMapping, self.block2.zMapping, self.block3.zMapping, self.block4.zMapping)
+        s0, s1, s2, s3, s4 = F.linear_act_multi(z, [(m.linear1.weight, m.linear1.bias) for m in maps], F.ACT_RELU)
+        h = F.adain_const_act(self.x, s0, 1e-8, F.ACT_RELU)     # = AdaIN(self.x.repeat(n, ...)), reference :141
+        h = self.block1(h, z, s1)
+        h = self.block2(h, z, s2)
         h = F.rigid_resample(h, minv)                                 # [N, 16*C, 16, 16]
         p = self.convTranspose2d1
         h = F.conv_transpose2d(h, p.weight, p.bias, K1S1P0, F.ACT_RELU)
-        h = self.block3(h, z)
-        h = self.block4(h, z)
+        h = self.block3(h, z, s3)
+        h = self.block4(h, z, s4)
         f = self.final_layer
         if isinstance(f, nn.ConvTranspose2d):                          # EXT-128
             return F.conv_transpose2d(h, f.weight, f.bias, F.K4S2P1, F.ACT_TANH)

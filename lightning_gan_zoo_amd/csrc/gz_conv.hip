@@ -160,14 +160,14 @@ __host__ __device__ constexpr int round4(int v) { return (v + 3) & ~3; }
 // pack_multi_kernel, which re-packs every weight of a network in one launch (a job table maps a block to its tensor).
 // dst[c][ld] (c < COLS) = src[r][c] transposed: dst[c*ld + r] = src[r*COLS + c]; zero for r in [R, ld)
 __device__ __forceinline__ void transpose_pad_body(const float* __restrict__ src, float* __restrict__ dst, int R,
-                                                   int COLS, int ld, int bx, int by) {
+                                                   int COLS, int ld, int bx, int by, float scale = 1.f) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const int c0 = bx * 32, r0 = by * 32;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int r = r0 + ty + 8 * i, c = c0 + tx;
-        tile[ty + 8 * i][tx] = (r < R && c < COLS) ? src[(long long)r * COLS + c] : 0.f;
+        tile[ty + 8 * i][tx] = (r < R && c < COLS) ? src[(long long)r * COLS + c] * scale : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -197,13 +197,13 @@ static bool dgrad_tap_major(int K, int KH, int KW, int S) {
 
 // wp[(tap, c)][ld] = w[ko][c][tap], c padded to a multiple of BK with zero rows
 __device__ __forceinline__ void pack_fwd_tap_body(const float* __restrict__ w, float* __restrict__ wp, int K, int C,
-                                                  int taps, int cpad, int ld, int bx, int gx) {
+                                                  int taps, int cpad, int ld, int bx, int gx, float scale = 1.f) {
     const long long total = (long long)taps * cpad * ld;
     for (long long i = (long long)bx * 256 + threadIdx.x; i < total; i += (long long)gx * 256) {
         int ko = (int)(i % ld);
         long long row = i / ld;
         int c = (int)(row % cpad), tap = (int)(row / cpad);
-        wp[i] = (ko < K && c < C) ? w[((long long)ko * C + c) * taps + tap] : 0.f;
+        wp[i] = (ko < K && c < C) ? w[((long long)ko * C + c) * taps + tap] * scale : 0.f;
     }
 }
 
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void pack_fwd_tap_kernel(const float* __restri
 // to a multiple of BK; the unused tail of the phase's fixed-size TY*TX*kpad-row region is never read
 __device__ __forceinline__ void pack_dgrad_tap_body(const float* __restrict__ w, float* __restrict__ wp, int K, int C,
                                                     int KH, int KW, int S, int P, int TY, int TX, int kpad, int ldc,
-                                                    int bx, int phase, int gx) {
+                                                    int bx, int phase, int gx, float scale = 1.f) {
     const int py = phase / S, px = phase % S;
     const int ry = (py + P) % S, rx = (px + P) % S;
     const int ny = dg_taps(KH, S, P, py), nx = dg_taps(KW, S, P, px);
@@ -227,7 +227,7 @@ __device__ __forceinline__ void pack_dgrad_tap_body(const float* __restrict__ w,
         long long row = i / ldc;
         int ko = (int)(row % kpad), tap = (int)(row / kpad);
         int ky = ry + S * (tap / nx), kx = rx + S * (tap % nx);
-        dst[i] = (ko < K && c < C) ? w[(((long long)ko * C + c) * KH + ky) * KW + kx] : 0.f;
+        dst[i] = (ko < K && c < C) ? w[(((long long)ko * C + c) * KH + ky) * KW + kx] * scale : 0.f;
     }
 }
 
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void pack_dgrad_tap_kernel(const float* __rest
 // phase's fixed-size K*TY*TX-row region is zero.  (k5 s2: 9/6/6/4 taps instead of 4 x 9.)
 __device__ __forceinline__ void pack_dgrad_body(const float* __restrict__ w, float* __restrict__ wp, int K, int C,
                                                 int KH, int KW, int S, int P, int TY, int TX, int ldc, int ko,
-                                                int phase) {
+                                                int phase, float scale = 1.f) {
     const int py = phase / S, px = phase % S;
     const int ry = (py + P) % S, rx = (px + P) % S;
     const int ny = dg_taps(KH, S, P, py), nx = dg_taps(KW, S, P, px);
@@ -251,7 +251,8 @@ __device__ __forceinline__ void pack_dgrad_body(const float* __restrict__ w, flo
     for (int i = threadIdx.x; i < taps * ldc; i += 256) {
         int tap = i / ldc, c = i - tap * ldc;
         int ky = ry + S * (tap / nx), kx = rx + S * (tap % nx);
-        dst[((long long)ko * taps + tap) * ldc + c] = c < C ? w[(((long long)ko * C + c) * KH + ky) * KW + kx] : 0.f;
+        dst[((long long)ko * taps + tap) * ldc + c] =
+            c < C ? w[(((long long)ko * C + c) * KH + ky) * KW + kx] * scale : 0.f;
     }
     for (int i = threadIdx.x; i < pad * ldc; i += 256)
         dst[((long long)K * taps + (long long)ko * pad) * ldc + i] = 0.f;
@@ -287,6 +288,46 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
         default:
             pack_dgrad_tap_body(jb.w, jb.wp, jb.K, jb.C, jb.KH, jb.KW, jb.S, jb.P, TY, TX, round_bk(jb.K), round4(jb.C), bx,
                                 by, jb.gx);
+    }
+}
+
+// The same bodies with the job table passed BY VALUE and an optional scale 1 / sigma[0] read from the device:
+// spectral normalisation's w = weight_orig / sigma is a fresh tensor at every discriminator call, so its images cannot
+// live in the persistent table above; one launch writes w itself (kind 4) and both packed images of every
+// spectral-normalised layer (functional.spectral_normalize_multi) -- they were a div_scalar and two pack launches per
+// layer and call.
+constexpr int PACK_TABLE_MAX = 12;
+struct PackTable {
+    int njobs, pad;
+    PackJob jobs[PACK_TABLE_MAX];
+    const float* sigma[PACK_TABLE_MAX];
+};
+
+__global__ __launch_bounds__(256) void pack_table_kernel(PackTable t) {
+    const int b = blockIdx.x;
+    int j = 0;
+    while (j + 1 < t.njobs && t.jobs[j + 1].block0 <= b) ++j;
+    const PackJob& jb = t.jobs[j];
+    const float scale = t.sigma[j] ? 1.f / t.sigma[j][0] : 1.f;
+    const int l = b - jb.block0, bx = l % jb.gx, by = l / jb.gx;
+    const int TY = (jb.KH + jb.S - 1) / jb.S, TX = (jb.KW + jb.S - 1) / jb.S;
+    switch (jb.kind) {
+        case 0: transpose_pad_body(jb.w, jb.wp, jb.K, jb.C * jb.KH * jb.KW, round4(jb.K), bx, by, scale); break;
+        case 1:
+            pack_fwd_tap_body(jb.w, jb.wp, jb.K, jb.C, jb.KH * jb.KW, round_bk(jb.C), round4(jb.K), bx, jb.gx, scale);
+            break;
+        case 2:
+            pack_dgrad_body(jb.w, jb.wp, jb.K, jb.C, jb.KH, jb.KW, jb.S, jb.P, TY, TX, round4(jb.C), bx, by, scale);
+            break;
+        case 3:
+            pack_dgrad_tap_body(jb.w, jb.wp, jb.K, jb.C, jb.KH, jb.KW, jb.S, jb.P, TY, TX, round_bk(jb.K), round4(jb.C), bx,
+                                by, jb.gx, scale);
+            break;
+        default: {      // 4: wp = w * scale, same layout
+            const long long total = (long long)jb.K * jb.C * jb.KH * jb.KW;
+            for (long long i = (long long)bx * 256 + threadIdx.x; i < total; i += (long long)jb.gx * 256)
+                jb.wp[i] = jb.w[i] * scale;
+        }
     }
 }
 
@@ -1826,6 +1867,44 @@ int gz_conv2d_pack_multi(const void* jobs_dev, int njobs, int total_blocks, hipS
     if (!jobs_dev || njobs <= 0 || total_blocks <= 0) return GZ_ERR_BAD_SHAPE;
     hipLaunchKernelGGL(pack_multi_kernel, dim3(total_blocks), dim3(256), 0, stream,
                        reinterpret_cast<const PackJob*>(jobs_dev), njobs);
+    return launch_status();
+}
+
+int gz_conv2d_pack_table_max_jobs(void) { return PACK_TABLE_MAX; }
+size_t gz_conv2d_pack_table_bytes(void) { return sizeof(PackTable); }
+
+/* what: 0 the forward image, 1 the dgrad image, 2 a plain copy (w * scale in w's own layout) */
+int gz_conv2d_pack_table_add(void* table_host, const float* w, float* wp, const float* sigma, int what, int K, int C, int KH,
+                             int KW, int S, int P) {
+    PackTable* t = reinterpret_cast<PackTable*>(table_host);
+    if (!t || !w || !wp || what < 0 || what > 2) return GZ_ERR_BAD_SHAPE;
+    if (t->njobs < 0 || t->njobs >= PACK_TABLE_MAX) return GZ_ERR_UNSUPPORTED;
+    PackJob jb;
+    if (what == 2) {
+        if (K <= 0 || C <= 0 || KH <= 0 || KW <= 0) return GZ_ERR_BAD_SHAPE;
+        const long long total = (long long)K * C * KH * KW;
+        jb = PackJob{w, wp, 4, K, C, KH, KW, 1, 0, (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256), 1, 0};
+    } else {
+        const int n = gz_conv2d_pack_job(&jb, w, wp, what, K, C, KH, KW, S, P, 0);
+        if (n < 0) return n;
+    }
+    t->jobs[t->njobs] = jb;
+    t->sigma[t->njobs] = sigma;
+    ++t->njobs;
+    return GZ_OK;
+}
+
+int gz_conv2d_pack_table_launch(void* table_host, hipStream_t stream) {
+    gz::clear_stale_error();
+    PackTable* t = reinterpret_cast<PackTable*>(table_host);
+    if (!t || t->njobs <= 0 || t->njobs > PACK_TABLE_MAX) return GZ_ERR_BAD_SHAPE;
+    long long blocks = 0;
+    for (int j = 0; j < t->njobs; ++j) {
+        t->jobs[j].block0 = (int)blocks;
+        blocks += (long long)t->jobs[j].gx * t->jobs[j].gy;
+    }
+    if (blocks <= 0 || blocks >= (1ll << 31)) return GZ_ERR_TOO_LARGE;
+    hipLaunchKernelGGL(pack_table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, *t);
     return launch_status();
 }
 

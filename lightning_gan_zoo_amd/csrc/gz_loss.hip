@@ -173,6 +173,146 @@ __global__ __launch_bounds__(LT) void sn_bwd_kernel(const float* __restrict__ G,
     }
 }
 
+// ---- spectral normalisation's power iteration for several weights, four launches -----------------------------
+// One iteration is v = normalise(W^T u), u = normalise(W v), sigma = u^T W v (torch.nn.utils.spectral_norm, used by
+// core/models/hologan_discriminator.py:15,32 on three convolutions).  As separate launches that was coldot, slab sum,
+// normalise, rowdot, normalise+dot PER LAYER and discriminator call -- launch-bound ~6 us kernels, 15 per call.  Here
+// every layer of the call is a job of the same four launches.  (Folding the single-workgroup tails into the last
+// workgroup to arrive at a ticket was built and measured first: the agent-scope release / acquire fences that make
+// other XCDs' partial results visible write back and invalidate the whole L2 per workgroup -- 86 + 71 us for the two
+// launches against 100 us for the fifteen they replaced.  Kernel boundaries are the cheaper barrier.)
+constexpr int SN_MAX_JOBS = 4;
+constexpr int SN_SLICES = 32;
+struct SnJob {
+    const float* W;        // [R][L] weight_orig
+    float* u;              // [R] module buffer, updated in place
+    float* v;              // [L] module buffer, updated in place
+    float* us;             // [R] the autograd node's copy
+    float* vs;             // [L]
+    float* sigma;          // [1]
+    float* slabs;          // [slices][L] workspace
+    float* vraw;           // [L] workspace: W^T u before normalisation
+    float* wv;             // [R] workspace: W v
+    float* norm2;          // [colblocks] workspace: sum of squares of vraw per column block
+    int R, L, slices, rps, blockA0, blocksA, blockC0, blocksC, blockR0, blocksR;
+};
+struct SnTable {
+    int njobs, pad;
+    SnJob jobs[SN_MAX_JOBS];
+};
+
+// slab[z][l] = sum_{r in slice z} u[r] * W[r][l]; grid per job: colblocks x slices
+__global__ __launch_bounds__(LT) void sn_coldot_kernel(SnTable t) {
+    int j = 0;
+    while (j + 1 < t.njobs && t.jobs[j + 1].blockA0 <= (int)blockIdx.x) ++j;
+    const SnJob& jb = t.jobs[j];
+    const int L4 = jb.L >> 2, colblocks = (L4 + LT - 1) / LT;
+    const int lb = blockIdx.x - jb.blockA0, cb = lb % colblocks, z = lb / colblocks;
+    const int q = cb * LT + threadIdx.x;
+    if (q >= L4) return;
+    const int r0 = z * jb.rps, r1 = min(jb.R, r0 + jb.rps);
+    const f32x4* pw = reinterpret_cast<const f32x4*>(jb.W) + q;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {            // four rows in flight, added in row order
+        const f32x4 w0 = pw[(long long)r * L4], w1 = pw[(long long)(r + 1) * L4];
+        const f32x4 w2 = pw[(long long)(r + 2) * L4], w3 = pw[(long long)(r + 3) * L4];
+        acc = acc + w0 * jb.u[r];
+        acc = acc + w1 * jb.u[r + 1];
+        acc = acc + w2 * jb.u[r + 2];
+        acc = acc + w3 * jb.u[r + 3];
+    }
+    for (; r < r1; ++r) acc = acc + pw[(long long)r * L4] * jb.u[r];
+    reinterpret_cast<f32x4*>(jb.slabs)[(long long)z * L4 + q] = acc;
+}
+
+// vraw = sum of the slabs in slice order (one float4 column per lane), norm2[cb] = the column block's sum of squares
+__global__ __launch_bounds__(LT) void sn_vsum_kernel(SnTable t) {
+    __shared__ float red[4];
+    int j = 0;
+    while (j + 1 < t.njobs && t.jobs[j + 1].blockC0 <= (int)blockIdx.x) ++j;
+    const SnJob& jb = t.jobs[j];
+    const int L4 = jb.L >> 2, cb = blockIdx.x - jb.blockC0;
+    const int q = cb * LT + threadIdx.x;
+    float s = 0.f;
+    if (q < L4) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(jb.slabs) + q;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        int sl = 0;
+        for (; sl + 8 <= jb.slices; sl += 8) {
+            f32x4 tv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tv[k] = p[(long long)(sl + k) * L4];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a = a + tv[k];
+        }
+        for (; sl < jb.slices; ++sl) a = a + p[(long long)sl * L4];
+        reinterpret_cast<f32x4*>(jb.vraw)[q] = a;
+        s = (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) jb.norm2[cb] = s;
+}
+
+// wv[r] = <W[r], v> with v = vraw / max(||vraw||, eps) formed on the fly; one workgroup per row, which also writes
+// its share of v to the module buffer and to the node's copy
+__global__ __launch_bounds__(LT) void sn_rowdot_kernel(SnTable t, float eps) {
+    __shared__ float red[4];
+    int j = 0;
+    while (j + 1 < t.njobs && t.jobs[j + 1].blockR0 <= (int)blockIdx.x) ++j;
+    const SnJob& jb = t.jobs[j];
+    const int L4 = jb.L >> 2, colblocks = (L4 + LT - 1) / LT, b = blockIdx.x - jb.blockR0;
+    float tot = 0.f;
+    for (int c = 0; c < colblocks; ++c) tot += jb.norm2[c];
+    const float inv = 1.f / fmaxf(sqrtf(tot), eps);
+    const f32x4* pv = reinterpret_cast<const f32x4*>(jb.vraw);
+    const int share = (L4 + jb.blocksR - 1) / jb.blocksR;
+    for (int c = b * share + threadIdx.x; c < min(L4, (b + 1) * share); c += LT) {
+        const f32x4 a = pv[c] * inv;
+        reinterpret_cast<f32x4*>(jb.vs)[c] = a;
+        reinterpret_cast<f32x4*>(jb.v)[c] = a;
+    }
+    for (int r = b; r < jb.R; r += jb.blocksR) {
+        const f32x4* pa = reinterpret_cast<const f32x4*>(jb.W) + (long long)r * L4;
+        float s0 = 0.f, s1 = 0.f;
+        int q = threadIdx.x;
+        for (; q + LT < L4; q += 2 * LT) {
+            const f32x4 a = pa[q], w = pv[q] * inv, a2 = pa[q + LT], w2 = pv[q + LT] * inv;
+            s0 += (a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w);
+            s1 += (a2.x * w2.x + a2.y * w2.y) + (a2.z * w2.z + a2.w * w2.w);
+        }
+        for (; q < L4; q += LT) {
+            const f32x4 a = pa[q], w = pv[q] * inv;
+            s0 += (a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w);
+        }
+        const float sr = block_sum(s0 + s1, red);
+        if (threadIdx.x == 0) jb.wv[r] = sr;
+    }
+}
+
+// u = wv / max(||wv||, eps), sigma = <u, wv>; one workgroup per job
+__global__ __launch_bounds__(LT) void sn_unorm_kernel(SnTable t, float eps) {
+    __shared__ float red[4];
+    const SnJob& jb = t.jobs[blockIdx.x];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < jb.R; i += LT) {
+        const float x = jb.wv[i];
+        s += x * x;
+    }
+    s = block_sum(s, red);
+    const float inv = 1.f / fmaxf(sqrtf(s), eps);
+    float d = 0.f;
+    for (int i = threadIdx.x; i < jb.R; i += LT) {
+        const float x = jb.wv[i];
+        const float qv = x * inv;
+        jb.u[i] = qv;
+        jb.us[i] = qv;
+        d += qv * x;
+    }
+    d = block_sum(d, red);
+    if (threadIdx.x == 0) jb.sigma[0] = d;
+}
+
 static int grid_for(long long items) {
     long long b = (items + LT - 1) / LT;
     if (b > 2048) b = 2048;
@@ -226,6 +366,53 @@ int gz_mse_mean_bwd(const float* a, const float* b, const float* gloss, float* d
     gz::clear_stale_error();
     if (n <= 0) return GZ_ERR_BAD_SHAPE;
     hipLaunchKernelGGL(mse_mean_bwd_kernel, dim3(grid_for(n)), dim3(LT), 0, stream, a, b, gloss, da, n);
+    return launch_status();
+}
+
+int gz_sn_max_jobs(void) { return SN_MAX_JOBS; }
+size_t gz_sn_table_bytes(void) { return sizeof(SnTable); }
+static int sn_colblocks(int L) { return (L / 4 + LT - 1) / LT; }
+long long gz_sn_workspace_floats(int R, int L) {
+    if (R <= 0 || L <= 0) return 0;
+    return (long long)(R >= 64 ? SN_SLICES : 1) * L + L + ((R + 3) & ~3) + sn_colblocks(L);
+}
+
+int gz_sn_add(void* table_host, const float* W, float* u, float* v, float* us, float* vs, float* sigma, float* workspace,
+              int R, int L) {
+    SnTable* t = reinterpret_cast<SnTable*>(table_host);
+    if (!t || !W || !u || !v || !us || !vs || !sigma || !workspace || R <= 0 || L <= 0 || (L & 3)) return GZ_ERR_BAD_SHAPE;
+    if ((((uintptr_t)W | (uintptr_t)v | (uintptr_t)vs | (uintptr_t)workspace) & 15)) return GZ_ERR_BAD_SHAPE;
+    if (t->njobs < 0 || t->njobs >= SN_MAX_JOBS) return GZ_ERR_UNSUPPORTED;
+    SnJob& jb = t->jobs[t->njobs++];
+    const int slices = R >= 64 ? SN_SLICES : 1;           // (gz_coldot's slicing)
+    float* vraw = workspace + (long long)slices * L;
+    float* wv = vraw + L;
+    jb = SnJob{W, u, v, us, vs, sigma, workspace, vraw, wv, wv + ((R + 3) & ~3), R, L, slices, (R + slices - 1) / slices,
+               0, 0, 0, 0, 0, 0};
+    return GZ_OK;
+}
+
+int gz_sn_power_iteration(void* table_host, float eps, hipStream_t stream) {
+    gz::clear_stale_error();
+    SnTable* t = reinterpret_cast<SnTable*>(table_host);
+    if (!t || t->njobs <= 0 || t->njobs > SN_MAX_JOBS) return GZ_ERR_BAD_SHAPE;
+    int a = 0, c = 0, r = 0;
+    for (int j = 0; j < t->njobs; ++j) {
+        SnJob& jb = t->jobs[j];
+        jb.blockA0 = a;
+        jb.blocksA = sn_colblocks(jb.L) * jb.slices;
+        a += jb.blocksA;
+        jb.blockC0 = c;
+        jb.blocksC = sn_colblocks(jb.L);
+        c += jb.blocksC;
+        jb.blockR0 = r;
+        jb.blocksR = jb.R > 2048 ? 2048 : jb.R;
+        r += jb.blocksR;
+    }
+    hipLaunchKernelGGL(sn_coldot_kernel, dim3(a), dim3(LT), 0, stream, *t);
+    hipLaunchKernelGGL(sn_vsum_kernel, dim3(c), dim3(LT), 0, stream, *t);
+    hipLaunchKernelGGL(sn_rowdot_kernel, dim3(r), dim3(LT), 0, stream, *t, eps);
+    hipLaunchKernelGGL(sn_unorm_kernel, dim3(t->njobs), dim3(LT), 0, stream, *t, eps);
     return launch_status();
 }
 

@@ -116,11 +116,183 @@ __global__ __launch_bounds__(MT) void colsum_kernel(const float* __restrict__ x,
     }
 }
 
+// ---- several small Linear layers over ONE input, one launch --------------------------------------------------
+// HoloGAN's generator feeds the same z through five ZMapping layers (Linear(128 -> 2C) + ReLU, reference
+// core/models/hologan_generator.py:7-19,33,57,141): 33 MFLOP in all, which as five GEMM launches forward and
+// fifteen launches backward (mask, dW, db each) cost ~0.2 ms of launch-bound time per generator pass.  A job table
+// passed by value carries the layers; plain FMA tiles through LDS are enough at this size.
+constexpr int LIN_MAX_JOBS = 8;
+struct LinJob {
+    const float* w;        // [J][K]
+    const float* b;        // [J] or null
+    float* out;            // [N][J]   forward: written; backward: read for the activation's derivative
+    const float* g;        // [N][J]   backward only
+    float* dw;             // [J][K]
+    float* db;             // [J] or null
+    int J, block0;
+};
+struct LinTable {
+    int njobs, pad;
+    LinJob jobs[LIN_MAX_JOBS];
+};
+
+__device__ __forceinline__ const LinJob& lin_job(const LinTable& t, int b) {
+    int j = 0;
+    while (j + 1 < t.njobs && t.jobs[j + 1].block0 <= b) ++j;
+    return t.jobs[j];
+}
+
+// out_j[n][o] = act(sum_k x[n][k] * w_j[o][k] + b_j[o]); a workgroup owns 64 outputs x 64 rows of one job, a lane
+// 4 x 4 of them (k-major LDS images: two 16-byte LDS reads per 16 FMAs)
+__global__ __launch_bounds__(MT) void linear_multi_fwd_kernel(LinTable t, const float* __restrict__ x, int N, int K,
+                                                              int act, float slope) {
+    __shared__ __attribute__((aligned(16))) float xs[32][68], ws[32][68];
+    const LinJob& jb = lin_job(t, blockIdx.x);
+    const int j0 = (blockIdx.x - jb.block0) * 64, n0 = blockIdx.y * 64;
+    const int tj = threadIdx.x & 15, tn = threadIdx.x >> 4;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        float xr[8], wr[8];          // all sixteen loads first (clamped addresses), the edge zeros on the way to LDS
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = threadIdx.x + MT * i, r = idx >> 5, kc = min(k0 + (idx & 31), K - 1);
+            xr[i] = x[(long long)min(n0 + r, N - 1) * K + kc];
+            wr[i] = jb.w[(long long)min(j0 + r, jb.J - 1) * K + kc];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = threadIdx.x + MT * i, r = idx >> 5, c = idx & 31;
+            const bool kin = k0 + c < K;
+            xs[c][r] = (kin && n0 + r < N) ? xr[i] : 0.f;
+            ws[c][r] = (kin && j0 + r < jb.J) ? wr[i] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(&xs[kk][tn * 4]);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(&ws[kk][tj * 4]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(wv[a], xv[b], acc[a][b]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int j = j0 + tj * 4 + a;
+        if (j >= jb.J) continue;
+        const float bv = jb.b ? jb.b[j] : 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int n = n0 + tn * 4 + b;
+            if (n < N) jb.out[(long long)n * jb.J + j] = act_fwd(acc[a][b] + bv, act, slope);
+        }
+    }
+}
+
+// dw_j[o][k] = sum_n gm[n][o] * x[n][k], db_j[o] = sum_n gm[n][o], gm = g_j * act'(out_j); a workgroup owns
+// 64 outputs x 64 inputs of one job and walks the rows in a fixed order
+__global__ __launch_bounds__(MT) void linear_multi_bwd_kernel(LinTable t, const float* __restrict__ x, int N, int K,
+                                                              int act, float slope) {
+    __shared__ __attribute__((aligned(16))) float gs[32][68], xs[32][68];
+    const LinJob& jb = lin_job(t, blockIdx.x);
+    const int j0 = (blockIdx.x - jb.block0) * 64, k0 = blockIdx.y * 64;
+    const int tk = threadIdx.x & 15, tj = threadIdx.x >> 4;
+    float acc[4][4] = {}, bacc[4] = {};
+    for (int n0 = 0; n0 < N; n0 += 32) {
+        float gr[8], orr[8], xr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = threadIdx.x + MT * i, r = min(n0 + (idx >> 6), N - 1), c = idx & 63;
+            const long long at = (long long)r * jb.J + min(j0 + c, jb.J - 1);
+            gr[i] = jb.g[at];
+            orr[i] = act != ACT_NONE ? jb.out[at] : 1.f;
+            xr[i] = x[(long long)r * K + min(k0 + c, K - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = threadIdx.x + MT * i, r = idx >> 6, c = idx & 63;
+            const bool nin = n0 + r < N;
+            gs[r][c] = (nin && j0 + c < jb.J) ? gr[i] * act_bwd_from_out(orr[i], act, slope) : 0.f;
+            xs[r][c] = (nin && k0 + c < K) ? xr[i] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int n = 0; n < 32; ++n) {
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(&gs[n][tj * 4]);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(&xs[n][tk * 4]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                bacc[a] += gv[a];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(gv[a], xv[b], acc[a][b]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int j = j0 + tj * 4 + a;
+        if (j >= jb.J) continue;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int k = k0 + tk * 4 + b;
+            if (k < K) jb.dw[(long long)j * K + k] = acc[a][b];
+        }
+        if (jb.db && blockIdx.y == 0 && tk == 0) jb.db[j] = bacc[a];
+    }
+}
+
 }  // namespace gz
 
 using namespace gz;
 
 extern "C" {
+
+int gz_linear_multi_max_jobs(void) { return LIN_MAX_JOBS; }
+size_t gz_linear_multi_table_bytes(void) { return sizeof(LinTable); }
+
+int gz_linear_multi_add(void* table_host, const float* weight, const float* bias, float* out, const float* g, float* dw,
+                        float* db, int J) {
+    LinTable* t = reinterpret_cast<LinTable*>(table_host);
+    if (!t || !out || J <= 0) return GZ_ERR_BAD_SHAPE;
+    if (t->njobs < 0 || t->njobs >= LIN_MAX_JOBS) return GZ_ERR_UNSUPPORTED;
+    t->jobs[t->njobs++] = LinJob{weight, bias, out, g, dw, db, J, 0};
+    return GZ_OK;
+}
+
+static int linear_multi_launch(void* table_host, const float* x, int N, int K, int act, float slope, bool bwd,
+                               hipStream_t stream) {
+    gz::clear_stale_error();
+    LinTable* t = reinterpret_cast<LinTable*>(table_host);
+    if (!t || !x || N <= 0 || K <= 0 || t->njobs <= 0 || t->njobs > LIN_MAX_JOBS) return GZ_ERR_BAD_SHAPE;
+    if (act < GZ_ACT_NONE || act > GZ_ACT_TANH) return GZ_ERR_BAD_SHAPE;
+    long long blocks = 0;
+    for (int j = 0; j < t->njobs; ++j) {
+        const LinJob& jb = t->jobs[j];
+        if (bwd ? (!jb.g || !jb.dw) : !jb.w) return GZ_ERR_BAD_SHAPE;
+        t->jobs[j].block0 = (int)blocks;
+        blocks += (jb.J + 63) / 64;
+    }
+    const long long by = bwd ? (K + 63) / 64 : (N + 63) / 64;
+    if (blocks >= (1ll << 31) || by > 65535) return GZ_ERR_TOO_LARGE;
+    if (bwd)
+        hipLaunchKernelGGL(linear_multi_bwd_kernel, dim3((unsigned)blocks, (unsigned)by), dim3(MT), 0, stream, *t, x, N, K,
+                           act, slope);
+    else
+        hipLaunchKernelGGL(linear_multi_fwd_kernel, dim3((unsigned)blocks, (unsigned)by), dim3(MT), 0, stream, *t, x, N, K,
+                           act, slope);
+    return launch_status();
+}
+
+int gz_linear_multi_fwd(void* table_host, const float* x, int N, int K, int act, float slope, hipStream_t stream) {
+    return linear_multi_launch(table_host, x, N, K, act, slope, false, stream);
+}
+
+int gz_linear_multi_bwd(void* table_host, const float* x, int N, int K, int act, float slope, hipStream_t stream) {
+    return linear_multi_launch(table_host, x, N, K, act, slope, true, stream);
+}
 
 int gz_colsum(const float* x, float* out, int R, int L, hipStream_t stream) {
     gz::clear_stale_error();

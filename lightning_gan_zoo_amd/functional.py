@@ -194,6 +194,9 @@ def _repack_group(gid):
 
 
 def _packed(w, kind, geom):
+    pk = getattr(w, "_gz_packs", None)          # spectral_normalize_multi wrote both images next to w itself
+    if pk is not None and pk["version"] == w._version and (kind == "f" or pk["geom"] == geom):
+        return pk[kind]
     key = (w.data_ptr(), kind)
     cacheable = _pack_cache_enabled and isinstance(w, torch.nn.Parameter)
     e = _pack_cache.get(key) if cacheable else None
@@ -1529,6 +1532,69 @@ def linear_act(x, weight, bias=None, act=ACT_NONE, slope=0.0):
     return _LinearAct.apply(x, weight, bias, act, slope)
 
 
+class _LinearActMulti(torch.autograd.Function):
+    """Several act(x @ W_j^T + b_j) over ONE x in one launch; one launch for every dW_j / db_j backward."""
+
+    @staticmethod
+    def forward(ctx, x, act, slope, *wb):
+        x = _req(x, "x")
+        ws = [_req(w, "weight") for w in wb[0::2]]
+        bs = [None if b is None else _req(b, "bias") for b in wb[1::2]]
+        N, K = x.shape
+        if any(w.dim() != 2 or w.shape[1] != K for w in ws) or len(ws) > lib.gz_linear_multi_max_jobs():
+            raise ValueError("linear_act_multi: weights must be [J, %d], at most %d of them"
+                             % (K, lib.gz_linear_multi_max_jobs()))
+        outs = tuple(torch.empty((N, w.shape[0]), device=x.device, dtype=torch.float32) for w in ws)
+        table = (ctypes.c_char * lib.gz_linear_multi_table_bytes())()
+        for w, b, o in zip(ws, bs, outs):
+            check(lib.gz_linear_multi_add(table, _p(w), _p(b), _p(o), None, None, None, w.shape[0]), "linear_multi_add")
+        check(lib.gz_linear_multi_fwd(table, _p(x), N, K, act, slope, _stream()), "linear_multi_fwd")
+        ctx.save_for_backward(x, *ws, *outs)
+        ctx.act, ctx.slope, ctx.has_bias = act, slope, [b is not None for b in bs]
+        return outs
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gs):
+        saved = ctx.saved_tensors
+        n = len(ctx.has_bias)
+        x, ws, outs = saved[0], saved[1:1 + n], saved[1 + n:]
+        N, K = x.shape
+        gs = [torch.zeros_like(o) if g is None else _req(g) for g, o in zip(gs, outs)]
+        grads = []
+        table = (ctypes.c_char * lib.gz_linear_multi_table_bytes())()
+        for j, (w, o, g) in enumerate(zip(ws, outs, gs)):
+            dw = torch.empty_like(w)
+            db = torch.empty(w.shape[0], device=w.device, dtype=torch.float32) if ctx.has_bias[j] else None
+            check(lib.gz_linear_multi_add(table, None, None, _p(o), _p(g), _p(dw), _p(db), w.shape[0]), "linear_multi_add")
+            grads += [dw, db]
+        check(lib.gz_linear_multi_bwd(table, _p(x), N, K, ctx.act, ctx.slope, _stream()), "linear_multi_bwd")
+        dx = None
+        if ctx.needs_input_grad[0]:          # (z is noise in the shipped models: not on their path)
+            for w, o, g in zip(ws, outs, gs):
+                gm = g if ctx.act == ACT_NONE else g * _act_derivative(o, ctx.act, ctx.slope)
+                part = gemm(gm.contiguous(), w)
+                dx = part if dx is None else dx + part
+        return (dx, None, None, *grads)
+
+
+def _act_derivative(out, act, slope):
+    if act == ACT_RELU:
+        return (out > 0).float()
+    if act == ACT_TANH:
+        return 1 - out * out
+    return torch.where(out > 0, 1.0, slope)
+
+
+def linear_act_multi(x, layers, act=ACT_NONE, slope=0.0):
+    """``[linear_act(x, w, b, act) for (w, b) in layers]`` in ONE launch (and one launch for all the weight and bias
+    gradients): HoloGAN's five ZMapping layers over the same z (reference core/models/hologan_generator.py:7-19)."""
+    flat = []
+    for w, b in layers:
+        flat += [w, b]
+    return _LinearActMulti.apply(x, act, slope, *flat)
+
+
 class _RigidResample(torch.autograd.Function):
     """[N,C,S,S,S] voxels + [N,16] inverse view matrices -> [N, C*S, S, S] projected feature map."""
 
@@ -1634,6 +1700,80 @@ def spectral_normalize(weight_orig, u, v, training, eps=1e-12):
     uc, vc = u.clone(), v.clone()
     sigma = torch.dot(uc, _DotF.apply(w_mat, vc))
     return weight_orig / sigma
+
+
+class _SpectralNormMulti(torch.autograd.Function):
+    """spectral_normalize for SEVERAL conv weights of one discriminator call: the power iterations in four launches
+    (gz_sn_power_iteration), w = weight_orig / sigma together with both packed images of every layer in a fifth
+    (gz_conv2d_pack_table_launch) -- 8 launches per layer before.  The packed images ride on the returned tensors
+    (``_gz_packs``) and are picked up by ``_packed``."""
+
+    @staticmethod
+    def forward(ctx, eps, geom, *wuv):
+        Ws = [_req(w, "weight_orig") for w in wuv[0::3]]
+        us_buf, vs_buf = wuv[1::3], wuv[2::3]
+        dev, st = Ws[0].device, _stream()
+        if len(Ws) > lib.gz_sn_max_jobs() or 3 * len(Ws) > lib.gz_conv2d_pack_table_max_jobs():
+            raise ValueError("spectral_normalize_multi: at most %d layers" % lib.gz_sn_max_jobs())
+        table = (ctypes.c_char * lib.gz_sn_table_bytes())()
+        packs = (ctypes.c_char * lib.gz_conv2d_pack_table_bytes())()
+        keep, saved, outs = [], [], []
+        for W, u, v in zip(Ws, us_buf, vs_buf):
+            K, C, KH, KW = W.shape
+            R, L = K, C * KH * KW
+            us = torch.empty(R, device=dev, dtype=torch.float32)
+            vs = torch.empty(L, device=dev, dtype=torch.float32)
+            sigma = torch.empty(1, device=dev, dtype=torch.float32)
+            ws = _ws(lib.gz_sn_workspace_floats(R, L), dev)
+            check(lib.gz_sn_add(table, _p(W), _p(u), _p(v), _p(us), _p(vs), _p(sigma), _p(ws), R, L), "sn_add")
+            w = torch.empty_like(W)
+            wf = torch.empty(lib.gz_conv2d_pack_fwd_elems(K, C, KH, KW), device=dev, dtype=torch.float32)
+            wd = torch.empty(lib.gz_conv2d_pack_dgrad_elems(K, C, KH, KW, geom.stride), device=dev, dtype=torch.float32)
+            for what, dst in ((2, w), (0, wf), (1, wd)):
+                check(lib.gz_conv2d_pack_table_add(packs, _p(W), _p(dst), _p(sigma), what, K, C, KH, KW, geom.stride,
+                                                   geom.pad), "pack_table_add")
+            w._gz_packs = {"f": wf, "d": wd, "geom": geom, "version": w._version}
+            keep.append(ws)
+            saved += [w, us, vs, sigma]
+            outs.append(w)
+        check(lib.gz_sn_power_iteration(table, eps, st), "sn_power_iteration")
+        check(lib.gz_conv2d_pack_table_launch(packs, st), "pack_table_launch")
+        del keep            # (stream-ordered allocator: the workspaces may be reused by later launches of this stream)
+        ctx.save_for_backward(*saved)
+        return tuple(outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gs):
+        saved = ctx.saved_tensors
+        grads = []
+        for k, g in enumerate(gs):
+            w, us, vs, sigma = saved[4 * k: 4 * k + 4]
+            if g is None:
+                grads += [None, None, None]
+                continue
+            g = _req(g)
+            R = w.shape[0]
+            L = w.numel() // R
+            rowdots = _rowdot_raw(g.view(R, L), w.view(R, L), False)
+            out = torch.empty_like(w)
+            check(lib.gz_spectral_norm_bwd(_p(g), _p(rowdots), _p(us), _p(vs), _p(sigma), _p(out), R, L, _stream()),
+                  "spectral_norm_bwd")
+            grads += [out, None, None]
+        return (None, None, *grads)
+
+
+def spectral_normalize_multi(layers, training, geom, eps=1e-12):
+    """``[spectral_normalize(W, u, v, training) for (W, u, v) in layers]`` for the conv weights of one discriminator call
+    (all of geometry ``geom``); training mode on 4-D weights with C*KH*KW % 4 == 0 takes the five-launch path."""
+    ok = training and all(W.dim() == 4 and (W.numel() // W.shape[0]) % 4 == 0 and W.is_cuda and W.is_contiguous()
+                          and W.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0 for W, _, v in layers)
+    if not ok or len(layers) > lib.gz_sn_max_jobs():
+        return [spectral_normalize(W, u, v, training, eps) for W, u, v in layers]
+    flat = []
+    for W, u, v in layers:
+        flat += [W, u, v]
+    return list(_SpectralNormMulti.apply(float(eps), geom, *flat))
 
 
 # ---------------------------------------------------------------------------

@@ -73,11 +73,26 @@ def record_product_masks(tape):
     from lightning_gan_zoo_amd import functional as F
     saved = {}
 
+    pending = {}          # id(style tensor) -> the tensor: ZMapping outputs waiting for the AdaIN that consumes them
+
+    def multi(x, layers, act=F.ACT_NONE, slope=0.0):
+        # the product maps z through all five ZMapping layers up front (one launch); the oracle, like the reference,
+        # takes each ReLU decision right before the AdaIN it feeds: tape them there
+        outs = saved["linear_act_multi"](x, layers, act, slope)
+        if act in (F.ACT_RELU, F.ACT_LRELU):
+            pending.update({id(o): o for o in outs})
+        return outs
+
+    saved["linear_act_multi"] = F.linear_act_multi
+    F.linear_act_multi = multi
+
     def wrap(name, act_pos, act_kw):
         fn = getattr(F, name)
         saved[name] = fn
 
         def inner(*a, **k):
+            if name in ("adain_act_packed", "adain_const_act") and id(a[1]) in pending:
+                tape.record(pending.pop(id(a[1])))
             out = fn(*a, **k)
             act = k.get(act_kw, a[act_pos] if len(a) > act_pos else F.ACT_NONE)
             if name in ("adain_act", "adain_act_packed", "adain_const_act") and act_kw not in k and len(a) <= act_pos:
@@ -96,6 +111,7 @@ def record_product_masks(tape):
     wrap("conv_transpose2d", 4, "act")
     try:
         yield tape
+        assert not pending, "a ZMapping output was never consumed by an AdaIN"
     finally:
         for name, fn in saved.items():
             setattr(F, name, fn)

@@ -515,6 +515,78 @@ def test_linear_act_fwd_bwd():
     assert rel(bd.grad, br.grad) < TOL and rel(wd.grad, wr.grad) < TOL
 
 
+@pytest.mark.parametrize("shape", [(64, 128, (1024, 256, 128, 512, 128)), (5, 7, (3, 70)), (130, 33, (65,))])
+def test_linear_act_multi_matches_separate_layers(shape):
+    """HoloGAN's five ZMapping layers in one launch (gz_linear_multi_fwd / _bwd): values, weight, bias and input
+    gradients against torch's nn.functional.linear per layer; ragged N, K, J exercise the tile edges."""
+    F = _F()
+    N, K, Js = shape
+    x = rnd(N, K, seed=300)
+    ws = [rnd(J, K, seed=301 + i, scale=0.2) for i, J in enumerate(Js)]
+    bs = [rnd(J, seed=331 + i) for i, J in enumerate(Js)]
+    for act, fn in ((F.ACT_RELU, torch.relu), (F.ACT_NONE, lambda t: t), (F.ACT_TANH, torch.tanh),
+                    (F.ACT_LRELU, lambda t: TF.leaky_relu(t, 0.2))):
+        xr = x.clone().requires_grad_()
+        wr, br = [w.clone().requires_grad_() for w in ws], [b.clone().requires_grad_() for b in bs]
+        refs = [fn(TF.linear(xr, w, b)) for w, b in zip(wr, br)]
+        sum((i + 1.0) * r.pow(2).sum() for i, r in enumerate(refs)).backward()
+        xd = x.cuda().requires_grad_()
+        wd, bd = [w.cuda().requires_grad_() for w in ws], [b.cuda().requires_grad_() for b in bs]
+        outs = F.linear_act_multi(xd, list(zip(wd, bd)), act, 0.2)
+        sum((i + 1.0) * o.pow(2).sum() for i, o in enumerate(outs)).backward()
+        assert rel(xd.grad, xr.grad) < TOL
+        for o, r, w1, w0, b1, b0 in zip(outs, refs, wd, wr, bd, br):
+            assert o.shape == r.shape and rel(o, r) < TOL
+            assert rel(w1.grad, w0.grad) < TOL and rel(b1.grad, b0.grad) < TOL
+    # an output nobody uses gets a zero gradient; a layer without bias
+    wd = [w.cuda().requires_grad_() for w in ws]
+    outs = F.linear_act_multi(x.cuda(), [(w, None) for w in wd], F.ACT_RELU)
+    outs[0].sum().backward()
+    assert rel(outs[0], torch.relu(TF.linear(x, ws[0]))) < TOL
+    assert all(float(w.grad.abs().max()) == 0.0 for w in wd[1:]) and float(wd[0].grad.abs().max()) > 0
+
+
+def test_spectral_normalize_multi_matches_per_layer_path():
+    """The five-launch spectral normalisation of all blocks of a HoloGAN discriminator call (power iterations as jobs of
+    four launches, w and both packed images in one table launch) against the per-layer path and against
+    torch.nn.utils.spectral_norm's arithmetic on the CPU: u / v buffers, sigma-scaled weights, the convolution run
+    from the attached images (forward, input gradient) and the weight_orig gradients."""
+    F = _F()
+    geom = F.Geom(5, 5, 2, 2)
+    shapes = [(128, 64), (256, 128), (512, 256), (24, 12)]            # the reference's three blocks + a ragged one
+    g = torch.Generator().manual_seed(77)
+    Ws = [torch.randn(k, c, 5, 5, generator=g) * 0.05 for k, c in shapes]
+    us = [torch.nn.functional.normalize(torch.randn(k, generator=g), dim=0) for k, _ in shapes]
+    vs = [torch.nn.functional.normalize(torch.randn(c * 25, generator=g), dim=0) for _, c in shapes]
+    xs = [torch.randn(2, c, 16, 16, generator=g) for _, c in shapes]
+    for rounds in (1, 2):            # twice: the buffers carry over
+        res = {}
+        for mode in ("multi", "single", "cpu"):
+            dev = "cpu" if mode == "cpu" else "cuda"
+            W = [w.clone().to(dev).requires_grad_() for w in Ws]
+            u, v = [t.clone().to(dev) for t in us], [t.clone().to(dev) for t in vs]
+            x = [t.clone().to(dev).requires_grad_() for t in xs]
+            for _ in range(rounds):
+                if mode == "multi":
+                    ws = F.spectral_normalize_multi(list(zip(W, u, v)), True, geom)
+                    assert all(hasattr(w, "_gz_packs") for w in ws)
+                elif mode == "single":
+                    ws = [F.spectral_normalize(a, b, c, True) for a, b, c in zip(W, u, v)]
+                else:
+                    ws = []
+                    for a, b, c in zip(W, u, v):
+                        m = a.detach().reshape(a.shape[0], -1)
+                        c.copy_(torch.nn.functional.normalize(m.t() @ b, dim=0, eps=1e-12))
+                        b.copy_(torch.nn.functional.normalize(m @ c, dim=0, eps=1e-12))
+                        ws.append(a / torch.dot(b, a.reshape(a.shape[0], -1) @ c))
+            ys = [(F.conv2d(xi, w, None, geom) if mode != "cpu" else TF.conv2d(xi, w, None, 2, 2)) for xi, w in zip(x, ws)]
+            sum(y.pow(2).sum() for y in ys).backward()
+            res[mode] = [t.detach().cpu() for t in ws + u + v + ys + [a.grad for a in W] + [xi.grad for xi in x]]
+        for k, (a, b, c) in enumerate(zip(res["multi"], res["single"], res["cpu"])):
+            assert rel(a, b) < 2e-6, (rounds, k, rel(a, b))
+            assert rel(a, c) < TOL, (rounds, k, rel(a, c))
+
+
 @pytest.mark.parametrize("width", [(8, 16), (64, 128)])      # (in_planes, z): small, and the reference's default width
 def test_hologan_ext128_matches_oracle_extension(width):
     """EXT-128: the reference cannot run at 128x128; product and oracle implement the
