@@ -442,6 +442,8 @@ def _sink_note_use(w):
 
 def _sink_done(w):
     """One forward use of ``w`` has delivered its gradient (through the sink or through autograd)."""
+    if w is None:
+        return
     k = id(w)
     n = _sinks.uses.get(k)
     if n is None:
@@ -492,6 +494,37 @@ def _sink_conv_wgrad(w, x, g, geom):
     _sinks.pending.setdefault(id(w), [w, []])[1].append(src)
     _sink_done(w)
     return True
+
+
+def _sink_grad(p, g):
+    """A COMPLETE gradient contribution ``g`` of parameter ``p`` (a bias, a Linear weight, a spectral-norm weight_orig).
+    Alone it goes back to autograd, whose AccumulateGrad keeps the tensor at no cost; when ``p`` is fed by several
+    forward uses of this pass (HoloGAN's discriminator runs twice per D step: 13 ``add_`` launches) or already holds a
+    gradient (the flat exchange buffer, gradient accumulation), it is queued as a one-slab source instead and summed
+    with everything else pending by flush_grad_sinks' one launch.  True = taken (return None to autograd)."""
+    if g is None or not _sinks.enabled or not isinstance(p, torch.nn.Parameter) or (p.numel() & 3):
+        return False
+    k = id(p)
+    if not (_sinks.uses.get(k, 0) > 1 or k in _sinks.pending or p.grad is not None):
+        return False
+    if p.grad is not None and (p.grad.data_ptr() & 15 or not p.grad.is_contiguous() or p.grad.dtype != torch.float32):
+        return False
+    g = _req(g)
+    if g.data_ptr() & 15:
+        return False
+    _sinks.pending.setdefault(k, [p, []])[1].append((g, 1, p.numel()))
+    _sink_done(p)
+    return True
+
+
+def _sink_or_return(p, g):
+    """``g`` for autograd, or None when the sink took it; either way one forward use of ``p`` is delivered."""
+    if g is None:
+        return None
+    if _sink_grad(p, g):
+        return None
+    _sink_done(p)
+    return g
 
 
 def _sink_fail(what):
@@ -634,6 +667,8 @@ class _ConvF(torch.autograd.Function):
         ctx.geom, ctx.act, ctx.slope = geom, act, slope
         ctx.has_bias = bias is not None
         _sink_note_use(w)
+        _sink_note_use(bias)
+        ctx.bias_ref = bias if isinstance(bias, torch.nn.Parameter) else None
         if want_stats:          # BatchNorm follows: no bias, no activation; second output = partial statistics
             y, stats = _conv_fwd_stats_raw(x, w, geom)
             ctx.save_for_backward(x, w, None)
@@ -667,6 +702,7 @@ class _ConvF(torch.autograd.Function):
             dw = _ConvWg.apply(x, gy, geom)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _ChannelSum.apply(gy)
+            _sink_done(ctx.bias_ref)
         if ctx.needs_input_grad[1]:
             _sink_done(w)
         return dx, dw, db, None, None, None, None
@@ -688,6 +724,8 @@ class _ConvF(torch.autograd.Function):
                 _sink_done(w)
         elif want_b:
             db = _channel_sum_raw(gy)
+        if want_b and ctx.bias_ref is not None:
+            db = _sink_or_return(ctx.bias_ref, db)
         return dx, dw, db, None, None, None, None
 
 
@@ -700,6 +738,8 @@ class _ConvDg(torch.autograd.Function):
         ctx.geom, ctx.act, ctx.slope = geom, act, slope
         ctx.has_bias = bias is not None
         _sink_note_use(w)
+        _sink_note_use(bias)
+        ctx.bias_ref = bias if isinstance(bias, torch.nn.Parameter) else None
         if want_stats:
             x, stats = _conv_dgrad_stats_raw(g, w, geom, hw)
             ctx.save_for_backward(g, w, None)
@@ -728,6 +768,8 @@ class _ConvDg(torch.autograd.Function):
                 dw = _conv_wgrad_raw(v, g, geom)
                 _sink_done(w)
             db = _channel_sum_raw(v) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            if db is not None and ctx.bias_ref is not None:
+                db = _sink_or_return(ctx.bias_ref, db)
             return dg, dw, db, None, None, None, None, None
         dg = dw = db = None
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
@@ -739,6 +781,7 @@ class _ConvDg(torch.autograd.Function):
             dw = _ConvWg.apply(v, g, geom)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _ChannelSum.apply(v)
+            _sink_done(ctx.bias_ref)
         if ctx.needs_input_grad[1]:
             _sink_done(w)
         return dg, dw, db, None, None, None, None, None
@@ -1506,6 +1549,9 @@ class _LinearAct(torch.autograd.Function):
         out = gemm(x, weight, bias, trans_b=True, act=act, slope=slope)
         ctx.save_for_backward(x, weight, out if act != ACT_NONE else None)
         ctx.act, ctx.slope, ctx.has_bias = act, slope, bias is not None
+        _sink_note_use(weight)
+        _sink_note_use(bias)
+        ctx.bias_ref = bias if isinstance(bias, torch.nn.Parameter) else None
         return out
 
     @staticmethod
@@ -1525,6 +1571,9 @@ class _LinearAct(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(g.shape[1], device=g.device, dtype=torch.float32)
             check(lib.gz_colsum(_p(g), _p(db), g.shape[0], g.shape[1], _stream()), "colsum")
+            db = _sink_or_return(ctx.bias_ref, db) if ctx.bias_ref is not None else db
+        if dw is not None:
+            dw = _sink_or_return(weight, dw)
         return dx, dw, db, None, None
 
 
@@ -1710,6 +1759,9 @@ class _SpectralNormMulti(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eps, geom, *wuv):
+        for w in wuv[0::3]:
+            _sink_note_use(w)
+        ctx.params = wuv[0::3]
         Ws = [_req(w, "weight_orig") for w in wuv[0::3]]
         us_buf, vs_buf = wuv[1::3], wuv[2::3]
         dev, st = Ws[0].device, _stream()
@@ -1751,6 +1803,7 @@ class _SpectralNormMulti(torch.autograd.Function):
             w, us, vs, sigma = saved[4 * k: 4 * k + 4]
             if g is None:
                 grads += [None, None, None]
+                _sink_done(ctx.params[k])
                 continue
             g = _req(g)
             R = w.shape[0]
@@ -1759,7 +1812,7 @@ class _SpectralNormMulti(torch.autograd.Function):
             out = torch.empty_like(w)
             check(lib.gz_spectral_norm_bwd(_p(g), _p(rowdots), _p(us), _p(vs), _p(sigma), _p(out), R, L, _stream()),
                   "spectral_norm_bwd")
-            grads += [out, None, None]
+            grads += [_sink_or_return(ctx.params[k], out), None, None]
         return (None, None, *grads)
 
 
