@@ -235,6 +235,124 @@ static int run_wgrad3(const float* x, const float* y, float* dw, float* ws, size
     return rc;
 }
 
+// ---- the igemm2 skeleton for the two gather-fed directions (round 4) -----------------------------------------
+// The round-1 kernels above run HoloGAN's two ConvTranspose3d layers at 89-100 TFLOP/s forward and 95-104 on the input
+// gradient; the one-wavefront-per-SIMD skeleton with 4-byte LDS-DMA gathers (Conv3DDgTapA2 / Conv3DTapA2) takes them
+// when the GEMM's column count is a multiple of 64.  tile: 0 = not taken, 1 = 256x128, 2 = 256x64.
+using C3_256x128 = TileCfg2<2, 2, 2, 2>;
+using C3_256x64 = TileCfg2<2, 2, 1, 3>;
+
+struct Plan3T {
+    int tile, splits;
+    long long slabs;      // split launches of the transposed form: slabs summed over the phases
+};
+
+// transposed form: weight rows tap-major per phase (pack_dgrad3_tap_kernel) -- the pack and the launch must agree.
+// Multiples of 128 columns only: with 64 (HoloGAN's block2, 8-64 chunks per workgroup) the 256x64 tile measured 164 us
+// against 147 us on the round-1 kernel, and a 512x64 tile needs more gather pieces per k-step than the stream holds.
+static bool dg3_tap2(int K, int C) {
+    return !knobs().no_igemm2 && !knobs().no_igemm2_tap && K >= BK && (C & 127) == 0;
+}
+
+static Plan3T plan3_dgtap2(long long Mp, int C, int K, int KS, int S, int P) {
+    if (!dg3_tap2(K, C) || S * S * S > 8) return Plan3T{0, 1, 0};
+    const int kblocks = round_bk(K) / BK;
+    int pc[8], maxpc = 0;
+    long long total = 0;
+    for (int ph = 0; ph < S * S * S; ++ph) {
+        pc[ph] = dg_taps(KS, S, P, ph / (S * S)) * dg_taps(KS, S, P, (ph / S) % S) * dg_taps(KS, S, P, ph % S) * kblocks;
+        total += pc[ph];
+        maxpc = pc[ph] > maxpc ? pc[ph] : maxpc;
+    }
+    const long long tm = (Mp + 255) / 256;
+    // 256x128 also when its tiles alone do not fill the chip (HoloGAN block1 at bs 64, 128 tiles, 27 slabs: 184 us
+    // against 193 us on 256x64 tiles with 21 slabs; the round-1 kernel: 223 us)
+    const int tile = knobs().dg3_tile == 2 ? 2 : 1;
+    const long long tp = tm * (tile == 1 ? C / 128 : C / 64);
+    // phases of 1..8 taps: with >= 4 workgroups per CU the longest-first launch order balances them; below that the
+    // reduction is cut into pieces of equal length (>= 32 chunks), ~2 workgroups per CU
+    if (knobs().no_splitk || tp * S * S * S >= 4LL * cus()) return Plan3T{tile, 1, 0};
+    const int wgs = knobs().dg3_wgs * cus();
+    long long cps = (total * tp + wgs - 1) / wgs;
+    if (cps < knobs().dg3_min_chunks) cps = knobs().dg3_min_chunks;
+    const int splits = (int)((maxpc + cps - 1) / cps);
+    if (splits < 2) return Plan3T{tile, 1, 0};
+    const int per = (maxpc + splits - 1) / splits;
+    long long slabs = 0;
+    for (int ph = 0; ph < S * S * S; ++ph) slabs += (pc[ph] + per - 1) / per;
+    return Plan3T{tile, splits, slabs};
+}
+
+// plain strided form (the transposed layer's input gradient): the tap-major forward image is the one already packed
+static Plan3T plan3_fwdtap2(long long M, int K, int C, int KS) {
+    if (knobs().no_igemm2 || knobs().no_igemm2_tap || !fwd3_tap_major(C) || (K & 63)) return Plan3T{0, 1, 0};
+    const int chunks = KS * KS * KS * round_bk(C) / BK;
+    const long long tm = (M + 255) / 256, t64 = tm * (K / 64), t128 = (K & 127) ? 0 : tm * (K / 128);
+    const int cu = cus();
+    if (t128 >= cu * 7 / 8) return Plan3T{1, 1, 0};
+    if (t64 >= cu * 7 / 8) return Plan3T{2, 1, 0};
+    if (knobs().no_splitk) return Plan3T{0, 1, 0};
+    for (int tile = t128 ? 1 : 2; tile <= 2; ++tile) {
+        const long long tiles = tile == 1 ? t128 : t64;
+        int splits = (int)((cu + tiles - 1) / tiles);
+        while (splits > 1 && chunks / splits < 48) --splits;
+        if (splits > 1 && tiles * splits >= cu * 3 / 4) return Plan3T{tile, splits, 0};
+    }
+    return Plan3T{0, 1, 0};
+}
+
+// wp[phase][(tap, ko)][ldc] = w[ko][c][kd][ky][kx] over the phase's own nd x ny x nx taps (tap = (td * ny + ty) * nx +
+// tx, k* = ((p* + P) % S) + S * t*), ko padded to a multiple of BK with zero rows; the unused tail of a phase's
+// fixed-size T^3 * kpad-row region is never read
+__global__ __launch_bounds__(256) void pack_dgrad3_tap_kernel(const float* __restrict__ w, float* __restrict__ wp, int K,
+                                                              int C, int KS, int S, int P, int T, int kpad, int ldc) {
+    const int phase = blockIdx.y;
+    const int pd = phase / (S * S), py = (phase / S) % S, px = phase % S;
+    const int rd = (pd + P) % S, ry = (py + P) % S, rx = (px + P) % S;
+    const int nd = dg_taps(KS, S, P, pd), ny = dg_taps(KS, S, P, py), nx = dg_taps(KS, S, P, px);
+    float* dst = wp + (long long)phase * T * T * T * kpad * ldc;
+    const long long total = (long long)nd * ny * nx * kpad * ldc;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % ldc);
+        const long long row = i / ldc;
+        const int ko = (int)(row % kpad), tap = (int)(row / kpad);
+        const int kd = rd + S * (tap / (ny * nx)), ky = ry + S * ((tap / nx) % ny), kx = rx + S * (tap % nx);
+        dst[i] = (ko < K && c < C) ? w[((((long long)ko * C + c) * KS + kd) * KS + ky) * KS + kx] : 0.f;
+    }
+}
+
+template <class Cfg, int KS, int S, int P>
+static int run_dgradtap3(const float* y, const float* wp, const float* bias, float* x, const Conv3DShape& s, int act,
+                         float slope, hipStream_t st, int splits, float* slab) {
+    using AL = Conv3DDgTapA2<Cfg::BM, KS, S, P>;
+    using BL = MContigB2<Cfg::BN>;
+    using Epi = EpiPhase3D<S>;
+    const int AD = s.D / S, AH = s.H / S, AW = s.W / S;
+    typename AL::Params pa{y, s, AD, AH, AW, make_fastdiv(AD * AH * AW), make_fastdiv(AH * AW), make_fastdiv(AW)};
+    const int kpad = round_bk(s.K), Kt = AL::T * AL::T * AL::T * kpad, ldc = r4(s.C);
+    typename BL::Params pb{wp, Kt, ldc, ldc, (long long)Kt * ldc};
+    const int M = s.N * AD * AH * AW;
+    typename Epi::Params pe{x, M, s.C, s.D, s.H, s.W, AD, AH, AW, make_fastdiv(AD * AH * AW), make_fastdiv(AH * AW),
+                            make_fastdiv(AW), bias, act, slope};
+    int pc[8];
+    for (int ph = 0; ph < S * S * S; ++ph)
+        pc[ph] = dg_taps(KS, S, P, ph / (S * S)) * dg_taps(KS, S, P, (ph / S) % S) * dg_taps(KS, S, P, ph % S) * (kpad / BK);
+    return launch_igemm2<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kt, S * S * S, splits, st, slab, pc);
+}
+
+template <class Cfg, int KS, int S, int P>
+static int run_fwdtap3(const float* x, const float* wp, const float* bias, float* y, const Conv3DShape& s, int act,
+                       float slope, hipStream_t st, int splits, float* slab) {
+    using AL = Conv3DTapA2<Cfg::BM, KS, S, P>;
+    using BL = MContigB2<Cfg::BN>;
+    const int osp = s.OD * s.OH * s.OW;
+    typename AL::Params pa{x, s, make_fastdiv(osp), make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW)};
+    const int M = s.N * osp, Kt = KS * KS * KS * round_bk(s.C);
+    EpiNCHWB::Params pe{y, M, s.K, osp, make_fastdiv(osp), bias, act, slope};
+    typename BL::Params pb{wp, Kt, r4(s.K), r4(s.K), 0};
+    return launch_igemm2<Cfg, AL, BL, EpiNCHWB>(pa, pb, pe, M, s.K, Kt, 1, splits, st, slab);
+}
+
 }  // namespace gz
 
 using namespace gz;
@@ -255,7 +373,7 @@ long long gz_conv3d_pack_fwd_elems(int K, int C, int KS) {
 
 long long gz_conv3d_pack_dgrad_elems(int K, int C, int KS, int S) {
     int T = (KS + S - 1) / S;
-    return (long long)S * S * S * K * T * T * T * r4(C);
+    return (long long)S * S * S * (dg3_tap2(K, C) ? round_bk(K) : K) * T * T * T * r4(C);
 }
 
 int gz_conv3d_pack_fwd(const float* w, float* wp, int K, int C, int KS, hipStream_t stream) {
@@ -277,6 +395,13 @@ int gz_conv3d_pack_dgrad(const float* w, float* wp, int K, int C, int KS, int S,
     gz::clear_stale_error();
     if (K <= 0 || C <= 0 || KS <= 0 || S <= 0) return GZ_ERR_BAD_SHAPE;
     int T = (KS + S - 1) / S;
+    if (dg3_tap2(K, C)) {
+        const long long total = (long long)T * T * T * round_bk(K) * r4(C);
+        const unsigned bx = (unsigned)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+        hipLaunchKernelGGL(pack_dgrad3_tap_kernel, dim3(bx, S * S * S), dim3(256), 0, stream, w, wp, K, C, KS, S, P, T,
+                           round_bk(K), r4(C));
+        return launch_status();
+    }
     hipLaunchKernelGGL(pack_dgrad3_kernel, dim3(K, S * S * S), dim3(256), 0, stream, w, wp, K, C, KS, S, P, T, r4(C));
     return launch_status();
 }
@@ -284,11 +409,15 @@ int gz_conv3d_pack_dgrad(const float* w, float* wp, int K, int C, int KS, int S,
 size_t gz_conv3d_fwd_workspace_bytes(int N, int C, int K, int OD, int OH, int OW, int KS) {
     long long M = (long long)N * OD * OH * OW;
     int Kg = (fwd3_tap_major(C) ? round_bk(C) : C) * KS * KS * KS;
+    const Plan3T p2 = plan3_fwdtap2(M, K, C, KS);
+    if (p2.tile) return bytes3(p2.splits, M, K, Kg, 1);
     return bytes3(plan3(pick3(M, K, 1), M, K, Kg, 1), M, K, Kg, 1);
 }
 
 size_t gz_conv3d_dgrad_workspace_bytes(int N, int C, int K, int OD, int OH, int OW, int KS) {
     long long M = (long long)N * OD * OH * OW;      // per phase: the S = 2 output grid has OD*OH*OW cells per phase
+    const Plan3T p2 = plan3_dgtap2(M, C, K, KS, 2, 1);
+    if (p2.tile) return p2.splits > 1 ? (size_t)p2.slabs * M * C * 4 : 0;
     DgPlan3 pl = plan3_dg(pick3(M, C, 8), M, C, K, KS, 2, 1);
     return pl.splits > 1 ? (size_t)pl.slabs * M * C * 4 : 0;
 }
@@ -302,8 +431,16 @@ int gz_conv3d_fwd(const float* x, const float* wpack, const float* bias, float* 
     if (!shape3_ok(s, KS, S, P)) return GZ_ERR_BAD_SHAPE;
     if (big3((long long)N * C * D * H * W) || big3((long long)N * K * OD * OH * OW)) return GZ_ERR_TOO_LARGE;
     if (((uintptr_t)wpack & 15) || ((uintptr_t)y & 15)) return GZ_ERR_BAD_SHAPE;
-    int t = pick3((long long)N * OD * OH * OW, K, 1);
     const int kdim = (fwd3_tap_major(C) ? round_bk(C) : C) * 27;
+    const Plan3T p2 = plan3_fwdtap2((long long)N * OD * OH * OW, K, C, KS);
+    if (p2.tile && !((uintptr_t)x & 3)) {
+        int sp = p2.splits;
+        if (sp > 1 && (!workspace || ws_bytes < bytes3(sp, (long long)N * OD * OH * OW, K, kdim, 1))) return GZ_ERR_WORKSPACE;
+        float* sl = sp > 1 ? workspace : nullptr;
+        return p2.tile == 1 ? run_fwdtap3<C3_256x128, 3, 2, 1>(x, wpack, bias, y, s, act, slope, stream, sp, sl)
+                            : run_fwdtap3<C3_256x64, 3, 2, 1>(x, wpack, bias, y, s, act, slope, stream, sp, sl);
+    }
+    int t = pick3((long long)N * OD * OH * OW, K, 1);
     int splits = plan3(t, (long long)N * OD * OH * OW, K, kdim, 1);
     if (splits > 1 && (!workspace || ws_bytes < bytes3(splits, (long long)N * OD * OH * OW, K, kdim, 1))) splits = 1;
     float* slab = splits > 1 ? workspace : nullptr;
@@ -322,6 +459,14 @@ int gz_conv3d_dgrad(const float* y, const float* wpack, const float* bias, float
     if (big3((long long)N * C * D * H * W) || big3((long long)N * K * OD * OH * OW)) return GZ_ERR_TOO_LARGE;
     if ((uintptr_t)wpack & 15) return GZ_ERR_BAD_SHAPE;
     const long long Mp = (long long)N * (D / S) * (H / S) * (W / S);
+    if (dg3_tap2(K, C)) {       // (the packed image is tap-major: this path or none)
+        const Plan3T p2 = plan3_dgtap2(Mp, C, K, KS, S, P);
+        if (!p2.tile) return GZ_ERR_UNSUPPORTED;
+        if (p2.splits > 1 && (!workspace || ws_bytes < (size_t)p2.slabs * Mp * C * 4)) return GZ_ERR_WORKSPACE;
+        float* sl = p2.splits > 1 ? workspace : nullptr;
+        return p2.tile == 1 ? run_dgradtap3<C3_256x128, 3, 2, 1>(y, wpack, bias, x, s, act, slope, stream, p2.splits, sl)
+                            : run_dgradtap3<C3_256x64, 3, 2, 1>(y, wpack, bias, x, s, act, slope, stream, p2.splits, sl);
+    }
     int t = pick3(Mp, C, S * S * S);
     DgPlan3 pl = plan3_dg(t, Mp, C, K, KS, S, P);
     int splits = pl.splits;

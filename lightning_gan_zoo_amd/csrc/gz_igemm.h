@@ -1673,13 +1673,14 @@ struct EpiNCHWB {
     template <int TM, int TN>
     __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
                                                  int n_base, int lane, int y, int z) {
-        const bool fast = !p.bias && p.act == ACT_NONE && n_base + TN * 32 <= p.CH;       // wave-uniform
+        const bool fast = n_base + TN * 32 <= p.CH;       // wave-uniform
         if (!fast) {
             EpiNCHW::template store<TM, TN>(p, acc, m_base, n_base, lane, y, z);
             return;
         }
         const int col_l = lane & 31, half = lane >> 5;
         if (p.stats) tile_channel_stats<TM, TN>(acc, p.stats, m_base / (TM * 32), p.CH, n_base, lane);
+        const bool plain = !p.bias && p.act == ACT_NONE;
         const uint32_t chs = (uint32_t)p.HW * 4u;
         __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.out, (uint32_t)(p.M / p.HW) * (uint32_t)p.CH * chs);
         uint32_t voff[TM];
@@ -1695,10 +1696,13 @@ struct EpiNCHWB {
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const uint32_t so = soff + (uint32_t)(j * 32 + (r & 3) + 8 * (r >> 2)) * chs;
+                const int cl = j * 32 + (r & 3) + 8 * (r >> 2);
+                const uint32_t so = soff + (uint32_t)cl * chs;
+                const float bv = (!plain && p.bias) ? p.bias[n_base + cl + 4 * half] : 0.f;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const float v = acc[i][j][r];
+                    float v = acc[i][j][r];
+                    if (!plain) v = act_fwd(v + bv, p.act, p.slope);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, voff[i], so, 0);
                 }
             }
@@ -1719,7 +1723,7 @@ struct EpiPhaseB {
     template <int TM, int TN>
     __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
                                                  int n_base, int lane, int y, int z) {
-        const bool fast = !p.bias && p.act == ACT_NONE && n_base + TN * 32 <= p.C;       // wave-uniform
+        const bool fast = n_base + TN * 32 <= p.C;       // wave-uniform
         if (!fast) {
             EpiPhase<S>::template store<TM, TN>(p, acc, m_base, n_base, lane, y, z);
             return;
@@ -1727,6 +1731,7 @@ struct EpiPhaseB {
         const int col_l = lane & 31, half = lane >> 5;
         if (p.stats)
             tile_channel_stats<TM, TN>(acc, p.stats, (long long)y * p.stats_rows + m_base / (TM * 32), p.C, n_base, lane);
+        const bool plain = !p.bias && p.act == ACT_NONE;      // (bias + activation: round 4, HoloGAN's generator layers)
         const int py = y / S, px = y % S;
         const uint32_t chs = (uint32_t)(p.H * p.W) * 4u;                 // bytes between channel planes
         __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.out, (uint32_t)(p.M / (p.AH * p.AW)) * (uint32_t)p.C * chs);
@@ -1746,10 +1751,13 @@ struct EpiPhaseB {
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const uint32_t so = soff + (uint32_t)(j * 32 + (r & 3) + 8 * (r >> 2)) * chs;
+                const int cl = j * 32 + (r & 3) + 8 * (r >> 2);
+                const uint32_t so = soff + (uint32_t)cl * chs;
+                const float bv = (!plain && p.bias) ? p.bias[n_base + cl + 4 * half] : 0.f;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const float v = acc[i][j][r];      // (bit_cast of the vector-element expression itself reads element 0)
+                    float v = acc[i][j][r];            // (bit_cast of the vector-element expression itself reads element 0)
+                    if (!plain) v = act_fwd(v + bv, p.act, p.slope);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, voff[i], so, 0);
                 }
             }
@@ -2484,6 +2492,150 @@ struct ConvDgTapA2 {
         const int ko = kob + row;
         bload_lds4(rsrc, stage + row * LD + g * 64, veff[g],
                    (live && ko < K) ? (uint32_t)ko * (uint32_t)OHW * 4u + tap_soff : SOFF_OOB);
+    }
+};
+
+// The two gathers in three dimensions (HoloGAN's ConvTranspose3d k3 s2 p1 op1, core/models/hologan_generator.py:29-30:
+// its forward is the transposed form with 8 phases of 1..8 taps, its input gradient the plain strided convolution).
+// Tap-major: chunk = 16 channels at one tap; the weight rows follow pack_fwd3_tap / pack_dgrad3_tap (gz_conv3d.hip).
+template <int BM, int KS, int S, int P>
+struct Conv3DTapA2 {
+    using Params = typename Conv3DFwdALoader<BM, KS, S, P>::Params;
+    static constexpr int LD = BM, ROWS = BK;
+    static constexpr int G = BM / 64;
+    static constexpr int PIECES = BK * G / 4;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t vbase[G], veff[G];
+    int id0[G], iy0[G], ix0[G];
+    int wave, C, D, H, W, DHW, cblocks, last_tap, last_kc, cb;
+    uint32_t tap_soff;
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        const Conv3DShape& s = p.s;
+        const uint32_t shift = (uint32_t)((P * s.H + P) * s.W + P) * 4u;
+        rsrc = make_rsrc(reinterpret_cast<const char*>(p.x) - shift,
+                         (uint32_t)s.N * s.C * s.D * s.H * s.W * 4u + shift);
+        const int lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        C = s.C; D = s.D; H = s.H; W = s.W; DHW = s.D * s.H * s.W;
+        cblocks = round_bk(s.C) / BK;
+        last_tap = -1; last_kc = -1; cb = 0; tap_soff = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint32_t m = (uint32_t)tile * BM + g * 64 + lane;
+            const bool m_ok = m < (uint32_t)s.N * s.OD * s.OH * s.OW;
+            const uint32_t n = fdiv(m, p.div_odhw);
+            uint32_t v = m - n * (uint32_t)(s.OD * s.OH * s.OW);
+            const uint32_t od = fdiv(v, p.div_ohw);
+            v -= od * (uint32_t)(s.OH * s.OW);
+            const uint32_t oy = fdiv(v, p.div_ow);
+            const uint32_t ox = v - oy * (uint32_t)s.OW;
+            id0[g] = m_ok ? (int)od * S - P : -(1 << 20);      // rows past M: every tap out of range
+            iy0[g] = (int)oy * S - P;
+            ix0[g] = (int)ox * S - P;
+            vbase[g] = (n * (uint32_t)(s.C * DHW) +
+                        (uint32_t)((((int)od * S) * H + (iy0[g] + P)) * W + (ix0[g] + P))) * 4u;   // shifted base
+            veff[g] = OOB;
+        }
+    }
+    __device__ __forceinline__ void issue_piece(int kc, float* stage, int p, bool live) {
+        if (p == 0) {
+            int tap = last_tap;
+            if (kc == last_kc + 1 && last_kc >= 0) {
+                cb += BK;
+                if (cb >= cblocks * BK) { cb = 0; ++tap; }
+            } else {
+                tap = kc / cblocks;
+                cb = (kc - tap * cblocks) * BK;
+            }
+            last_kc = kc;
+            if (tap != last_tap) {
+                last_tap = tap;
+                const int kd = tap / (KS * KS), r = tap - kd * (KS * KS), ky = r / KS, kx = r - ky * KS;
+                tap_soff = (uint32_t)((kd * H + ky) * W + kx) * 4u;
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    veff[g] = ((unsigned)(id0[g] + kd) < (unsigned)D && (unsigned)(iy0[g] + ky) < (unsigned)H &&
+                               (unsigned)(ix0[g] + kx) < (unsigned)W) ? vbase[g] : OOB;
+            }
+        }
+        const int row = wave * 4 + p / G, g = p % G;
+        const int c = cb + row;
+        bload_lds4(rsrc, stage + row * LD + g * 64, veff[g],
+                   (live && c < C) ? (uint32_t)c * (uint32_t)DHW * 4u + tap_soff : SOFF_OOB);
+    }
+};
+
+// A[k = (tap, ko)][m = (n, a, b, c)] = y[n][ko][od0 - td][oy0 - ty][ox0 - tx] of phase (pd, py, px); a phase has its own
+// nd x ny x nx taps (tap = (td * ny + ty) * nx + tx) and chunk count.
+template <int BM, int KS, int S, int P>
+struct Conv3DDgTapA2 {
+    static constexpr int T = (KS + S - 1) / S;
+    using Params = typename Conv3DDgALoader<BM, KS, S, P>::Params;
+    static constexpr int LD = BM, ROWS = BK;
+    static constexpr int G = BM / 64;
+    static constexpr int PIECES = BK * G / 4;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t vbase[G], veff[G];
+    int od0[G], oy0[G], ox0[G];
+    int wave, K, OD, OH, OW, OSP, kblocks, ny_p, nx_p, last_tap, last_kc, kob;
+    uint32_t tap_soff;
+    __device__ __forceinline__ void init(const Params& p, int tile, int phase, int tid) {
+        const Conv3DShape& s = p.s;
+        const uint32_t shift = (uint32_t)(((T - 1) * s.OH + (T - 1)) * s.OW + (T - 1)) * 4u;
+        rsrc = make_rsrc(reinterpret_cast<const char*>(p.y) - shift,
+                         (uint32_t)s.N * s.K * s.OD * s.OH * s.OW * 4u + shift);
+        const int lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int pd = phase / (S * S), py = (phase / S) % S, px = phase % S;
+        ny_p = dg_taps(KS, S, P, py);
+        nx_p = dg_taps(KS, S, P, px);
+        K = s.K; OD = s.OD; OH = s.OH; OW = s.OW; OSP = s.OD * s.OH * s.OW;
+        kblocks = round_bk(s.K) / BK;
+        last_tap = -1; last_kc = -1; kob = 0; tap_soff = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint32_t m = (uint32_t)tile * BM + g * 64 + lane;
+            const bool m_ok = m < (uint32_t)s.N * p.AD * p.AH * p.AW;
+            const uint32_t n = fdiv(m, p.div_adhw);
+            uint32_t v = m - n * (uint32_t)(p.AD * p.AH * p.AW);
+            const uint32_t a = fdiv(v, p.div_ahw);
+            v -= a * (uint32_t)(p.AH * p.AW);
+            const uint32_t b = fdiv(v, p.div_aw);
+            const uint32_t c = v - b * (uint32_t)p.AW;
+            const int od = (int)a + (pd + P) / S;
+            od0[g] = m_ok ? od : -(1 << 20);
+            oy0[g] = (int)b + (py + P) / S;
+            ox0[g] = (int)c + (px + P) / S;
+            // addresses (od - (T-1), oy0 - (T-1), ox0 - (T-1)) through the shifted base; the tap's scalar offset walks forward
+            vbase[g] = (n * (uint32_t)(s.K * OSP) + (uint32_t)((od * OH + oy0[g]) * OW + ox0[g])) * 4u;
+            veff[g] = OOB;
+        }
+    }
+    __device__ __forceinline__ void issue_piece(int kc, float* stage, int p, bool live) {
+        if (p == 0) {
+            int tap = last_tap;
+            if (kc == last_kc + 1 && last_kc >= 0) {
+                kob += BK;
+                if (kob >= kblocks * BK) { kob = 0; ++tap; }
+            } else {
+                tap = kc / kblocks;
+                kob = (kc - tap * kblocks) * BK;
+            }
+            last_kc = kc;
+            if (tap != last_tap) {
+                last_tap = tap;
+                const int td = tap / (ny_p * nx_p), r = tap - td * (ny_p * nx_p), ty = r / nx_p, tx = r - ty * nx_p;
+                tap_soff = (uint32_t)(((T - 1 - td) * OH + (T - 1 - ty)) * OW + (T - 1 - tx)) * 4u;
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    veff[g] = ((unsigned)(od0[g] - td) < (unsigned)OD && (unsigned)(oy0[g] - ty) < (unsigned)OH &&
+                               (unsigned)(ox0[g] - tx) < (unsigned)OW) ? vbase[g] : OOB;
+            }
+        }
+        const int row = wave * 4 + p / G, g = p % G;
+        const int ko = kob + row;
+        bload_lds4(rsrc, stage + row * LD + g * 64, veff[g],
+                   (live && ko < K) ? (uint32_t)ko * (uint32_t)OSP * 4u + tap_soff : SOFF_OOB);
     }
 };
 

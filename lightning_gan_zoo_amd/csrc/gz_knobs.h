@@ -16,6 +16,9 @@ namespace gz {
     /* tile / skeleton choice */                                                                                      \
     X(bool, no_igemm2, "GZ_NO_IGEMM2", false)               /* keep everything on igemm_kernel (round 2) */         \
     X(bool, no_igemm2_tap, "GZ_NO_IGEMM2_TAP", false)       /* ... the gather-loader launches only */               \
+    X(int, dg3_tile, "GZ_DG3_TILE", 0)                      /* ConvTranspose3d forward on igemm2: force 256x128 (1) / 256x64 (2) */ \
+    X(int, dg3_wgs, "GZ_DG3_WGS", 2)                        /* ... split launches aim at this many workgroups per CU */ \
+    X(int, dg3_min_chunks, "GZ_DG3_MIN_CHUNKS", 32)         /* ... of at least this many chunks */                   \
     X(bool, no_igemm2_wg, "GZ_NO_IGEMM2_WG", false)         /* ... the weight gradients only */                     \
     X(bool, no_igemm2w, "GZ_NO_IGEMM2W", false)             /* register-staged instead of LDS-DMA weight gradient */ \
     X(bool, no_igemm2wg, "GZ_NO_IGEMM2WG", false)           /* ... its generic-geometry image only */               \

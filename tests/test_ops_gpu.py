@@ -293,7 +293,10 @@ def test_gp_tail_ops():
 @pytest.mark.parametrize("case", [(2, 8, 4, 4), (3, 20, 4, 12), (4, 64, 8, 16), (2, 128, 4, 130),
                                   (8, 512, 4, 128),       # few output tiles -> split-K forward and dgrad
                                   (8, 128, 8, 64),        # HoloGAN block2 at bs 8: phases split with 8-chunk slabs
-                                  (64, 512, 4, 128)])     # HoloGAN block1 at the benched bs 64: 27 slabs over 8 phases
+                                  (64, 512, 4, 128),      # HoloGAN block1 at the benched bs 64: 27 slabs over 8 phases
+                                  (3, 64, 4, 64),         # igemm2 gathers with fewer rows than one 256-row tile
+                                  (2, 192, 4, 192),       # ... 192 columns: three 64-wide tiles, ragged 16-channel blocks
+                                  (5, 72, 8, 64)])        # ... 72 input channels: the last channel block is half empty
 def test_conv3d_family(case):
     """ConvTranspose3d(k3,s2,p1,op1) forward (Dg), its input gradient (F) and weight gradient (Wg)."""
     F = _F()
