@@ -532,6 +532,13 @@ static int run_fwdtap2(const float* x, const float* wp, const float* bias, float
     const int Kt = G::kh * G::kw * round_bk(s.C);
     // (1x1: the plain [C][K] weight image IS the tap-major one; it has no padding rows, the descriptor ends at row C)
     typename BL::Params pb{wp, G::kh * G::kw == 1 ? s.C : Kt, round4(s.K), round4(s.K), 0};
+    if constexpr (G::kh * G::kw == 1 && G::s == 1 && G::p == 0) {
+        if (!knobs().no_plane_a && ((s.H * s.W) & 3) == 0 && !((uintptr_t)x & 15)) {      // plain GEMM: 16-byte pieces
+            using AP = PlaneA2<Cfg::BM>;
+            typename AP::Params pp{x, s.C, s.H * s.W, M, make_fastdiv(s.H * s.W)};
+            return launch_igemm2<Cfg, AP, BL, EpiNCHWB>(pp, pb, pe, M, s.K, Kt, 1, splits, st, slab);
+        }
+    }
     return launch_igemm2<Cfg, AL, BL, EpiNCHWB>(pa, pb, pe, M, s.K, Kt, 1, splits, st, slab);
 }
 
@@ -1048,6 +1055,13 @@ static int run_dgradtap2(const float* y, const float* wp, const float* bias, flo
     int pc[8];
     for (int ph = 0; ph < G::s * G::s; ++ph)
         pc[ph] = dg_taps(G::kh, G::s, G::p, ph / G::s) * dg_taps(G::kw, G::s, G::p, ph % G::s) * (kpad / BK);
+    if constexpr (G::kh * G::kw == 1 && G::s == 1 && G::p == 0) {
+        if (!knobs().no_plane_a && ((s.OH * s.OW) & 3) == 0 && !((uintptr_t)y & 15)) {
+            using AP = PlaneA2<Cfg::BM>;
+            typename AP::Params pp{y, s.K, s.OH * s.OW, M, make_fastdiv(s.OH * s.OW)};
+            return launch_igemm2<Cfg, AP, BL, Epi>(pp, pb, pe, M, s.C, Kt, 1, splits, st, slab, pc);
+        }
+    }
     return launch_igemm2<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kt, G::s * G::s, splits, st, slab, pc);
 }
 
@@ -1290,6 +1304,93 @@ __global__ __launch_bounds__(256) void conv3x3_smallch_kernel(const float* __res
     }
 }
 
+// ... with at most 4 output channels on 64-pixel-wide maps (HoloGAN's last layer, 64 -> 3 + tanh): the MFMA tile above
+// multiplies 13 padding rows of 16 (81 us for one read of a 67 MB activation).  Plain FMAs: a workgroup owns an
+// 8-row x 64-pixel block of one sample, lane = (row, 8-pixel segment) as in wgrad_k3_fewk_kernel; its four wavefronts
+// take a quarter of the input channels each and meet in LDS in a fixed order.  Same weight images, `flip` as above.
+template <int KK>
+__global__ __launch_bounds__(256) void conv3x3_fewk_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int N,
+                                                           int CI, int CO, int H, int tap_major, int inpad, int ld,
+                                                           int flip, int act, float slope) {
+    __shared__ float Ws[64 * 9 * KK];                // [ci][tap][k]
+    __shared__ float red[3][KK * 8][64];
+    for (int e = threadIdx.x; e < CI * 9 * KK; e += 256) {
+        const int k = e % KK, tap = (e / KK) % 9, ci = e / (9 * KK);
+        const int t = flip ? 8 - tap : tap;
+        Ws[e] = k < CO ? wp[(long long)(tap_major ? t * inpad + ci : ci * 9 + t) * ld + k] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rbs = H >> 3, HW = H * 64;
+    const int n = blockIdx.x / rbs, rb = blockIdx.x - n * rbs;
+    const int r = lane >> 3, sg = lane & 7, h = rb * 8 + r, w0 = sg * 8;
+    const int cq = (CI + 3) >> 2, c0 = wave * cq, c1 = min(CI, c0 + cq);
+    float acc[KK][8];
+#pragma unroll
+    for (int k = 0; k < KK; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+    const float* xn = in + (long long)n * CI * HW + w0;
+#pragma unroll 2
+    for (int ci = c0; ci < c1; ++ci) {
+        const float* xc = xn + (long long)ci * HW;
+        float xr[3][10];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int hh = h + d - 1;
+            const bool ok = (unsigned)hh < (unsigned)H;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 v0 = ok ? *reinterpret_cast<const f32x4*>(xc + hh * 64) : z;
+            const f32x4 v1 = ok ? *reinterpret_cast<const f32x4*>(xc + hh * 64 + 4) : z;
+            const float left = __shfl_up(v1[3], 1, 64), right = __shfl_down(v0[0], 1, 64);
+            xr[d][0] = sg == 0 ? 0.f : left;
+            xr[d][1] = v0[0]; xr[d][2] = v0[1]; xr[d][3] = v0[2]; xr[d][4] = v0[3];
+            xr[d][5] = v1[0]; xr[d][6] = v1[1]; xr[d][7] = v1[2]; xr[d][8] = v1[3];
+            xr[d][9] = sg == 7 ? 0.f : right;
+        }
+        const float* wc = Ws + ci * 9 * KK;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                for (int k = 0; k < KK; ++k) {
+                    const float wv = wc[(d * 3 + tx) * KK + k];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[k][j] = fmaf(wv, xr[d][j + tx], acc[k][j]);
+                }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int k = 0; k < KK; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[wave - 1][k * 8 + j][lane] = acc[k][j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            if (k >= CO) continue;
+            const float bv = bias ? bias[k] : 0.f;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = ((acc[k][j] + red[0][k * 8 + j][lane]) + red[1][k * 8 + j][lane]) + red[2][k * 8 + j][lane];
+                o[j] = act_fwd(v + bv, act, slope);
+            }
+            float* dst = out + ((long long)(n * CO + k) * H + h) * 64 + w0;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        }
+    }
+}
+
+static bool conv3_fewk_ok(int CI, int CO, int H, int W, const void* in, const void* out) {
+    return !knobs().no_fewk_conv && CO <= 4 && CI <= 64 && W == 64 && (H & 7) == 0 &&
+           !(((uintptr_t)in | (uintptr_t)out) & 15);
+}
+
 static bool conv3_smallch_ok(int N, int CI, int CO, int H, int W) {
     const bool off = knobs().no_smallch_conv;
     // measured against the implicit-GEMM path (tools/resnet_bench.py): wins when the output side fits one 16-row
@@ -1300,6 +1401,18 @@ static bool conv3_smallch_ok(int N, int CI, int CO, int H, int W) {
 
 static int run_conv3_smallch(const float* in, const float* wp, const float* bias, float* out, int N, int CI, int CO,
                              int H, int W, int tap_major, int flip, int act, float slope, hipStream_t st) {
+    if (conv3_fewk_ok(CI, CO, H, W, in, out)) {
+        const dim3 grid((unsigned)(N * (H >> 3)));
+#define GZ_FEWK(KK_)                                                                                                  \
+    hipLaunchKernelGGL((conv3x3_fewk_kernel<KK_>), grid, dim3(256), 0, st, in, wp, bias, out, N, CI, CO, H, tap_major, \
+                       round_bk(CI), round4(CO), flip, act, slope)
+        if (CO == 1) GZ_FEWK(1);
+        else if (CO == 2) GZ_FEWK(2);
+        else if (CO == 3) GZ_FEWK(3);
+        else GZ_FEWK(4);
+#undef GZ_FEWK
+        return launch_status();
+    }
     const int groups = N * H * (W >> 4);
     const int gpw = knobs().c3_gpw;
     long long blocks = (groups + 4 * gpw - 1) / (4 * gpw);   // >= gpw pixel groups per wavefront: the weights are staged per workgroup
@@ -1436,6 +1549,105 @@ __global__ __launch_bounds__(256) void wgrad_smallch_k3_kernel(const float* __re
     }
 }
 
+// ---------------------------------------------------------------------------
+// ... and with at most 4 OUTPUT channels on 64-pixel-wide maps (HoloGAN's last layer, Conv2d(64, 3, k3, p1) at 64x64,
+// core/models/hologan_generator.py:65): the 16x16x4 MFMA above multiplies 13 padding rows out of 16 and ran at
+// 6 TFLOP/s (150 us for 0.9 GFLOP; the layer is one read of a 67 MB activation).  Plain FMAs instead: a wavefront owns
+// one input channel and an 8-row x 64-pixel block -- lane = (row, 8-pixel segment) -- keeps the 9 * K sums of its
+// channel in registers while it walks the samples of its slice, and adds the 64 lanes once at the end.  The image rows
+// come as aligned float4 loads, the two halo pixels of a segment from the neighbouring lanes.  One slab row per
+// (row block, sample slice); reduce_slabs_kernel adds them (and the bias gradient in the row's tail).
+// ---------------------------------------------------------------------------
+template <int KK>
+__global__ __launch_bounds__(256) void wgrad_k3_fewk_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            float* __restrict__ slab, ConvShape s, int nslices,
+                                                            int n_per_slice) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int H = s.H, HW = s.H * 64, rbs = s.H >> 3;
+    int b = blockIdx.x;
+    const int ns = b % nslices;
+    b /= nslices;
+    const int rb = b % rbs, c = (b / rbs) * 4 + wave;
+    if (c >= s.C) return;                                     // (wave-uniform)
+    const int r = lane >> 3, sg = lane & 7, h = rb * 8 + r, w0 = sg * 8;
+    float acc[KK][9], ysum[KK];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+        ysum[k] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[k][t] = 0.f;
+    }
+    const int n0 = ns * n_per_slice, n1 = min(s.N, n0 + n_per_slice);
+    for (int n = n0; n < n1; ++n) {
+        const float* xc = x + ((long long)n * s.C + c) * HW + w0;
+        const float* yn = y + (long long)n * s.K * HW + h * 64 + w0;
+        float xr[3][10];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int hh = h + d - 1;
+            const bool ok = (unsigned)hh < (unsigned)H;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 v0 = ok ? *reinterpret_cast<const f32x4*>(xc + hh * 64) : z;
+            const f32x4 v1 = ok ? *reinterpret_cast<const f32x4*>(xc + hh * 64 + 4) : z;
+            const float left = __shfl_up(v1[3], 1, 64), right = __shfl_down(v0[0], 1, 64);
+            xr[d][0] = sg == 0 ? 0.f : left;
+            xr[d][1] = v0[0]; xr[d][2] = v0[1]; xr[d][3] = v0[2]; xr[d][4] = v0[3];
+            xr[d][5] = v1[0]; xr[d][6] = v1[1]; xr[d][7] = v1[2]; xr[d][8] = v1[3];
+            xr[d][9] = sg == 7 ? 0.f : right;
+        }
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            float yv[8];
+            if (k < s.K) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(yn + (long long)k * HW);
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(yn + (long long)k * HW + 4);
+                yv[0] = a[0]; yv[1] = a[1]; yv[2] = a[2]; yv[3] = a[3];
+                yv[4] = bq[0]; yv[5] = bq[1]; yv[6] = bq[2]; yv[7] = bq[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) yv[j] = 0.f;
+            }
+            if (c == 0) ysum[k] += ((yv[0] + yv[1]) + (yv[2] + yv[3])) + ((yv[4] + yv[5]) + (yv[6] + yv[7]));
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) {
+                    float a = acc[k][d * 3 + tx];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a = fmaf(yv[j], xr[d][j + tx], a);
+                    acc[k][d * 3 + tx] = a;
+                }
+        }
+    }
+    const long long count = (long long)s.K * s.C * 9;
+    float* out = slab + (long long)(rb * nslices + ns) * (count + s.K);
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float v = wave_sum(acc[k][t]);
+            if (lane == 0 && k < s.K) out[((long long)k * s.C + c) * 9 + t] = v;
+        }
+        if (c == 0) {
+            const float v = wave_sum(ysum[k]);
+            if (lane == 0 && k < s.K) out[count + k] = v;
+        }
+    }
+}
+
+static bool wgrad_fewk_ok(const ConvShape& s) {
+    return !knobs().no_fewk_wg && s.K <= 4 && s.W == 64 && (s.H & 7) == 0 && s.OH == s.H && s.OW == s.W;
+}
+
+static int wgrad_fewk_slices(const ConvShape& s) {       // sample slices: ~4 workgroups per CU in all
+    const long long base = (long long)((s.C + 3) / 4) * (s.H >> 3);
+    long long want = (4LL * cus() + base - 1) / base;
+    if (want > s.N) want = s.N;
+    if (want < 1) want = 1;
+    const int per = (int)((s.N + want - 1) / want);
+    return (s.N + per - 1) / per;
+}
+
 static bool wgrad_smallch_ok(const ConvShape& s, int KH, int KW, int S, int P) {
     const bool off = knobs().no_smallch_wg;
     const int kt = (s.K + 15) / 16, ct = (s.C + 15) / 16;      // 16x16 tiles per tap: at most 4 (36 accumulators)
@@ -1444,6 +1656,7 @@ static bool wgrad_smallch_ok(const ConvShape& s, int KH, int KW, int S, int P) {
 }
 
 static int wgrad_smallch_blocks(const ConvShape& s) {
+    if (wgrad_fewk_ok(s)) return (s.H >> 3) * wgrad_fewk_slices(s);       // slab rows
     long long groups = (long long)s.N * s.H * (s.W >> 4);
     long long blocks = (groups + 15) / 16;          // >= 4 pixel groups per wavefront
     return (int)(blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks));
@@ -1454,6 +1667,21 @@ static int run_wgrad_smallch(const float* x, const float* y, float* dw, float* d
     const int blocks = wgrad_smallch_blocks(s);
     const long long count = (long long)s.K * s.C * 9;
     if (!ws || ws_bytes < (size_t)blocks * (count + s.K) * 4) return GZ_ERR_WORKSPACE;
+    const long long row = count + s.K;
+    const long long outs = dbias ? row : count;
+    if (wgrad_fewk_ok(s)) {
+        const int nsl = wgrad_fewk_slices(s), per = (s.N + nsl - 1) / nsl;
+        const dim3 grid((unsigned)(((s.C + 3) / 4) * (s.H >> 3) * nsl));
+        switch (s.K) {
+            case 1: hipLaunchKernelGGL((wgrad_k3_fewk_kernel<1>), grid, dim3(256), 0, st, x, y, ws, s, nsl, per); break;
+            case 2: hipLaunchKernelGGL((wgrad_k3_fewk_kernel<2>), grid, dim3(256), 0, st, x, y, ws, s, nsl, per); break;
+            case 3: hipLaunchKernelGGL((wgrad_k3_fewk_kernel<3>), grid, dim3(256), 0, st, x, y, ws, s, nsl, per); break;
+            default: hipLaunchKernelGGL((wgrad_k3_fewk_kernel<4>), grid, dim3(256), 0, st, x, y, ws, s, nsl, per);
+        }
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((outs + 63) / 64)), dim3(64 * RS_WAVES), 0, st, ws, dw, blocks,
+                           outs, row, dbias, count);
+        return launch_status();
+    }
     const int groups = s.N * s.H * (s.W >> 4);
     const FastDiv dseg = make_fastdiv(s.W >> 4), dh = make_fastdiv(s.H);
     const int kt = (s.K + 15) / 16, ct = (s.C + 15) / 16;
@@ -1467,8 +1695,6 @@ static int run_wgrad_smallch(const float* x, const float* y, float* dw, float* d
     else GZ_SMALLCH(4, 1);
 #undef GZ_SMALLCH
     // slab rows are count + K long; without a dbias pointer the K-long tails are simply not reduced
-    const long long row = count + s.K;
-    const long long outs = dbias ? row : count;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((outs + 63) / 64)), dim3(64 * RS_WAVES), 0, st, ws, dw, blocks,
                        outs, row, dbias, count);
     return launch_status();
@@ -2310,7 +2536,8 @@ static const char* tile_text(TileId t) {
 template <class G>
 static int describe_fwd(const ConvShape& s, char* b, size_t n) {
     if (G::kh == 3 && G::kw == 3 && G::s == 1 && G::p == 1 && conv3_smallch_ok(s.N, s.C, s.K, s.H, s.W))
-        return snprintf(b, n, "F direct conv3x3_smallch<mfma16x16x4>");
+        return snprintf(b, n, "F direct %s", (!knobs().no_fewk_conv && s.K <= 4 && s.C <= 64 && s.W == 64 && (s.H & 7) == 0)
+                                                 ? "conv3x3_fewk<fma>" : "conv3x3_smallch<mfma16x16x4>");
     const SplitPlan sp = fwd_plan<G>(s);
     const int rows = gz_conv2d_fwd_stats_rows(s.N, s.C, s.H, s.W, s.K, s.OH, s.OW, G::kh, G::kw, G::s, G::p);
     if (is_tile2(sp.tile)) {
@@ -2366,7 +2593,8 @@ static int describe_dgrad(const ConvShape& s, char* b, size_t n) {
 template <class G>
 static int describe_wgrad(const ConvShape& s, char* b, size_t n) {
     if (wgrad_smallch_ok(s, G::kh, G::kw, G::s, G::p))
-        return snprintf(b, n, "Wg direct wgrad_smallch_k3<mfma16x16x4> slabs=%d", wgrad_smallch_blocks(s));
+        return snprintf(b, n, "Wg direct %s slabs=%d", wgrad_fewk_ok(s) ? "wgrad_k3_fewk<fma>" : "wgrad_smallch_k3<mfma16x16x4>",
+                        wgrad_smallch_blocks(s));
     TileId t = (TileId)gz_conv2d_tile(2, s.N, s.C, s.H, s.W, s.K, s.OH, s.OW, G::kh, G::kw, G::s);
     const int chunks = (s.N * s.OH * s.OW + BK - 1) / BK;
     const int NTOT = s.C * G::kh * G::kw;

@@ -321,12 +321,22 @@ __global__ __launch_bounds__(256) void pack_dgrad3_tap_kernel(const float* __res
     }
 }
 
+__global__ __launch_bounds__(256) void act_inplace3_kernel(float* __restrict__ x, long long total4, int act, float slope) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+        f32x4 v = reinterpret_cast<f32x4*>(x)[i];
+        v[0] = act_fwd(v[0], act, slope); v[1] = act_fwd(v[1], act, slope);
+        v[2] = act_fwd(v[2], act, slope); v[3] = act_fwd(v[3], act, slope);
+        reinterpret_cast<f32x4*>(x)[i] = v;
+    }
+}
+
 template <class Cfg, int KS, int S, int P>
 static int run_dgradtap3(const float* y, const float* wp, const float* bias, float* x, const Conv3DShape& s, int act,
                          float slope, hipStream_t st, int splits, float* slab) {
     using AL = Conv3DDgTapA2<Cfg::BM, KS, S, P>;
     using BL = MContigB2<Cfg::BN>;
-    using Epi = EpiPhase3D<S>;
+    using Epi = EpiPhase3DB<S>;
     const int AD = s.D / S, AH = s.H / S, AW = s.W / S;
     typename AL::Params pa{y, s, AD, AH, AW, make_fastdiv(AD * AH * AW), make_fastdiv(AH * AW), make_fastdiv(AW)};
     const int kpad = round_bk(s.K), Kt = AL::T * AL::T * AL::T * kpad, ldc = r4(s.C);
@@ -337,7 +347,13 @@ static int run_dgradtap3(const float* y, const float* wp, const float* bias, flo
     int pc[8];
     for (int ph = 0; ph < S * S * S; ++ph)
         pc[ph] = dg_taps(KS, S, P, ph / (S * S)) * dg_taps(KS, S, P, (ph / S) % S) * dg_taps(KS, S, P, ph % S) * (kpad / BK);
-    return launch_igemm2<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kt, S * S * S, splits, st, slab, pc);
+    const int rc = launch_igemm2<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kt, S * S * S, splits, st, slab, pc);
+    if (rc != GZ_OK || act == ACT_NONE) return rc;
+    // (EpiPhase3DB adds the bias only; no shipped model puts an activation on a ConvTranspose3d)
+    const long long total4 = (long long)s.N * s.C * s.D * s.H * s.W / 4;       // D, H, W even: a multiple of 8 elements
+    hipLaunchKernelGGL(act_inplace3_kernel, dim3((unsigned)((total4 + 255) / 256 > 4096 ? 4096 : (total4 + 255) / 256)),
+                       dim3(256), 0, st, x, total4, act, slope);
+    return launch_status();
 }
 
 template <class Cfg, int KS, int S, int P>

@@ -1625,6 +1625,58 @@ struct EpiPhase3D {
     }
 };
 
+// EpiPhase3D with the lean store path of EpiPhaseB (below) for the igemm2 skeleton, and ONLY that path: a bias is added
+// on the way (the only epilogue HoloGAN's ConvTranspose3d layers have); the caller guarantees whole 32-channel blocks
+// (C a multiple of 64) and applies an activation, if any, afterwards (p.act is ignored).
+template <int S>
+struct EpiPhase3DB {
+    static constexpr bool SWAP = true;
+    using Params = typename EpiPhase3D<S>::Params;
+    template <int TM, int TN>
+    __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
+                                                 int n_base, int lane, int y, int z) {
+        const int col_l = lane & 31, half = lane >> 5;
+        const int pd = y / (S * S), py = (y / S) % S, px = y % S;
+        const uint32_t chs = (uint32_t)(p.D * p.H * p.W) * 4u;           // bytes between channel volumes
+        __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.out, (uint32_t)(p.M / (p.AD * p.AH * p.AW)) * (uint32_t)p.C * chs);
+        uint32_t voff[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m_base + i * 32 + col_l;
+            const uint32_t n = fdiv((uint32_t)m, p.div_adhw);
+            uint32_t v = (uint32_t)m - n * (uint32_t)(p.AD * p.AH * p.AW);
+            const uint32_t a = fdiv(v, p.div_ahw);
+            v -= a * (uint32_t)(p.AH * p.AW);
+            const uint32_t b = fdiv(v, p.div_aw);
+            const uint32_t c = v - b * (uint32_t)p.AW;
+            const uint32_t o = (((n * (uint32_t)p.C + 4u * half) * (uint32_t)p.D + (S * a + pd)) * (uint32_t)p.H + (S * b + py)) *
+                                   (uint32_t)p.W + (S * c + px);
+            voff[i] = m < p.M ? o * 4u : OOB;
+        }
+        const uint32_t soff = (uint32_t)n_base * chs;
+        // (n_base is wave-uniform; the two half-waves sit four channels apart.  Known cost: hipcc hoists the 32 bias loads
+        // and the accumulator reads above the first store, and the 256x128 instantiation ends up with ~190 bytes of
+        // scratch per lane in this epilogue -- without the bias it needs 51 VGPRs.  HoloGAN's block1 launch is split, so
+        // its epilogue runs in splitk_finish_kernel, where registers are not scarce.)
+        const float* bias = p.bias ? p.bias + n_base : nullptr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = j * 32 + (r & 3) + 8 * (r >> 2);
+                const uint32_t so = soff + (uint32_t)cl * chs;
+                const float b0 = bias ? bias[cl] : 0.f, b1 = bias ? bias[cl + 4] : 0.f;
+                const float bv = half ? b1 : b0;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float v = acc[i][j][r] + bv;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, voff[i], so, 0);
+                }
+            }
+        }
+    }
+};
+
 // EpiRowMajor with the lean store path (weight-gradient slabs of the igemm2 skeleton): no bias / activation and the
 // wavefront's rows inside the matrix -> buffer_store from the accumulator registers, column offset per lane, row
 // through the scalar offset.
@@ -1673,14 +1725,13 @@ struct EpiNCHWB {
     template <int TM, int TN>
     __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
                                                  int n_base, int lane, int y, int z) {
-        const bool fast = n_base + TN * 32 <= p.CH;       // wave-uniform
+        const bool fast = !p.bias && p.act == ACT_NONE && n_base + TN * 32 <= p.CH;       // wave-uniform
         if (!fast) {
             EpiNCHW::template store<TM, TN>(p, acc, m_base, n_base, lane, y, z);
             return;
         }
         const int col_l = lane & 31, half = lane >> 5;
         if (p.stats) tile_channel_stats<TM, TN>(acc, p.stats, m_base / (TM * 32), p.CH, n_base, lane);
-        const bool plain = !p.bias && p.act == ACT_NONE;
         const uint32_t chs = (uint32_t)p.HW * 4u;
         __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.out, (uint32_t)(p.M / p.HW) * (uint32_t)p.CH * chs);
         uint32_t voff[TM];
@@ -1696,13 +1747,10 @@ struct EpiNCHWB {
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int cl = j * 32 + (r & 3) + 8 * (r >> 2);
-                const uint32_t so = soff + (uint32_t)cl * chs;
-                const float bv = (!plain && p.bias) ? p.bias[n_base + cl + 4 * half] : 0.f;
+                const uint32_t so = soff + (uint32_t)(j * 32 + (r & 3) + 8 * (r >> 2)) * chs;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    float v = acc[i][j][r];
-                    if (!plain) v = act_fwd(v + bv, p.act, p.slope);
+                    const float v = acc[i][j][r];
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, voff[i], so, 0);
                 }
             }
@@ -1723,7 +1771,7 @@ struct EpiPhaseB {
     template <int TM, int TN>
     __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
                                                  int n_base, int lane, int y, int z) {
-        const bool fast = n_base + TN * 32 <= p.C;       // wave-uniform
+        const bool fast = !p.bias && p.act == ACT_NONE && n_base + TN * 32 <= p.C;       // wave-uniform
         if (!fast) {
             EpiPhase<S>::template store<TM, TN>(p, acc, m_base, n_base, lane, y, z);
             return;
@@ -1731,7 +1779,6 @@ struct EpiPhaseB {
         const int col_l = lane & 31, half = lane >> 5;
         if (p.stats)
             tile_channel_stats<TM, TN>(acc, p.stats, (long long)y * p.stats_rows + m_base / (TM * 32), p.C, n_base, lane);
-        const bool plain = !p.bias && p.act == ACT_NONE;      // (bias + activation: round 4, HoloGAN's generator layers)
         const int py = y / S, px = y % S;
         const uint32_t chs = (uint32_t)(p.H * p.W) * 4u;                 // bytes between channel planes
         __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.out, (uint32_t)(p.M / (p.AH * p.AW)) * (uint32_t)p.C * chs);
@@ -1751,13 +1798,10 @@ struct EpiPhaseB {
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int cl = j * 32 + (r & 3) + 8 * (r >> 2);
-                const uint32_t so = soff + (uint32_t)cl * chs;
-                const float bv = (!plain && p.bias) ? p.bias[n_base + cl + 4 * half] : 0.f;
+                const uint32_t so = soff + (uint32_t)(j * 32 + (r & 3) + 8 * (r >> 2)) * chs;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    float v = acc[i][j][r];            // (bit_cast of the vector-element expression itself reads element 0)
-                    if (!plain) v = act_fwd(v + bv, p.act, p.slope);
+                    const float v = acc[i][j][r];      // (bit_cast of the vector-element expression itself reads element 0)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, voff[i], so, 0);
                 }
             }
@@ -2492,6 +2536,44 @@ struct ConvDgTapA2 {
         const int ko = kob + row;
         bload_lds4(rsrc, stage + row * LD + g * 64, veff[g],
                    (live && ko < K) ? (uint32_t)ko * (uint32_t)OHW * 4u + tap_soff : SOFF_OOB);
+    }
+};
+
+// 1x1 stride-1 layers are plain GEMMs over an NCHW tensor: A[k = channel][m = (n, pixel)], 256 consecutive rows of a
+// channel are 1 KB of contiguous memory whenever H*W is a multiple of 4 (a lane's 16-byte quad never straddles two
+// samples).  One 16-byte LDS-DMA piece per LDS row instead of the gather's four 4-byte ones (HoloGAN's 1024 -> 1024
+// projection, core/models/hologan_generator.py:130: 114 -> see DESIGN.md).
+template <int BM>
+struct PlaneA2 {
+    static_assert(BM % 256 == 0, "whole 256-pixel pieces per LDS row");
+    struct Params {
+        const float* base;
+        int CH, HW, M;
+        FastDiv div_hw;
+    };
+    static constexpr int LD = BM, ROWS = BK;
+    static constexpr int PPR = BM / 256;
+    static constexpr int PIECES = BK * PPR / 4;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff[PPR], plane;
+    int wave, CH;
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        rsrc = make_rsrc(p.base, (uint32_t)(p.M / p.HW) * (uint32_t)p.CH * (uint32_t)p.HW * 4u);
+        const int lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        CH = p.CH;
+        plane = (uint32_t)p.HW * 4u;
+#pragma unroll
+        for (int g = 0; g < PPR; ++g) {
+            const uint32_t m = (uint32_t)tile * BM + g * 256 + 4 * lane;
+            const uint32_t n = fdiv(m, p.div_hw);
+            voff[g] = m < (uint32_t)p.M ? (n * (uint32_t)(p.CH * p.HW) + (m - n * (uint32_t)p.HW)) * 4u : OOB;
+        }
+    }
+    __device__ __forceinline__ void issue_piece(int kc, float* stage, int p, bool live) {
+        const int row = wave * 4 + p / PPR, g = p % PPR;
+        const int c = kc * BK + row;
+        bload_lds16(rsrc, stage + row * LD + g * 256, voff[g], (live && c < CH) ? (uint32_t)c * plane : SOFF_OOB);
     }
 };
 

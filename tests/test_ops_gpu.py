@@ -822,11 +822,12 @@ def test_gemm_split_k(shape, tb):
 
 
 @pytest.mark.parametrize("case", [(16, 16, 64, 16), (4, 3, 128, 16), (4, 16, 128, 3), (16, 32, 64, 32),
-                                  (16, 16, 64, 32), (32, 20, 48, 24), (16, 64, 64, 3), (16, 5, 64, 50)])
+                                  (16, 16, 64, 32), (32, 20, 48, 24), (16, 64, 64, 3), (16, 5, 64, 50),
+                                  (16, 7, 64, 4), (17, 10, 64, 1), (64, 64, 64, 2)])      # <= 4 output channels: FMA kernel
 def test_wgrad_small_channel_3x3(case):
     """The 16x16x4-MFMA weight-gradient kernel of 3x3 s1 p1 layers with <= 32 channels (R1 ResNet high-resolution
-    stages): against torch, and against the implicit-GEMM path it replaces (GZ_NO_SMALLCH_WG is read once per
-    process, so the comparison is with the CPU reference only)."""
+    stages) and the plain-FMA kernel of layers with <= 4 output channels on 64-wide maps (HoloGAN's last layer):
+    against torch (GZ_NO_SMALLCH_WG is read once per process, so the comparison is with the CPU reference only)."""
     F = _F()
     from lightning_gan_zoo_amd._lib import lib
     N, C, H, K = case
@@ -845,7 +846,7 @@ def test_wgrad_small_channel_3x3(case):
 
 @pytest.mark.parametrize("case", [(16, 16, 64, 16), (4, 3, 128, 16), (4, 16, 128, 3), (16, 32, 64, 32),
                                   (16, 16, 64, 32), (32, 20, 48, 24), (8, 5, 96, 30), (16, 64, 64, 3),
-                                  (16, 9, 64, 50)])
+                                  (16, 9, 64, 50), (16, 9, 64, 4), (17, 33, 64, 1), (64, 64, 64, 2)])   # <= 4 outputs: FMA kernel
 def test_conv3x3_small_channel_fwd_dgrad(case):
     """The direct 16x16x4-MFMA forward / input-gradient kernel of 3x3 s1 p1 layers with <= 32 channels, with the
     bias + activation epilogues, for both weight image formats (tap-major when the input side has >= 16
