@@ -331,6 +331,58 @@ __global__ __launch_bounds__(256) void act_inplace3_kernel(float* __restrict__ x
     }
 }
 
+// weight gradient on the igemm2 skeleton with the register-staged loaders above (igemm2r_kernel, as the 2-D layers
+// without an LDS-DMA image).  Split so that two workgroups per CU come out, >= 24 chunks each: HoloGAN block1 (54 tiles
+// x 9 splits) 238 -> 178 us, block2 (7 tiles x 73) 210 -> 205 us; pieces of 48-64 chunks leave a partial second round
+// of workgroups and measured 240-310 us.
+// (256 x 128 tiles, or 128 x 256 with fewer than 256 output channels)
+using C3_128x256 = TileCfg2<1, 4, 2, 2>;
+static bool wg3r_ok(const Conv3DShape& s) { return !knobs().no_igemm2 && !knobs().no_wg3r && s.K >= 128; }
+
+static int wg3r_splits(const Conv3DShape& s, int KS) {
+    const long long ntot = (long long)s.C * KS * KS * KS;
+    const long long tiles = s.K >= 256 ? (long long)((s.K + 255) / 256) * ((ntot + 127) / 128)
+                                       : (long long)((s.K + 127) / 128) * ((ntot + 255) / 256);
+    const int chunks = (s.N * s.OD * s.OH * s.OW + BK - 1) / BK;
+    int splits = (int)(knobs().wg3r_wgs * cus() / tiles);
+    if (splits < 1) splits = 1;
+    while (splits > 1 && chunks / splits < knobs().wg3r_min_chunks) --splits;
+    return splits;
+}
+
+template <class Cfg, int KS, int S, int P>
+static int run_wgrad3r(const float* x, const float* y, float* dw, float* ws, size_t ws_bytes, const Conv3DShape& s,
+                       hipStream_t st) {
+    using AL = WgALoader<Cfg::BM>;
+    using BL = Wg3DBLoader<Cfg::BN, KS, S, P>;
+    const int osp = s.OD * s.OH * s.OW;
+    const int KTOT = s.N * osp;
+    const int NTOT = s.C * KS * KS * KS;
+    ConvShape flat{s.N, s.C, 1, 1, s.K, osp, 1};
+    typename AL::Params pa{y, flat, make_fastdiv(osp), KTOT};
+    typename BL::Params pb{x, s, make_fastdiv(osp), make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW), KTOT, NTOT};
+    const int chunks = (KTOT + BK - 1) / BK;
+    int splits = wg3r_splits(s, KS);
+    const long long count = (long long)s.K * NTOT;
+    if (splits > 1) {
+        const long long max_splits = (long long)(ws_bytes / 4) / count;
+        if (max_splits < 2) splits = 1;
+        else if (splits > max_splits) splits = (int)max_splits;
+    }
+    const int cps = (chunks + splits - 1) / splits;
+    const int nz = (chunks + cps - 1) / cps;
+    float* out = nz > 1 ? ws : dw;
+    EpiRowMajorB::Params pe{out, s.K, NTOT, NTOT, count, nullptr, ACT_NONE, 0.f};
+    int rc = launch_igemm2r<Cfg, AL, BL, EpiRowMajorB>(pa, pb, pe, s.K, NTOT, KTOT, splits, st);
+    if (rc != GZ_OK) return rc;
+    if (nz > 1) {
+        hipLaunchKernelGGL(reduce_slabs3_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws, dw, nz,
+                           count);
+        rc = launch_status();
+    }
+    return rc;
+}
+
 template <class Cfg, int KS, int S, int P>
 static int run_dgradtap3(const float* y, const float* wp, const float* bias, float* x, const Conv3DShape& s, int act,
                          float slope, hipStream_t st, int splits, float* slab) {
@@ -498,6 +550,8 @@ size_t gz_conv3d_wgrad_workspace_bytes(int N, int C, int K, int OD, int OH, int 
     int chunks = (N * OD * OH * OW + BK - 1) / BK;
     long long tiles = (long long)((K + 127) / 128) * ((C * KS * KS * KS + 127) / 128);
     int splits = splits3(tiles, chunks);
+    const Conv3DShape s{N, C, 2 * OD, 2 * OH, 2 * OW, K, OD, OH, OW};
+    if (wg3r_ok(s)) splits = wg3r_splits(s, KS);
     return splits > 1 ? (size_t)splits * count * 4 : 0;
 }
 
@@ -508,6 +562,9 @@ int gz_conv3d_wgrad(const float* x, const float* y, float* dw, float* workspace,
     if (KS != 3 || S != 2 || P != 1) return GZ_ERR_UNSUPPORTED;
     if (!shape3_ok(s, KS, S, P)) return GZ_ERR_BAD_SHAPE;
     if (big3((long long)N * C * D * H * W) || big3((long long)N * K * OD * OH * OW)) return GZ_ERR_TOO_LARGE;
+    if (wg3r_ok(s))
+        return K >= 256 ? run_wgrad3r<C3_256x128, 3, 2, 1>(x, y, dw, workspace, ws_bytes, s, stream)
+                        : run_wgrad3r<C3_128x256, 3, 2, 1>(x, y, dw, workspace, ws_bytes, s, stream);
     long long NTOT = (long long)C * KS * KS * KS;
     int t = NTOT <= 32 ? 2 : ((NTOT <= 64 || K <= 64) ? (K <= 64 ? 3 : 1) : 0);
     const int force = knobs().wg3_tile;      // experiment

@@ -1344,9 +1344,11 @@ struct Wg3DBLoader {
     // Validity of a tap is kept as 3 + 3 bits per element (tap index 0 / KS-1 along d, y, x: the only taps that can
     // leave the volume below / above), eight elements to a register -- the per-element kd/ky/kx arrays of round 1
     // cost 24 more registers and the 128x128 kernel spilled 22 of them inside the reduction loop.
-    static_assert(EPT <= 8 && KS == 3 && S == 2 && P == 1, "only tap 0 / tap KS-1 may leave the volume");
+    static_assert(EPT <= 16 && KS == 3 && S == 2 && P == 1, "only tap 0 / tap KS-1 may leave the volume");
+    using Mask = std::conditional_t<(EPT > 8), unsigned long long, uint32_t>;      // (BN = 256: 16 elements, 48 bits)
+    static constexpr Mask REP = (Mask)0x249249249249ull;                            // 001 repeated: one bit per element
     int toff[EPT];
-    uint32_t lo_bits, hi_bits;       // 3 bits per element j at 3*j: (kd == 0, ky == 0, kx == 0) / (== KS-1)
+    Mask lo_bits, hi_bits;           // 3 bits per element j at 3*j: (kd == 0, ky == 0, kx == 0) / (== KS-1)
     int kl, n_l, ODHW, OHW, OW, D, H, W, CDHW, KTOT;
     FastDiv div_odhw, div_ohw, div_ow;
     float r[EPT];
@@ -1368,8 +1370,8 @@ struct Wg3DBLoader {
             const int kd = tap / (KS * KS), ky = (tap / KS) % KS, kx = tap % KS;
             const bool in = col < p.NTOT;
             toff[j] = in ? ((c * D + kd - P) * H + ky - P) * W + kx - P : INT32_MIN;     // INT32_MIN: column past the end
-            lo_bits |= (uint32_t)((kd == 0) | (ky == 0) << 1 | (kx == 0) << 2) << (3 * j);
-            hi_bits |= (uint32_t)((kd == KS - 1) | (ky == KS - 1) << 1 | (kx == KS - 1) << 2) << (3 * j);
+            lo_bits |= (Mask)((kd == 0) | (ky == 0) << 1 | (kx == 0) << 2) << (3 * j);
+            hi_bits |= (Mask)((kd == KS - 1) | (ky == KS - 1) << 1 | (kx == KS - 1) << 2) << (3 * j);
         }
     }
     __device__ __forceinline__ void issue(int kc) {
@@ -1388,10 +1390,10 @@ struct Wg3DBLoader {
         const uint32_t pos_lo = (uint32_t)(bd < P) | (uint32_t)(by < P) << 1 | (uint32_t)(bx < P) << 2;
         const uint32_t pos_hi = (uint32_t)(bd + KS - 1 - P >= D) | (uint32_t)(by + KS - 1 - P >= H) << 1 |
                                 (uint32_t)(bx + KS - 1 - P >= W) << 2;
-        const uint32_t bad = (lo_bits & (pos_lo * 0x249249u)) | (hi_bits & (pos_hi * 0x249249u));
+        const Mask bad = (lo_bits & ((Mask)pos_lo * REP)) | (hi_bits & ((Mask)pos_hi * REP));
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            bool v2 = ok && toff[j] != INT32_MIN && ((bad >> (3 * j)) & 7u) == 0;
+            bool v2 = ok && toff[j] != INT32_MIN && ((uint32_t)(bad >> (3 * j)) & 7u) == 0;
             r[j] = bload(rsrc, v2 ? (uint32_t)(base + toff[j]) * 4u : OOB, 0);
         }
     }

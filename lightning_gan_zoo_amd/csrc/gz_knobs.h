@@ -17,6 +17,9 @@ namespace gz {
     X(bool, no_igemm2, "GZ_NO_IGEMM2", false)               /* keep everything on igemm_kernel (round 2) */         \
     X(bool, no_igemm2_tap, "GZ_NO_IGEMM2_TAP", false)       /* ... the gather-loader launches only */               \
     X(bool, no_plane_a, "GZ_NO_PLANE_A", false)             /* 1x1 layers: the 4-byte gather instead of PlaneA2 */   \
+    X(bool, no_wg3r, "GZ_NO_WG3R", false)                   /* 3-D weight gradient: the round-1 kernel */            \
+    X(int, wg3r_wgs, "GZ_WG3R_WGS", 2)                      /* ... workgroups per CU aimed at by its split */        \
+    X(int, wg3r_min_chunks, "GZ_WG3R_MIN_CHUNKS", 24)       /* ... chunks per workgroup at least */                  \
     X(bool, no_fewk_wg, "GZ_NO_FEWK_WG", false)             /* 3x3 Wg with <= 4 output channels: the MFMA kernel */  \
     X(bool, no_fewk_conv, "GZ_NO_FEWK_CONV", false)         /* 3x3 F with <= 4 output channels: the MFMA kernel */   \
     X(int, dg3_tile, "GZ_DG3_TILE", 0)                      /* ConvTranspose3d forward on igemm2: force 256x128 (1) / 256x64 (2) */ \
