@@ -834,12 +834,33 @@ __global__ __launch_bounds__(256) void dgrad_smallc4_k4s2p1_kernel(const float* 
     const int kpad = round_bk(s.K);
     const long long phase_stride = KH == 4 ? (long long)s.K * 16             // floats: K * 4 taps * ldc(4)
                                            : (long long)TMAX * TMAX * kpad * 4;
+    // the next channel's three rows are requested before this channel's 192 FMAs (round 4: with two wavefronts per SIMD
+    // nothing else covers the load latency; G's last layer at bs 128: 56 us with the loads issued in place)
+    // (the 256-position form, KS = 1, runs 4-7 wavefronts per SIMD and keeps its loads in place: 26 registers fewer)
+    f32x4 nxt[3];
+    if constexpr (KS > 1) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+            nxt[dy] = bload4(rsrc, wave < s.K ? voff[dy] : OOB, (uint32_t)wave * (uint32_t)OHW * 4u);
+    }
     for (int ko = wave; ko < s.K; ko += KS) {
         float v[3][6];
-        const uint32_t soff = (uint32_t)ko * (uint32_t)OHW * 4u;
+        f32x4 cur[3];
+        if constexpr (KS > 1) {
+            const bool more = ko + KS < s.K;
+            const uint32_t soff = (uint32_t)(more ? ko + KS : ko) * (uint32_t)OHW * 4u;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                cur[dy] = nxt[dy];
+                nxt[dy] = bload4(rsrc, more ? voff[dy] : OOB, soff);
+            }
+        } else {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) cur[dy] = bload4(rsrc, voff[dy], (uint32_t)ko * (uint32_t)OHW * 4u);
+        }
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
-            const f32x4 r = bload4(rsrc, voff[dy], soff);
+            const f32x4 r = cur[dy];
             const float l = __shfl_up(r.w, 1), rr = __shfl_down(r.x, 1);
             v[dy][0] = has_l ? l : 0.f;
             v[dy][1] = r.x; v[dy][2] = r.y; v[dy][3] = r.z; v[dy][4] = r.w;
@@ -1332,17 +1353,30 @@ __global__ __launch_bounds__(256) void conv3x3_fewk_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
     const float* xn = in + (long long)n * CI * HW + w0;
-#pragma unroll 2
-    for (int ci = c0; ci < c1; ++ci) {
+    // the next channel's rows are requested before this channel's FMAs (two wavefronts per SIMD: nothing else covers
+    // the load latency)
+    auto load_rows = [&](int ci, f32x4 (&rws)[6]) {
         const float* xc = xn + (long long)ci * HW;
-        float xr[3][10];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int hh = h + d - 1;
             const bool ok = (unsigned)hh < (unsigned)H;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 v0 = ok ? *reinterpret_cast<const f32x4*>(xc + hh * 64) : z;
-            const f32x4 v1 = ok ? *reinterpret_cast<const f32x4*>(xc + hh * 64 + 4) : z;
+            rws[2 * d] = ok ? *reinterpret_cast<const f32x4*>(xc + hh * 64) : z;
+            rws[2 * d + 1] = ok ? *reinterpret_cast<const f32x4*>(xc + hh * 64 + 4) : z;
+        }
+    };
+    f32x4 nxt[6];
+    if (c0 < c1) load_rows(c0, nxt);
+    for (int ci = c0; ci < c1; ++ci) {
+        f32x4 cur[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) cur[e] = nxt[e];
+        if (ci + 1 < c1) load_rows(ci + 1, nxt);
+        float xr[3][10];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const f32x4 v0 = cur[2 * d], v1 = cur[2 * d + 1];
             const float left = __shfl_up(v1[3], 1, 64), right = __shfl_down(v0[0], 1, 64);
             xr[d][0] = sg == 0 ? 0.f : left;
             xr[d][1] = v0[0]; xr[d][2] = v0[1]; xr[d][3] = v0[2]; xr[d][4] = v0[3];
@@ -1578,17 +1612,37 @@ __global__ __launch_bounds__(256) void wgrad_k3_fewk_kernel(const float* __restr
         for (int t = 0; t < 9; ++t) acc[k][t] = 0.f;
     }
     const int n0 = ns * n_per_slice, n1 = min(s.N, n0 + n_per_slice);
-    for (int n = n0; n < n1; ++n) {
+    // the next sample's rows are requested before this sample's FMAs (see conv3x3_fewk_kernel)
+    auto load_rows = [&](int n, f32x4 (&rws)[6], f32x4 (&yws)[2 * KK]) {
         const float* xc = x + ((long long)n * s.C + c) * HW + w0;
         const float* yn = y + (long long)n * s.K * HW + h * 64 + w0;
-        float xr[3][10];
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int hh = h + d - 1;
             const bool ok = (unsigned)hh < (unsigned)H;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 v0 = ok ? *reinterpret_cast<const f32x4*>(xc + hh * 64) : z;
-            const f32x4 v1 = ok ? *reinterpret_cast<const f32x4*>(xc + hh * 64 + 4) : z;
+            rws[2 * d] = ok ? *reinterpret_cast<const f32x4*>(xc + hh * 64) : z;
+            rws[2 * d + 1] = ok ? *reinterpret_cast<const f32x4*>(xc + hh * 64 + 4) : z;
+        }
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            yws[2 * k] = k < s.K ? *reinterpret_cast<const f32x4*>(yn + (long long)k * HW) : z;
+            yws[2 * k + 1] = k < s.K ? *reinterpret_cast<const f32x4*>(yn + (long long)k * HW + 4) : z;
+        }
+    };
+    f32x4 nxt[6], ynx[2 * KK];
+    if (n0 < n1) load_rows(n0, nxt, ynx);
+    for (int n = n0; n < n1; ++n) {
+        f32x4 cur[6], ycur[2 * KK];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) cur[e] = nxt[e];
+#pragma unroll
+        for (int e = 0; e < 2 * KK; ++e) ycur[e] = ynx[e];
+        if (n + 1 < n1) load_rows(n + 1, nxt, ynx);
+        float xr[3][10];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const f32x4 v0 = cur[2 * d], v1 = cur[2 * d + 1];
             const float left = __shfl_up(v1[3], 1, 64), right = __shfl_down(v0[0], 1, 64);
             xr[d][0] = sg == 0 ? 0.f : left;
             xr[d][1] = v0[0]; xr[d][2] = v0[1]; xr[d][3] = v0[2]; xr[d][4] = v0[3];
@@ -1598,14 +1652,10 @@ __global__ __launch_bounds__(256) void wgrad_k3_fewk_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
             float yv[8];
-            if (k < s.K) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(yn + (long long)k * HW);
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(yn + (long long)k * HW + 4);
+            {
+                const f32x4 a = ycur[2 * k], bq = ycur[2 * k + 1];
                 yv[0] = a[0]; yv[1] = a[1]; yv[2] = a[2]; yv[3] = a[3];
                 yv[4] = bq[0]; yv[5] = bq[1]; yv[6] = bq[2]; yv[7] = bq[3];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) yv[j] = 0.f;
             }
             if (c == 0) ysum[k] += ((yv[0] + yv[1]) + (yv[2] + yv[3])) + ((yv[4] + yv[5]) + (yv[6] + yv[7]));
 #pragma unroll
