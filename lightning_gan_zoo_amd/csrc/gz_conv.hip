@@ -43,7 +43,11 @@ static TileId pick_tile2(long long M, long long N, int ny, int kdim) {
     const bool off = knobs().no_igemm2;
     if (!off && N > 32 && N <= 64 && kdim >= 256) {             // one 64-wide column of 512-pixel tiles
         const long long t = ((M + 511) / 512) * ny;
-        return t >= 2 * cus() ? T512x64 : T64x64;
+        if (t >= 2 * cus()) return T512x64;
+        // (round 4: fewer than that -- D.block1's input gradient in a bs-128 generator step, 256 tiles of 512x64 -- go to
+        // 256x64 tiles when those give every CU a workgroup)
+        if (!knobs().no_tile64 && knobs().igemm2_tile == 0 && N == 64 && ((M + 255) / 256) * ny >= cus()) return T256x64;
+        return T64x64;
     }
     if (off || N < 128 || kdim < 256) return T64x64;            // "not applicable"
     const long long t128 = ((M + 255) / 256) * ((N + 127) / 128) * ny;
