@@ -840,7 +840,8 @@ __global__ __launch_bounds__(256) void dgrad_smallc4_k4s2p1_kernel(const float* 
                                            : (long long)TMAX * TMAX * kpad * 4;
     // the next channel's three rows are requested before this channel's 192 FMAs (round 4: with two wavefronts per SIMD
     // nothing else covers the load latency; G's last layer at bs 128: 56 us with the loads issued in place)
-    // (the 256-position form, KS = 1, runs 4-7 wavefronts per SIMD and keeps its loads in place: 26 registers fewer)
+    // (the 256-position form, KS = 1, runs 4-7 wavefronts per SIMD and keeps its loads in place: with the prefetch's 26
+    // extra registers it measured 80 -> 110 us at bs 256 and 113 -> 133 us at bs 512)
     f32x4 nxt[3];
     if constexpr (KS > 1) {
 #pragma unroll
