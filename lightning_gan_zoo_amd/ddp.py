@@ -37,15 +37,18 @@ CU_RESERVE = int(os.environ.get("GZ_DDP_CU_RESERVE", "0"))
 class _FlatGrads:
     def __init__(self, params, bucket_bytes=BUCKET_BYTES):
         self.params = [p for p in params][::-1]        # backward order: the last layer's gradient lands first
-        n = sum(p.numel() for p in self.params)
-        ref = self.params[0]
-        self.flat = torch.zeros(n, device=ref.device, dtype=ref.dtype)
+        # every view starts on a 16-byte boundary (the sink kernels read and write float4; a 1-element bias -- HoloGAN's
+        # logit head -- would otherwise misalign everything behind it); the <= 3 padding floats per parameter stay zero
         self.offsets = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off = (off + 3) & ~3
             self.offsets.append(off)
             off += p.numel()
+        ref = self.params[0]
+        self.flat = torch.zeros(off, device=ref.device, dtype=ref.dtype)
+        for p, o in zip(self.params, self.offsets):
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
         # contiguous buckets: close one when the next parameter would push it over the cap
         self.buckets = []            # [start, end, first param index, last param index + 1]
         start = first = 0

@@ -476,6 +476,8 @@ def _sink_conv_wgrad(w, x, g, geom):
     it the ordinary way).  x / g are the operands gz_conv2d_wgrad takes."""
     if not _sinks.enabled or not isinstance(w, torch.nn.Parameter) or (w.numel() & 3):
         return False
+    if w.grad is not None and (w.grad.data_ptr() & 15 or not w.grad.is_contiguous() or w.grad.dtype != torch.float32):
+        return False          # a foreign p.grad layout (not 16-byte aligned): autograd's accumulation takes it
     N, C, H, W = x.shape
     _, K, OH, OW = g.shape
     nbytes = lib.gz_conv2d_wgrad_workspace_bytes(N, C, H, W, K, OH, OW, geom.kh, geom.kw)

@@ -260,3 +260,26 @@ def test_optimizer_schedule_follows_frequencies():
     assert optimizer_schedule([1, 1]) == [0, 1]
     assert optimizer_schedule([5, 1]) == [0, 0, 0, 0, 0, 1]          # conf/expt/wgan.yaml:22-23
     assert optimizer_schedule([1, 2]) == [0, 1, 1]                   # conf/expt/hologan.yaml:16-17
+
+
+def test_flat_gradient_views_start_on_16_byte_boundaries():
+    """The sink kernels read and write float4: every ``p.grad`` view of the flat exchange buffer starts at a multiple of
+    four floats whatever the parameter sizes in front of it (HoloGAN's 1-element logit bias, 3-element image bias), the
+    views do not overlap and the padding stays zero through a fill."""
+    import torch
+    from lightning_gan_zoo_amd.ddp import _FlatGrads
+    params = [torch.nn.Parameter(torch.zeros(*shape)) for shape in ((3,), (64, 3, 3, 3), (1,), (1, 8192), (5, 7), (128,))]
+    fg = _FlatGrads(params, bucket_bytes=4096)
+    assert all(off % 4 == 0 for off in fg.offsets)
+    assert all(p.grad.data_ptr() == fg.flat.data_ptr() + 4 * off for p, off in zip(fg.params, fg.offsets))
+    for k, p in enumerate(fg.params):
+        p.grad.fill_(k + 1.0)
+    covered = torch.zeros_like(fg.flat)
+    for k, (p, off) in enumerate(zip(fg.params, fg.offsets)):
+        assert float(covered[off:off + p.numel()].abs().sum()) == 0.0           # no overlap
+        covered[off:off + p.numel()] = 1.0
+        assert torch.equal(fg.flat[off:off + p.numel()], torch.full((p.numel(),), k + 1.0))
+    assert float(fg.flat[covered == 0].abs().sum()) == 0.0                      # padding untouched
+    # the buckets tile [0, end of the last parameter) without gaps
+    assert fg.buckets[0][0] == 0 and all(a[1] == b[0] for a, b in zip(fg.buckets, fg.buckets[1:]))
+    assert fg.buckets[-1][1] == fg.offsets[-1] + fg.params[-1].numel()

@@ -18,7 +18,13 @@ def _free_port():
     return p
 
 
-def test_gradsync_on_rccl_single_rank_matches_plain_trainer():
+@pytest.mark.parametrize("expt", ["dc_gan", "wgan_gp", "hologan"])
+def test_gradsync_on_rccl_single_rank_matches_plain_trainer(expt):
+    """GradSync (gradients in the flat exchange buffer, every contribution through the sinks with beta = 1, one
+    all-reduce per bucket) against the plain trainer, four steps, same parameters bit for bit.  hologan covers the
+    complete-gradient sources (biases, Linear weights, spectral-norm weight_orig: functional._sink_grad) and parameters
+    whose view into the flat buffer is not 16-byte aligned (they stay with autograd)."""
+    import numpy as np
     import torch.distributed as dist
     from helpers import FixedNoise, fill_closed_form, synthetic_noise, synthetic_real
     from lightning_gan_zoo_amd.config import locate, make_cfg
@@ -30,11 +36,12 @@ def test_gradsync_on_rccl_single_rank_matches_plain_trainer():
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         def build():
-            cfg = make_cfg("dc_gan", batch_size=8, features=8, noise_dim=16)
+            cfg = make_cfg(expt, batch_size=8, features=8, noise_dim=16)
             torch.manual_seed(42)
             m = locate(cfg.model.lm["_target_"])(cfg, None)
-            fill_closed_form(m.generator, 1)
-            fill_closed_form(m.discriminator, 2)
+            if expt != "hologan":          # (hologan keeps its own initialisation: spectral-norm buffers, zero biases)
+                fill_closed_form(m.generator, 1)
+                fill_closed_form(m.discriminator, 2)
             return m.cuda()
 
         labels = torch.zeros(8, dtype=torch.int64, device="cuda")
@@ -44,6 +51,8 @@ def test_gradsync_on_rccl_single_rank_matches_plain_trainer():
         for use_sync in (True, False):
             m = build()
             tr = Trainer(m, grad_sync=GradSync(m) if use_sync else None)
+            torch.manual_seed(7)
+            np.random.seed(7)              # (hologan's views, wgan_gp's interpolation weights)
             for k in range(4):
                 m.noise_distn = FixedNoise(noises[k])
                 tr.step(batches[k])
