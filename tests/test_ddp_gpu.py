@@ -101,7 +101,8 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
         assert all(v >= 0.0 for v in ov["exposed_wait_ms_per_step"].values())
 
 
-def test_two_rank_training_run_rehearsal_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("expt", ["dc_gan", "hologan"])
+def test_two_rank_training_run_rehearsal_on_one_gpu(tmp_path, expt):
     """``python -m torch.distributed.run --nproc-per-node 2 -m lightning_gan_zoo_amd.run_network +expt=dc_gan ...`` on
     one GPU (GZ_REHEARSE_ONE_GPU): sharded synthetic data, gradient exchange from the backward hooks, rank 0 alone
     writes the Lightning-format checkpoint, both ranks leave together."""
@@ -113,9 +114,12 @@ def test_two_rank_training_run_rehearsal_on_one_gpu(tmp_path):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), "-m", "lightning_gan_zoo_amd.run_network", "+expt=dc_gan",
-           "dataset=synthetic", "train.features_gen=8", "train.features_disc=8", "model.noise_dim=16",
-           "train.batch_size=8", "train.ckpt_dir=" + ck, "log_every=1000", "max_steps=4"]
+           "127.0.0.1", "--master-port", str(_free_port()), "-m", "lightning_gan_zoo_amd.run_network", "+expt=" + expt,
+           "dataset=synthetic", "model.noise_dim=16", "train.batch_size=8", "train.ckpt_dir=" + ck, "log_every=1000",
+           "max_steps=4"]
+    cmd += (["train.features_gen=8", "train.features_disc=8"] if expt == "dc_gan"
+            else ["generator.in_planes=8", "discriminator.out_planes=8"])      # hologan: gradients of every kind of parameter
+                                                                               # through the flat exchange buffer
     r = subprocess.run(cmd, env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
