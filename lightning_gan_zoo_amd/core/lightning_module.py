@@ -317,9 +317,26 @@ class HOLOGAN(BaseGAN):
         z = self.sample_noise(len(real))
 
         if optimizer_idx == 0:
+            d, c = self.discriminator, self.criterion
+            fake = None
+            if (self.stack_d_passes and getattr(d, "supports_stacked_batches", False) and real.is_cuda and d.training
+                    and isinstance(c, torch.nn.BCEWithLogitsLoss) and c.reduction == "mean" and c.weight is None
+                    and c.pos_weight is None):
+                # ONE pass over [real; fake]: InstanceNorm is per sample, and each half gets the sigma of its own power
+                # iteration (real's first, as in the reference's call order) -- hologan_discriminator.Discriminator
+                fake = self.generator(z)
+                if real.shape == fake.shape:
+                    logits, d_z_pred = d(torch.cat([real, fake.detach()]), groups=2)
+                    loss_disc = F.bce_logits_pair_mean(logits, 1.0, 0.0)       # (BCE(real, 1) + BCE(fake, 0)) / 2
+                    q_loss = F.mse_mean(d_z_pred[len(real):], z)
+                    self.log("train/d_loss", loss_disc)
+                    self.log("train/q_loss", q_loss)
+                    return loss_disc + q_loss
             # (the generator draws its views from numpy's generator inside forward(): no other numpy draw happens in
             # this step, so running D(real) first leaves that stream untouched)
-            if self.real_first:
+            if fake is not None:
+                disc_real, _ = self.discriminator(real)
+            elif self.real_first:
                 disc_real, _ = self.discriminator(real)
                 fake = self.generator(z)
             else:

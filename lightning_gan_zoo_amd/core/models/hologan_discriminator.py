@@ -74,16 +74,36 @@ class Discriminator(nn.Module):
         self.sigmoid = nn.Sigmoid()
         self.tanh = nn.Tanh()
 
-    def forward(self, x):
+    # Training-mode blocks run as IN_{eps sigma^2}(conv(x, weight_orig)) (functional.sn_conv_in_act): the same function of
+    # the inputs as conv(x, weight_orig / sigma) + bias -> InstanceNorm, on weight_orig's cached packed images.  With it a
+    # discriminator step can apply D ONCE to [real; fake] (`groups` = 2: two consecutive power iterations, one sigma per
+    # half -- what the reference's two calls see).  False: the per-call weight copy of rounds 2-4a.
+    fused_sn_blocks = True
+
+    @property
+    def supports_stacked_batches(self):
+        return self.fused_sn_blocks and all(blk.conv2d.weight_orig.shape[1] % 4 == 0 for blk in self.blocks)
+
+    def forward(self, x, groups=1):
         batch_size = x.size(0)
         slope = self.lrelu.negative_slope
         h = F.conv2d(x, self.conv2d.weight, self.conv2d.bias, K5S2P2, F.ACT_LRELU, slope)
         # torch.nn.utils.spectral_norm's pre-forward hook of each block (reference :15,32) depends only on the block's
         # own weight and buffers: the three power iterations share their launches
         convs = [blk.conv2d for blk in self.blocks]
-        ws = F.spectral_normalize_multi([(c.weight_orig, c.weight_u, c.weight_v) for c in convs], self.training, K5S2P2)
-        for blk, w in zip(self.blocks, ws):
-            h = blk(h, w)
+        layers = [(c.weight_orig, c.weight_u, c.weight_v) for c in convs]
+        if self.training and x.is_cuda and self.supports_stacked_batches:
+            for blk, (sigma, us, vs) in zip(self.blocks, F.spectral_power_iterations(layers, calls=groups)):
+                c = blk.conv2d
+                h = F.sn_conv_in_act(h, c.weight_orig, c.bias, sigma, us, vs, K5S2P2, blk.instance_norm.eps, F.ACT_LRELU,
+                                     blk.lrelu.negative_slope)
+        else:
+            if groups != 1:
+                raise ValueError("a stacked batch needs the fused spectral-norm blocks (training mode, channel counts "
+                                 "that are multiples of 4)")
+            ws = F.spectral_normalize_multi(layers, self.training, K5S2P2)
+            for blk, w in zip(self.blocks, ws):
+                h = blk(h, w)
         h = h.reshape(batch_size, -1)
         logit = F.linear_act(h, self.linear1.weight, self.linear1.bias)
         enc = F.linear_act(h, self.linear2.weight, self.linear2.bias, F.ACT_LRELU, slope)

@@ -1831,6 +1831,111 @@ def spectral_normalize_multi(layers, training, geom, eps=1e-12):
     return list(_SpectralNormMulti.apply(float(eps), geom, *flat))
 
 
+def spectral_power_iterations(layers, calls=1, eps=1e-12):
+    """``calls`` consecutive power iterations of torch.nn.utils.spectral_norm for each (weight_orig, u, v) -- what
+    ``calls`` discriminator forward passes would run one after the other (the module buffers end up where the last call
+    leaves them).  Returns per layer (sigma [calls], u [calls, R], v [calls, L]): the values each call works with.
+    No autograd: sigma's dependence on the weight is handled by sn_conv_in_act's backward (u, v constants, as in torch)."""
+    st = _stream()
+    out = []
+    with torch.no_grad():
+        for W, _, _ in layers:
+            R, L = W.shape[0], W.numel() // W.shape[0]
+            out.append((torch.empty(calls, device=W.device, dtype=torch.float32),
+                        torch.empty((calls, R), device=W.device, dtype=torch.float32),
+                        torch.empty((calls, L), device=W.device, dtype=torch.float32)))
+        keep = []
+        for g in range(calls):
+            table = (ctypes.c_char * lib.gz_sn_table_bytes())()
+            for (W, u, v), (sig, us, vs) in zip(layers, out):
+                W = _req(W.detach(), "weight_orig")
+                R, L = W.shape[0], W.numel() // W.shape[0]
+                ws = _ws(lib.gz_sn_workspace_floats(R, L), W.device)
+                keep.append(ws)
+                check(lib.gz_sn_add(table, _p(W), _p(u), _p(v), _p(us[g]), _p(vs[g]), _p(sig[g:g + 1]), _p(ws), R, L),
+                      "sn_add")
+            check(lib.gz_sn_power_iteration(table, eps, st), "sn_power_iteration")
+        del keep
+    return out
+
+
+class _SNConvINAct(torch.autograd.Function):
+    """act(InstanceNorm(conv2d(x, weight_orig / sigma) + bias)) for the spectral-normalised blocks of HoloGAN's critic
+    (reference core/models/hologan_discriminator.py:28-38), computed as act(IN_{eps sigma^2}(conv2d(x, weight_orig))):
+    the InstanceNorm removes the bias and any scale except through eps, so the convolution runs on weight_orig's own
+    packed images (cached for the whole optimizer step instead of re-packed at every call) and ``groups`` discriminator
+    calls with different sigma can share one pass over the stacked batch.  Backward: weight_orig's gradient is the
+    convolution's weight gradient plus dL/dsigma_g u_g v_g^T (gz_sn_sigma_term: exactly torch's -(sum g w) u v^T / sigma);
+    the bias gradient is exactly zero (the reference's is rounding noise)."""
+
+    @staticmethod
+    def forward(ctx, x, weight_orig, bias, sigma, us, vs, geom, in_eps, act, slope):
+        x, W = _req(x, "x"), _req(weight_orig, "weight_orig")
+        groups = sigma.numel()
+        N = x.shape[0]
+        y = _conv_fwd_raw(x, W, None, geom, ACT_NONE, 0.0)
+        C, inner = y.shape[1], y.shape[2] * y.shape[3]
+        st = _stream()
+        eps_n = torch.empty(N, device=x.device, dtype=torch.float32)
+        check(lib.gz_sn_sample_eps(_p(sigma), _p(eps_n), N, groups, in_eps, st), "sn_sample_eps")
+        coef = torch.empty(4 * N * C, device=x.device, dtype=torch.float32)
+        out = torch.empty_like(y)
+        check(lib.gz_rownorm_act_fwd_eps(_p(y), _p(eps_n), _p(coef), _p(out), N, C, inner, act, slope, st),
+              "rownorm_act_fwd_eps")
+        ctx.save_for_backward(x, W, y, coef, sigma, us, vs)
+        ctx.cfg = (geom, in_eps, act, slope, groups, bias is not None)
+        ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        ctx.param = weight_orig
+        _sink_note_use(weight_orig)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        x, W, y, coef, sigma, us, vs = ctx.saved_tensors
+        geom, in_eps, act, slope, groups, has_bias = ctx.cfg
+        gout = _req(gout)
+        N, C = y.shape[0], y.shape[1]
+        inner = y.shape[2] * y.shape[3]
+        st = _stream()
+        g_raw = torch.empty_like(y)
+        rowsums = torch.empty(2 * N * C, device=y.device, dtype=torch.float32)
+        check(lib.gz_rownorm_act_bwd_rows(_p(gout), _p(y), _p(coef), _p(g_raw), _p(rowsums), N, C, inner, act, slope, st),
+              "rownorm_act_bwd_rows")
+        dx = _conv_dgrad_raw(g_raw, W, None, geom, tuple(x.shape[2:]), ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
+        dW = None
+        if ctx.needs_input_grad[1]:
+            R, L = W.shape[0], W.numel() // W.shape[0]
+            coefs = torch.empty(groups, device=y.device, dtype=torch.float32)
+            term = torch.empty_like(W)
+            check(lib.gz_sn_sigma_term(_p(rowsums), _p(coef[3 * N * C:]), _p(sigma), _p(us), _p(vs), _p(coefs), _p(term),
+                                       N * C, groups, R, L, in_eps, st), "sn_sigma_term")
+            p = ctx.param
+            k = id(p)
+            sunk = False
+            if _sinks.enabled and isinstance(p, torch.nn.Parameter) and k in _sinks.uses and not (W.numel() & 3):
+                _sinks.uses[k] += 1                    # (keeps the listener quiet until the sigma term is queued too)
+                if _sink_conv_wgrad(p, x, g_raw, geom):
+                    _sinks.pending[k][1].append((term, 1, W.numel()))
+                    _sink_done(p)
+                    sunk = True
+                else:
+                    _sinks.uses[k] -= 1
+            if not sunk:
+                dW = _conv_wgrad_raw(x, g_raw, geom)
+                dW.add_(term)
+                _sink_done(p)
+        db = torch.zeros(ctx.bias_shape, device=y.device, dtype=torch.float32) \
+            if (has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dW, db, None, None, None, None, None, None, None
+
+
+def sn_conv_in_act(x, weight_orig, bias, sigma, us, vs, geom, in_eps=1e-5, act=ACT_NONE, slope=0.0):
+    """One spectral-normalised conv + InstanceNorm2d(affine=False) + activation block; sigma [groups], us [groups, R],
+    vs [groups, L] from spectral_power_iterations (groups = discriminator calls stacked along the batch)."""
+    return _SNConvINAct.apply(x, weight_orig, bias, sigma, us, vs, geom, float(in_eps), act, slope)
+
+
 # ---------------------------------------------------------------------------
 # loss heads (csrc/gz_loss.hip)
 # ---------------------------------------------------------------------------

@@ -107,6 +107,7 @@ def record_product_masks(tape):
     wrap("adain_act_packed", 3, "act")       # (x, scale|shift, eps, act, slope)
     wrap("adain_const_act", 3, "act")
     wrap("instance_norm_act", 4, "act")      # (x, gamma, beta, eps, act, slope)
+    wrap("sn_conv_in_act", 8, "act")         # (x, weight_orig, bias, sigma, us, vs, geom, in_eps, act, slope)
     wrap("conv2d", 4, "act")                 # (x, w, bias, geom, act, slope)
     wrap("conv_transpose2d", 4, "act")
     try:

@@ -590,6 +590,53 @@ def test_spectral_normalize_multi_matches_per_layer_path():
             assert rel(a, c) < TOL, (rounds, k, rel(a, c))
 
 
+@pytest.mark.parametrize("groups", [1, 2])
+def test_sn_conv_in_act_matches_spectral_norm_conv_instance_norm(groups):
+    """functional.sn_conv_in_act: act(IN_{eps sigma^2}(conv(x, weight_orig))) on weight_orig's own packed images against
+    the reference's composition conv2d(x, weight_orig / sigma) + bias -> InstanceNorm2d -> LeakyReLU in torch on the CPU
+    (sigma = u^T W v after the power iteration, u / v constants): values, input gradient, weight_orig gradient including
+    the sigma term, u / v buffers; groups = 2: two consecutive power iterations, each half of the batch with its own
+    sigma -- what two discriminator calls see."""
+    F = _F()
+    geom = F.Geom(5, 5, 2, 2)
+    g = torch.Generator().manual_seed(5)
+    for (K, C, N, H) in ((32, 16, 4 * groups, 16), (128, 64, 2 * groups, 8)):
+        W = torch.randn(K, C, 5, 5, generator=g) * 0.05
+        b = torch.randn(K, generator=g) * 0.1
+        u0 = torch.nn.functional.normalize(torch.randn(K, generator=g), dim=0)
+        v0 = torch.nn.functional.normalize(torch.randn(C * 25, generator=g), dim=0)
+        x = torch.randn(N, C, H, H, generator=g)
+        go = torch.randn(N, K, H // 2, H // 2, generator=g)
+        # torch, CPU
+        Wr, xr = W.clone().requires_grad_(), x.clone().requires_grad_()
+        u, v = u0.clone(), v0.clone()
+        outs = []
+        for h in range(groups):
+            with torch.no_grad():
+                m = Wr.detach().reshape(K, -1)
+                v = torch.nn.functional.normalize(m.t() @ u, dim=0, eps=1e-12)
+                u = torch.nn.functional.normalize(m @ v, dim=0, eps=1e-12)
+            sigma = torch.dot(u, Wr.reshape(K, -1) @ v)
+            xs = xr[h * (N // groups):(h + 1) * (N // groups)]
+            y = TF.conv2d(xs, Wr / sigma, b, 2, 2)
+            outs.append(TF.leaky_relu(TF.instance_norm(y, eps=1e-5), 0.2))
+        ref = torch.cat(outs)
+        ref.backward(go)
+        # product
+        Wd = torch.nn.Parameter(W.cuda())
+        bd = torch.nn.Parameter(b.cuda())
+        xd = x.cuda().requires_grad_()
+        ud, vd = u0.cuda(), v0.cuda()
+        (sig, us, vs), = F.spectral_power_iterations([(Wd, ud, vd)], calls=groups)
+        out = F.sn_conv_in_act(xd, Wd, bd, sig, us, vs, geom, 1e-5, F.ACT_LRELU, 0.2)
+        out.backward(go.cuda())
+        assert rel(ud, u) < 1e-5 and rel(vd, v) < 1e-5
+        assert rel(out, ref) < TOL, rel(out, ref)
+        assert rel(xd.grad, xr.grad) < TOL, rel(xd.grad, xr.grad)
+        assert rel(Wd.grad, Wr.grad) < TOL, rel(Wd.grad, Wr.grad)
+        assert float(bd.grad.abs().max()) == 0.0          # exactly zero (the reference's is rounding noise)
+
+
 @pytest.mark.parametrize("width", [(8, 16), (64, 128)])      # (in_planes, z): small, and the reference's default width
 def test_hologan_ext128_matches_oracle_extension(width):
     """EXT-128: the reference cannot run at 128x128; product and oracle implement the
