@@ -260,12 +260,12 @@ int gz_sn_power_iteration(void* table_host, float eps, hipStream_t stream);
 /* A spectral-normalised convolution followed by InstanceNorm (no affine) without the per-call weight copy
  * (core/models/hologan_discriminator.py:28-38): IN_eps(conv(x, W / sigma) + b) = IN_{eps sigma^2}(conv(x, W)), so the
  * convolution runs on weight_orig's own packed images and the InstanceNorm takes one eps per sample.
- *   gz_sn_sample_eps: eps_n[n] = eps * sigma[n / (N / groups)]^2   (groups: discriminator calls stacked along n)
- *   gz_rownorm_act_fwd_eps (below): the InstanceNorm + activation with that array
+ *   gz_rownorm_act_fwd_sigma (below): the InstanceNorm + activation with eps * sigma[g]^2 for the samples of group g
+ *     (groups: discriminator calls stacked along n, sigma[groups] on the device)
  *   gz_sn_sigma_term: the gradient's sigma term, term[R][L] = sum_g coefs[g] u[g] v[g]^T with coefs[g] = dL/dsigma_g =
  *     -eps sigma_g sum_{rows of g} rstd^2 S2 from the backward's row sums (gz_rownorm_act_bwd_rows: [rows] pairs
  *     (sum dz, sum dz xh)); rstd = the forward's coef + 3 * rows.  Equal to torch's -(sum g w) u v^T / sigma. */
-int gz_sn_sample_eps(const float* sigma, float* eps_n, int N, int groups, float eps, hipStream_t stream);
+int gz_sn_sigma_coef_floats(int groups);      /* size of `coefs` (scratch) */
 int gz_sn_sigma_term(const float* rowsums, const float* rstd, const float* sigma, const float* u, const float* v,
                      float* coefs, float* term, int rows, int groups, int R, int L, float eps, hipStream_t stream);
 int gz_div_scalar(const float* x, const float* sigma, float* out, long long count, hipStream_t stream);
@@ -319,10 +319,10 @@ int gz_adain_const_bwd(const float* gout, const float* x, const float* coef, flo
 int gz_norm_act_fwd(const float* x, const float* coef, float* out, int N, int C, int inner, int per_channel,
                     int act, float slope, hipStream_t stream);
 /* first backward of norm+act: dx (may be NULL), dgamma, dbeta (may be NULL); kbuf: 2*ncoef floats scratch */
-/* InstanceNorm (no affine) + activation with one eps per sample (eps_n[N]), and its first-order backward that also
- * leaves the row sums (sum dz, sum dz xh) in rowsums[N*C] pairs: the two halves of functional.sn_conv_in_act */
-int gz_rownorm_act_fwd_eps(const float* x, const float* eps_n, float* coef, float* out, int N, int C, int inner, int act,
-                           float slope, hipStream_t stream);
+/* InstanceNorm (no affine) + activation with eps * sigma[n / (N / groups)]^2 per sample, and its first-order backward
+ * that also leaves the row sums (sum dz, sum dz xh) in rowsums[N*C] pairs: the two halves of functional.sn_conv_in_act */
+int gz_rownorm_act_fwd_sigma(const float* x, const float* sigma, int groups, float* coef, float* out, int N, int C,
+                             int inner, float eps, int act, float slope, hipStream_t stream);
 int gz_rownorm_act_bwd_rows(const float* gout, const float* x, const float* coef, float* dx, float* rowsums, int N, int C,
                             int inner, int act, float slope, hipStream_t stream);
 int gz_norm_act_bwd(const float* gout, const float* x, const float* coef, float* dx, float* dgamma, float* dbeta,

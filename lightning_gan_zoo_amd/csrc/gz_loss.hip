@@ -316,45 +316,45 @@ __global__ __launch_bounds__(LT) void sn_unorm_kernel(SnTable t, float eps) {
 // ---- a spectral-normalised convolution followed by InstanceNorm without the per-call weight copy ------------------
 // sigma enters such a block only as a scalar on the convolution's output, and the InstanceNorm behind it removes any
 // scale except through eps: IN_eps(conv(x, W / sigma) + b) = IN_{eps sigma^2}(conv(x, W)) (b is removed by the mean).
-// eps_n[n] = eps * sigma[group of sample n]^2
-__global__ __launch_bounds__(LT) void sn_sample_eps_kernel(const float* __restrict__ sigma, float* __restrict__ eps_n,
-                                                          int N, int groups, float eps) {
-    const int n = blockIdx.x * LT + threadIdx.x;
-    if (n >= N) return;
-    const float sg = sigma[n / (N / groups)];
-    eps_n[n] = eps * sg * sg;
-}
-
 // The gradient's sigma term.  With the row sums S2 = sum_i dz_i xh_i of the InstanceNorm backward,
 //   dL/dsigma_g = -eps sigma_g sum_{rows of group g} rstd_row^2 S2_row     (= -(sum g_raw . y_raw) / sigma_g exactly:
 //   the "- c u v^T / sigma" term of torch's spectral_norm backward), and d sigma / dW = u v^T.
-// coefs[g] <- dL/dsigma_g; one workgroup per group, fixed order
+// coefs[g][s] <- the share of slice s (SN_COEF_SLICES workgroups per group, fixed order inside and across the slices)
+constexpr int SN_COEF_SLICES = 16;
 __global__ __launch_bounds__(LT) void sn_sigma_coef_kernel(const f32x2* __restrict__ rowsums, const float* __restrict__ rstd,
                                                           const float* __restrict__ sigma, float* __restrict__ coefs,
                                                           int rows_per_group, float eps) {
     __shared__ float red[4];
-    const int g = blockIdx.x;
+    const int g = blockIdx.x, sl = blockIdx.y;
+    const int per = (rows_per_group + SN_COEF_SLICES - 1) / SN_COEF_SLICES;
+    const int i0 = sl * per, i1 = min(rows_per_group, i0 + per);
     float s = 0.f;
-    for (int i = threadIdx.x; i < rows_per_group; i += LT) {
+    for (int i = i0 + threadIdx.x; i < i1; i += LT) {
         const int r = g * rows_per_group + i;
         const float rs = rstd[r];
         s += rs * rs * rowsums[r].y;
     }
     s = block_sum(s, red);
-    if (threadIdx.x == 0) coefs[g] = -eps * sigma[g] * s;
+    if (threadIdx.x == 0) coefs[g * SN_COEF_SLICES + sl] = -eps * sigma[g] * s;
 }
 
-// term[r][l] = sum_g coefs[g] u[g][r] v[g][l]
+// term[r][l] = sum_g coef_g u[g][r] v[g][l],  coef_g = the sum of the group's slices
 __global__ __launch_bounds__(LT) void sn_sigma_term_kernel(const float* __restrict__ coefs, const float* __restrict__ u,
                                                           const float* __restrict__ v, float* __restrict__ term, int R,
                                                           int L4, int groups, long long total4, FastDiv div_l4) {
+    float cg[8];
+    for (int g = 0; g < groups; ++g) {
+        float c = 0.f;
+        for (int sl = 0; sl < SN_COEF_SLICES; ++sl) c += coefs[g * SN_COEF_SLICES + sl];
+        cg[g] = c;
+    }
     const long long stride = (long long)gridDim.x * LT;
     for (long long i = (long long)blockIdx.x * LT + threadIdx.x; i < total4; i += stride) {
         const uint32_t r = fdiv((uint32_t)i, div_l4);
         const uint32_t q = (uint32_t)i - r * (uint32_t)L4;
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
         for (int g = 0; g < groups; ++g) {
-            const float cu = coefs[g] * u[(long long)g * R + r];
+            const float cu = cg[g] * u[(long long)g * R + r];
             const f32x4 vv = reinterpret_cast<const f32x4*>(v)[(long long)g * L4 + q];
             o = o + vv * cu;
         }
@@ -465,20 +465,15 @@ int gz_sn_power_iteration(void* table_host, float eps, hipStream_t stream) {
     return launch_status();
 }
 
-int gz_sn_sample_eps(const float* sigma, float* eps_n, int N, int groups, float eps, hipStream_t stream) {
-    gz::clear_stale_error();
-    if (!sigma || !eps_n || N <= 0 || groups <= 0 || N % groups) return GZ_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL(sn_sample_eps_kernel, dim3((N + LT - 1) / LT), dim3(LT), 0, stream, sigma, eps_n, N, groups, eps);
-    return launch_status();
-}
+int gz_sn_sigma_coef_floats(int groups) { return groups > 0 ? groups * SN_COEF_SLICES : 0; }
 
 int gz_sn_sigma_term(const float* rowsums, const float* rstd, const float* sigma, const float* u, const float* v,
                      float* coefs, float* term, int rows, int groups, int R, int L, float eps, hipStream_t stream) {
     gz::clear_stale_error();
-    if (!rowsums || !rstd || !sigma || !u || !v || !coefs || !term || rows <= 0 || groups <= 0 || rows % groups || R <= 0 ||
-        L <= 0 || (L & 3))
+    if (!rowsums || !rstd || !sigma || !u || !v || !coefs || !term || rows <= 0 || groups <= 0 || groups > 8 || rows % groups ||
+        R <= 0 || L <= 0 || (L & 3))
         return GZ_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL(sn_sigma_coef_kernel, dim3(groups), dim3(LT), 0, stream, reinterpret_cast<const f32x2*>(rowsums), rstd,
+    hipLaunchKernelGGL(sn_sigma_coef_kernel, dim3(groups, SN_COEF_SLICES), dim3(LT), 0, stream, reinterpret_cast<const f32x2*>(rowsums), rstd,
                        sigma, coefs, rows / groups, eps);
     const long long total4 = (long long)R * (L / 4);
     hipLaunchKernelGGL(sn_sigma_term_kernel, dim3(grid_for(total4)), dim3(LT), 0, stream, coefs, u, v, term, R, L / 4, groups,

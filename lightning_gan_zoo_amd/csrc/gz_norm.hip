@@ -211,7 +211,8 @@ __global__ __launch_bounds__(PW_THREADS) void rownorm_act_fused_kernel(const flo
                                                                        float* __restrict__ out, RowGeom g, int C,
                                                                        int inner, float eps, int affine_per_row,
                                                                        int unbiased, int act, float slope,
-                                                                       int x_rows, const float* __restrict__ eps_n) {
+                                                                       int x_rows, const float* __restrict__ sigma,
+                                                                       int sigma_rows) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * PW_THREADS + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * PW_THREADS) >> 6;
@@ -276,9 +277,15 @@ __global__ __launch_bounds__(PW_THREADS) void rownorm_act_fused_kernel(const flo
         double var = ((double)d[1] - (double)d[0] * (double)d[0] / cnt) / cnt;
         if (var < 0.0) var = 0.0;
         if (unbiased && inner > 1) var = var * cnt / (cnt - 1.0);
-        // eps_n (round 4): one eps per SAMPLE -- a spectral-normalised convolution's 1 / sigma folded into the
-        // InstanceNorm behind it (functional.sn_conv_in_act): IN_eps(y / sigma) = IN_{eps sigma^2}(y)
-        const float rstd = (float)(1.0 / sqrt(var + (double)(eps_n ? eps_n[r / C] : eps)));
+        // sigma (round 4): a spectral-normalised convolution's 1 / sigma folded into the InstanceNorm behind it
+        // (functional.sn_conv_in_act): IN_eps(y / sigma) = IN_{eps sigma^2}(y); sigma[g] belongs to rows [g, g + 1) *
+        // sigma_rows (the discriminator calls stacked along the batch)
+        float eps_r = eps;
+        if (sigma) {
+            const float sg = sigma[r / sigma_rows];
+            eps_r = eps * sg * sg;
+        }
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps_r));
         const int gi = affine_per_row == 2 ? (r / C) * 2 * C + r % C : (affine_per_row ? r : r % C);
         const float ga = gamma ? gamma[gi] : 1.f, be = beta ? beta[gi] : 0.f;
         const float sc = ga * rstd;
@@ -775,11 +782,11 @@ static bool norm_shape_ok(int N, int C, int inner) {
 static void launch_rownorm_fused(const float* x, const float* gamma, const float* beta, float* coef, float* out,
                                  const RowGeom& g, int C, int inner, float eps, int affine_per_row, int unbiased,
                                  int act, float slope, hipStream_t stream, int x_rows = 0,
-                                 const float* eps_n = nullptr) {
+                                 const float* sigma = nullptr, int sigma_rows = 1) {
     const int per_lane = (g.q4 + g.lpr - 1) / g.lpr;      // float4 per lane
 #define GZ_RN(CACHE)                                                                                               \
     hipLaunchKernelGGL(rownorm_act_fused_kernel<CACHE>, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, gamma, \
-                       beta, coef, out, g, C, inner, eps, affine_per_row, unbiased, act, slope, x_rows, eps_n)
+                       beta, coef, out, g, C, inner, eps, affine_per_row, unbiased, act, slope, x_rows, sigma, sigma_rows)
     if (per_lane <= 1) GZ_RN(1);
     else if (per_lane <= 4) GZ_RN(4);
     else if (per_lane <= 16) GZ_RN(16);
@@ -877,12 +884,13 @@ int gz_rownorm_act_fwd(const float* x, const float* gamma, const float* beta, fl
     return launch_status();
 }
 
-int gz_rownorm_act_fwd_eps(const float* x, const float* eps_n, float* coef, float* out, int N, int C, int inner, int act,
-                           float slope, hipStream_t stream) {
+int gz_rownorm_act_fwd_sigma(const float* x, const float* sigma, int groups, float* coef, float* out, int N, int C,
+                             int inner, float eps, int act, float slope, hipStream_t stream) {
     gz::clear_stale_error();
-    if (!norm_shape_ok(N, C, inner) || !eps_n) return GZ_ERR_BAD_SHAPE;
+    if (!norm_shape_ok(N, C, inner) || !sigma || groups <= 0 || N % groups) return GZ_ERR_BAD_SHAPE;
     RowGeom g = row_geom((long long)N * C, inner);
-    launch_rownorm_fused(x, nullptr, nullptr, coef, out, g, C, inner, 0.f, 0, 0, act, slope, stream, 0, eps_n);
+    launch_rownorm_fused(x, nullptr, nullptr, coef, out, g, C, inner, eps, 0, 0, act, slope, stream, 0, sigma,
+                         (N / groups) * C);
     return launch_status();
 }
 

@@ -1875,13 +1875,10 @@ class _SNConvINAct(torch.autograd.Function):
         N = x.shape[0]
         y = _conv_fwd_raw(x, W, None, geom, ACT_NONE, 0.0)
         C, inner = y.shape[1], y.shape[2] * y.shape[3]
-        st = _stream()
-        eps_n = torch.empty(N, device=x.device, dtype=torch.float32)
-        check(lib.gz_sn_sample_eps(_p(sigma), _p(eps_n), N, groups, in_eps, st), "sn_sample_eps")
         coef = torch.empty(4 * N * C, device=x.device, dtype=torch.float32)
         out = torch.empty_like(y)
-        check(lib.gz_rownorm_act_fwd_eps(_p(y), _p(eps_n), _p(coef), _p(out), N, C, inner, act, slope, st),
-              "rownorm_act_fwd_eps")
+        check(lib.gz_rownorm_act_fwd_sigma(_p(y), _p(sigma), groups, _p(coef), _p(out), N, C, inner, in_eps, act, slope,
+                                           _stream()), "rownorm_act_fwd_sigma")
         ctx.save_for_backward(x, W, y, coef, sigma, us, vs)
         ctx.cfg = (geom, in_eps, act, slope, groups, bias is not None)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
@@ -1906,7 +1903,7 @@ class _SNConvINAct(torch.autograd.Function):
         dW = None
         if ctx.needs_input_grad[1]:
             R, L = W.shape[0], W.numel() // W.shape[0]
-            coefs = torch.empty(groups, device=y.device, dtype=torch.float32)
+            coefs = torch.empty(lib.gz_sn_sigma_coef_floats(groups), device=y.device, dtype=torch.float32)
             term = torch.empty_like(W)
             check(lib.gz_sn_sigma_term(_p(rowsums), _p(coef[3 * N * C:]), _p(sigma), _p(us), _p(vs), _p(coefs), _p(term),
                                        N * C, groups, R, L, in_eps, st), "sn_sigma_term")
