@@ -89,28 +89,35 @@ constexpr int FW_LC = 4;
 __global__ __launch_bounds__(RS_THREADS) void resample_fwd_staged_kernel(const float* __restrict__ vox,
                                                                          const float* __restrict__ minv,
                                                                          float* __restrict__ out, int N, int C, int S) {
-    extern __shared__ __attribute__((aligned(16))) float vl[];      // [FW_LC][S^3]
+    // [S^3][FW_LC], channels interleaved (round 4): a corner's FW_LC channel values are ONE 16-byte LDS read instead of
+    // FW_LC scattered 4-byte ones -- the gathers' bank conflicts, not HBM, set this kernel's pace (111 us for 134 MB)
+    static_assert(FW_LC == 4, "one f32x4 per corner");
+    extern __shared__ __attribute__((aligned(16))) float vl[];
     const int S3 = S * S * S;
     const int n = blockIdx.x;
     const int c0 = blockIdx.y * FW_LC;
     const int lc = min(FW_LC, C - c0);
     const float* src = vox + ((long long)n * C + c0) * S3;
-    for (int i = threadIdx.x * 4; i < lc * S3; i += RS_THREADS * 4)
-        *reinterpret_cast<f32x4*>(vl + i) = *reinterpret_cast<const f32x4*>(src + i);
+    for (int i = threadIdx.x * 4; i < FW_LC * S3; i += RS_THREADS * 4) {
+        const int j = i / S3, u = i - j * S3;            // (S^3 is a multiple of 4: a float4 stays inside one channel)
+        const f32x4 v = j < lc ? *reinterpret_cast<const f32x4*>(src + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        vl[(u + 0) * FW_LC + j] = v[0];
+        vl[(u + 1) * FW_LC + j] = v[1];
+        vl[(u + 2) * FW_LC + j] = v[2];
+        vl[(u + 3) * FW_LC + j] = v[3];
+    }
     __syncthreads();
     const float* m = minv + n * 16;
+    const f32x4* vq = reinterpret_cast<const f32x4*>(vl);
     for (int r = threadIdx.x; r < S3; r += RS_THREADS) {
         const int z = r / (S * S), y = (r / S) % S, x = r % S;
         Corner8 cn = corners(m, x, y, z, S);
+        f32x4 acc = vq[cn.off[0]] * cn.w[0];
 #pragma unroll
-        for (int j = 0; j < FW_LC; ++j) {
-            if (j >= lc) break;
-            const float* sv = vl + j * S3;
-            float acc = cn.w[0] * sv[cn.off[0]];
+        for (int k = 1; k < 8; ++k) acc = acc + vq[cn.off[k]] * cn.w[k];       // same order as resample_fwd_kernel
 #pragma unroll
-            for (int k = 1; k < 8; ++k) acc += cn.w[k] * sv[cn.off[k]];       // same order as resample_fwd_kernel
-            out[(((long long)n * C * S + (long long)(c0 + j) * S + (S - 1 - y)) * S + z) * S + x] = acc;
-        }
+        for (int j = 0; j < FW_LC; ++j)
+            if (j < lc) out[(((long long)n * C * S + (long long)(c0 + j) * S + (S - 1 - y)) * S + z) * S + x] = acc[j];
     }
 }
 
@@ -320,28 +327,35 @@ __global__ __launch_bounds__(RS_THREADS) void resample_bwd_staged_kernel(const f
                                                                          const float* __restrict__ hw,
                                                                          const int* __restrict__ overflow,
                                                                          float* __restrict__ gvox, int N, int C, int S) {
-    extern __shared__ __attribute__((aligned(16))) float gl[];      // [LC][S^3]
+    static_assert(LC == 4, "one f32x4 per hit");
+    extern __shared__ __attribute__((aligned(16))) float gl[];      // [S^3][LC], channels interleaved (see the forward)
     if (*overflow) return;                 // the launcher re-runs this gradient with the gather kernel
     const int S3 = S * S * S;
     const int n = blockIdx.x;
     const int c0 = blockIdx.y * LC;
     const int lc = min(LC, C - c0);
     const float* src = gout + ((long long)n * C + c0) * S3;
-    for (int i = threadIdx.x * 4; i < lc * S3; i += RS_THREADS * 4)
-        *reinterpret_cast<f32x4*>(gl + i) = *reinterpret_cast<const f32x4*>(src + i);
+    for (int i = threadIdx.x * 4; i < LC * S3; i += RS_THREADS * 4) {
+        const int j = i / S3, u = i - j * S3;
+        const f32x4 v = j < lc ? *reinterpret_cast<const f32x4*>(src + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        gl[(u + 0) * LC + j] = v[0];
+        gl[(u + 1) * LC + j] = v[1];
+        gl[(u + 2) * LC + j] = v[2];
+        gl[(u + 3) * LC + j] = v[3];
+    }
     __syncthreads();
     const long long NS3 = (long long)N * S3;
+    const f32x4* gq = reinterpret_cast<const f32x4*>(gl);
     for (int u = threadIdx.x; u < S3; u += RS_THREADS) {
         const long long slot = (long long)n * S3 + u;
-        float acc[LC];
-#pragma unroll
-        for (int j = 0; j < LC; ++j) acc[j] = 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int cnt = hoff[BH * NS3 + slot];
         for (int k = 0; k < cnt; ++k) {
             const int off = hoff[k * NS3 + slot];
             const float w = hw[k * NS3 + slot];
+            const f32x4 g4 = gq[off];
 #pragma unroll
-            for (int j = 0; j < LC; ++j) acc[j] = fmaf(w, gl[j * S3 + off], acc[j]);
+            for (int j = 0; j < LC; ++j) acc[j] = fmaf(w, g4[j], acc[j]);
         }
 #pragma unroll
         for (int j = 0; j < LC; ++j)
