@@ -56,10 +56,11 @@ class BasicBlock(nn.Module):
         """style: this block's zMapping(z) when the caller already has it (Generator.forward maps z through all five
         ZMapping layers in one launch)."""
         ct = self.convTranspose
+        # (the AdaIN below normalises every (sample, channel) plane: the bias cannot reach the loss, its gradient is 0)
         if self.transpose_dim == 2:
-            h = F.conv_transpose2d(h, ct.weight, ct.bias, F.K4S2P1)
+            h = F.conv_transpose2d(h, ct.weight, ct.bias, F.K4S2P1, bias_cancels=True)
         else:
-            h = F.conv_transpose3d(h, ct.weight, ct.bias)
+            h = F.conv_transpose3d(h, ct.weight, ct.bias, bias_cancels=True)
         return F.adain_act_packed(h, self.zMapping(z) if style is None else style, 1e-8, F.ACT_RELU)
 
 

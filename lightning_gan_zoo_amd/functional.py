@@ -735,10 +735,11 @@ class _ConvDg(torch.autograd.Function):
     """x = act(conv_transpose2d(g, w) + bias): ConvTranspose2d forward and Conv2d input gradient."""
 
     @staticmethod
-    def forward(ctx, g, w, bias, geom, hw, act, slope, want_stats=False):
+    def forward(ctx, g, w, bias, geom, hw, act, slope, want_stats=False, bias_cancels=False):
         g, w = _req(g, "g"), _req(w, "w")
         ctx.geom, ctx.act, ctx.slope = geom, act, slope
         ctx.has_bias = bias is not None
+        ctx.bias_cancels = bias_cancels      # the caller normalises the output per (sample, channel): d/d bias == 0
         _sink_note_use(w)
         _sink_note_use(bias)
         ctx.bias_ref = bias if isinstance(bias, torch.nn.Parameter) else None
@@ -757,7 +758,7 @@ class _ConvDg(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v, *_stats_grad):
         if v is None:
-            return (None,) * 8
+            return (None,) * 9
         g, w, x = ctx.saved_tensors
         geom = ctx.geom
         if ctx.act != ACT_NONE:
@@ -769,10 +770,13 @@ class _ConvDg(torch.autograd.Function):
             if ctx.needs_input_grad[1] and not _sink_conv_wgrad(w, v, g, geom):
                 dw = _conv_wgrad_raw(v, g, geom)
                 _sink_done(w)
-            db = _channel_sum_raw(v) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            db = None
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = (torch.zeros(v.shape[1], device=v.device, dtype=torch.float32) if ctx.bias_cancels
+                      else _channel_sum_raw(v))
             if db is not None and ctx.bias_ref is not None:
                 db = _sink_or_return(ctx.bias_ref, db)
-            return dg, dw, db, None, None, None, None, None
+            return dg, dw, db, None, None, None, None, None, None
         dg = dw = db = None
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
             dg, dw = _pair_wgrad_dgrad(lambda: _ConvWg.apply(v, g, geom),
@@ -786,7 +790,7 @@ class _ConvDg(torch.autograd.Function):
             _sink_done(ctx.bias_ref)
         if ctx.needs_input_grad[1]:
             _sink_done(w)
-        return dg, dw, db, None, None, None, None, None
+        return dg, dw, db, None, None, None, None, None, None
 
 
 class _ConvWg(torch.autograd.Function):
@@ -814,12 +818,15 @@ def conv2d(x, w, bias=None, geom=K4S2P1, act=ACT_NONE, slope=0.0):
     return _ConvF.apply(x, w, bias, geom, act, slope)
 
 
-def conv_transpose2d(x, w, bias=None, geom=K4S2P1, act=ACT_NONE, slope=0.0):
-    """w is the ConvTranspose2d weight [Cin, Cout, KH, KW]; output size (H-1)*S - 2P + KH."""
+def conv_transpose2d(x, w, bias=None, geom=K4S2P1, act=ACT_NONE, slope=0.0, bias_cancels=False):
+    """w is the ConvTranspose2d weight [Cin, Cout, KH, KW]; output size (H-1)*S - 2P + KH.
+    bias_cancels: the caller feeds the output straight into a normalisation over each (sample, channel) plane (AdaIN,
+    InstanceNorm), which removes a per-channel constant -- the bias gradient is exactly zero and is returned as such
+    (a first-order backward skips the two reduction launches; the reference's value is rounding noise)."""
     H, W = x.shape[2:]
     oh = (H - 1) * geom.stride - 2 * geom.pad + geom.kh
     ow = (W - 1) * geom.stride - 2 * geom.pad + geom.kw
-    return _ConvDg.apply(x, w, bias, geom, (oh, ow), act, slope)
+    return _ConvDg.apply(x, w, bias, geom, (oh, ow), act, slope, False, bias_cancels)
 
 
 def conv2d_with_stats(x, w, geom=K4S2P1):
@@ -1369,10 +1376,11 @@ class _Conv3DDg(torch.autograd.Function):
     """x = conv_transpose3d(g, w) + bias   (k3, s2, p1, output_padding 1)"""
 
     @staticmethod
-    def forward(ctx, g, w, bias):
+    def forward(ctx, g, w, bias, bias_cancels=False):
         g, w = _req(g, "g"), _req(w, "w")
         ctx.save_for_backward(g, w)
         ctx.has_bias = bias is not None
+        ctx.bias_cancels = bias_cancels
         return _conv3d_dgrad_raw(g, w, bias, ACT_NONE, 0.0)
 
     @staticmethod
@@ -1383,8 +1391,11 @@ class _Conv3DDg(torch.autograd.Function):
         dw = _Conv3DWg.apply(v, g, w.shape[2]) if ctx.needs_input_grad[1] else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _ChannelSum.apply(v) if torch.is_grad_enabled() else _channel_sum_raw(v)
-        return dg, dw, db
+            if ctx.bias_cancels and not torch.is_grad_enabled():
+                db = torch.zeros(v.shape[1], device=v.device, dtype=torch.float32)
+            else:
+                db = _ChannelSum.apply(v) if torch.is_grad_enabled() else _channel_sum_raw(v)
+        return dg, dw, db, None
 
 
 class _Conv3DF(torch.autograd.Function):
@@ -1398,7 +1409,7 @@ class _Conv3DF(torch.autograd.Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gy = _req(gy)
-        dx = _Conv3DDg.apply(gy, w, None) if ctx.needs_input_grad[0] else None
+        dx = _Conv3DDg.apply(gy, w, None, False) if ctx.needs_input_grad[0] else None
         dw = _Conv3DWg.apply(x, gy, w.shape[2]) if ctx.needs_input_grad[1] else None
         return dx, dw
 
@@ -1414,14 +1425,15 @@ class _Conv3DWg(torch.autograd.Function):
     def backward(ctx, v):
         x, g = ctx.saved_tensors
         v = _req(v)
-        dx = _Conv3DDg.apply(g, v, None) if ctx.needs_input_grad[0] else None
+        dx = _Conv3DDg.apply(g, v, None, False) if ctx.needs_input_grad[0] else None
         dg = _Conv3DF.apply(x, v) if ctx.needs_input_grad[1] else None
         return dx, dg, None
 
 
-def conv_transpose3d(x, w, bias=None):
-    """nn.ConvTranspose3d(kernel 3, stride 2, padding 1, output_padding 1); w [Cin, Cout, 3, 3, 3]."""
-    return _Conv3DDg.apply(x, w, bias)
+def conv_transpose3d(x, w, bias=None, bias_cancels=False):
+    """nn.ConvTranspose3d(kernel 3, stride 2, padding 1, output_padding 1); w [Cin, Cout, 3, 3, 3]; bias_cancels as in
+    conv_transpose2d."""
+    return _Conv3DDg.apply(x, w, bias, bias_cancels)
 
 
 class _AdaINAct(torch.autograd.Function):
