@@ -188,3 +188,47 @@ def test_hologan_bs64_batch_consistency(img):
     assert max(v for k, v in worst.items() if k.startswith("grad D.") and k != "grad D.input") <= 2.5e-3, top
     assert worst["grad D.input"] <= 1e-2, top
     assert max(v for k, v in worst.items() if not k.startswith("grad D.")) <= TOL, top
+
+
+@pytest.mark.parametrize("img", [64, 128])
+def test_hologan_bs64_stacked_critic_step_matches_two_calls(img):
+    """The benchmarked HoloGAN D step (in_planes 64, z 128, bs 64; ``img`` 128 = EXT-128) in training mode: ONE critic
+    pass over [real; fake] with one sigma per half (the default) against two calls, both through the fused
+    spectral-norm blocks -- the same power iterations, the same per-sample InstanceNorm, the pair loss against the two
+    BCE means.  Loss and spectral-norm buffers to rounding; gradients up to the LeakyReLU entries that two summation
+    orders (128-row vs 64-row tiles) put on different sides of zero (2.5e-3 per entry, see the test above)."""
+    import numpy as np
+    from helpers import FixedNoise
+    res = {}
+    for stacked in (True, False):
+        cfg = make_cfg("hologan", batch_size=64, features=64, noise_dim=128, img_size=img)
+        torch.manual_seed(42)
+        step = locate(cfg.model.lm["_target_"])(cfg, None)
+        scenario._prepare(step, True)
+        step.to("cuda")
+        step.stack_d_passes = stacked
+        step.real_first = False
+        g = torch.Generator().manual_seed(77)
+        step.noise_distn = FixedNoise(torch.rand(64, 128, generator=g) * 2 - 1)
+        real = (torch.rand(64, 3, img, img, generator=g) * 1.8 - 0.9).cuda()
+        labels = torch.zeros(64, dtype=torch.int64, device="cuda")
+        np.random.seed(5)
+        scenario._toggle(step, 0)
+        step.zero_grad(set_to_none=True)
+        loss = step.training_step((real, labels), 0, 0)
+        loss.backward()
+        res[stacked] = (float(loss.detach()), {n: p.grad.detach().clone() for n, p in step.discriminator.named_parameters()},
+                        {n: b.detach().clone() for n, b in step.discriminator.named_buffers()})
+    (la, ga, ba), (lb, gb, bb) = res[True], res[False]
+    assert abs(la - lb) <= 1e-5 * max(1.0, abs(lb)), (la, lb)
+    for n in bb:
+        assert float((ba[n] - bb[n]).norm() / bb[n].norm().clamp_min(1e-30)) <= 1e-5, n
+    worst = {}
+    for n in gb:
+        if n.startswith("blocks.") and n.endswith("conv2d.bias"):
+            assert float(ga[n].abs().max()) == 0.0 and float(gb[n].abs().max()) == 0.0
+            continue
+        worst[n] = float((ga[n] - gb[n]).norm() / gb[n].norm().clamp_min(1e-30))
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    print(f"hologan {img}x{img} bs64 stacked vs two calls:", [(k, f"{v:.1e}") for k, v in top])
+    assert top[0][1] <= 5e-3, top
