@@ -74,6 +74,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay each optimizer step from a captured HIP graph (single GPU)")
+    ap.add_argument("--no-gradsync-w1", action="store_true",
+                    help="skip the single-rank-RCCL GradSync sub-records of the default run")
     ap.add_argument("--force-grad-sync", action="store_true",
                     help="use the data-parallel gradient path (flat buffers, deferred step) even on one rank")
     args = ap.parse_args(argv)
@@ -221,20 +223,34 @@ def cpu_baseline(batch=128, budget_s=14.0):
                       % (batch, best[1], avail, len(times), med * 1e3)}
 
 
+_TRAFFIC = None
+
+
 def load_traffic(config_key, label):
-    """HBM bytes per launch of kernel ``label`` in configuration ``config_key`` from the round's PMC passes
+    """(HBM bytes per launch of kernel ``label`` in configuration ``config_key``, stale) from the round's PMC passes
     (profiles/traffic.json, written by tools/pmc_traffic.py from two separate ``rocprofv3 --pmc`` runs of this same
-    command: counters cannot be collected inside a timed run).  None when that configuration was not profiled."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+    command: counters cannot be collected inside a timed run).  The file carries the digest of the kernel sources it
+    was measured on (``_source_digest``, = the library's gz_source_digest()); ``stale`` is True when the library that is
+    running now was built from other sources -- the number then describes an earlier kernel.  (None, None) when that
+    configuration was not profiled."""
+    global _TRAFFIC
+    if _TRAFFIC is None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                _TRAFFIC = json.load(f)
+        except Exception:  # noqa: BLE001
+            _TRAFFIC = {}
+    per_cfg = _TRAFFIC.get(config_key)
+    if not isinstance(per_cfg, dict) or label not in per_cfg:
+        return None, None
     try:
-        with open(path) as f:
-            tab = json.load(f)
+        from lightning_gan_zoo_amd._lib import lib
+        now = lib.gz_source_digest().decode()
     except Exception:  # noqa: BLE001
-        return None
-    per_cfg = tab.get(config_key)
-    if isinstance(per_cfg, dict):
-        return per_cfg.get(label)
-    return None
+        now = None
+    measured_on = (_TRAFFIC.get("_source_digest") or {})
+    measured_on = measured_on.get(config_key) if isinstance(measured_on, dict) else measured_on
+    return per_cfg[label], (measured_on is None or now is None or measured_on != now)
 
 
 def roofline_of(timer, ms_per_step, steps, flop_cycle, config_key=None):
@@ -246,10 +262,11 @@ def roofline_of(timer, ms_per_step, steps, flop_cycle, config_key=None):
     total_ms = sum(v[1] for v in agg.values())
     label, (n, ms, fl) = max(agg.items(), key=lambda kv: kv[1][1])
     achieved = fl / (ms * 1e-3) / 1e12
+    traffic, stale = load_traffic(config_key, label)
     return {
         "bound": "mfma", "kernel": label, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-        "traffic": load_traffic(config_key, label),
+        "traffic": traffic, "traffic_stale": stale,
         "launches": n, "avg_launch_ms": round(ms / n, 4),
         "sampled_cycles": sampled_cycles,
         "share_of_step": round(ms / (ms_per_step * sampled_cycles), 3),
@@ -310,7 +327,8 @@ def measure(F, expt, batch, img_size, device, rank, world, steps, warmup, reps, 
            "per_rank_ms_per_step": [round(t / steps * 1e3, 3) for t in per_rank]}
     if sync is not None:
         rec["grad_exchange"] = {"buckets": [[(e - s0) * 4 for s0, e, _, _ in fg.buckets] for fg in sync.flats],
-                                **sync.stats}
+                                "deferred_tail_buckets": [sorted(fg.tail_buckets) for fg in sync.flats],
+                                "per_layer_gates": list(sync.lazy), **sync.stats}
         if sync.measure:
             # how much of the exchange was EXPOSED on this rank: time the compute stream sat behind a gradient bucket
             # that had not been reduced yet (events around every wait), per optimizer cycle of the timed region
@@ -342,6 +360,54 @@ def measure(F, expt, batch, img_size, device, rank, world, steps, warmup, reps, 
     gc.collect()
     torch.cuda.empty_cache()
     return rec
+
+
+class single_rank_rccl:
+    """A one-rank RCCL communicator with GZ_DDP_ALWAYS_REDUCE (ddp.GradSync then really issues its all-reduces) and
+    GZ_DDP_MEASURE (events around every wait for a bucket): the data-parallel code path on one GPU."""
+    KEYS = ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "GZ_DDP_ALWAYS_REDUCE", "GZ_DDP_MEASURE")
+
+    def __init__(self, device):
+        self.device = device
+
+    def __enter__(self):
+        import torch.distributed as dist
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        self.saved = {k: os.environ.get(k) for k in self.KEYS}
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                          GZ_DDP_ALWAYS_REDUCE="1", GZ_DDP_MEASURE="1")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=self.device)
+        return self
+
+    def __exit__(self, *exc):
+        import torch.distributed as dist
+        dist.destroy_process_group()
+        for k, v in self.saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        return False
+
+
+def gradsync_w1_records(F, args, device, use_timer, out, head_key):
+    """dc_gan bs 128 and bs 512 under ddp.GradSync over RCCL at world size 1 (GZ_DDP_ALWAYS_REDUCE: the collective is
+    really issued).  The numbers price the data-parallel machinery itself; an N > 1 run adds the wire time."""
+    recs = {}
+    with single_rank_rccl(device):
+        for key, bs in (("dc_gan_bs128", 128), ("dc_gan_bs512", 512)):
+            rec = measure(F, "dc_gan", bs, 64, device, 0, 1, args.steps, args.warmup, args.reps, use_timer,
+                          force_sync=True)
+            plain = out if key == head_key else out["sub_configs"].get(key)
+            if plain is not None:
+                rec["vs_plain"] = round(rec["ms_per_step"] / plain["ms_per_step"], 4)
+                rec["plain_ms_per_step"] = plain["ms_per_step"]
+            rec["transport"] = "RCCL, single-rank communicator (world 1): code-path cost, no wire time"
+            recs[key + "_gradsync_w1"] = rec
+    return recs
 
 
 def run_rank(args):
@@ -378,11 +444,14 @@ def run_rank(args):
 
     # the host side of the step is launch-only; a big OpenMP team only burns the container's CPU quota
     torch.set_num_threads(min(8, torch.get_num_threads()))
-    if args.force_grad_sync and world == 1 and not dist.is_initialized() and "RANK" in os.environ:
-        dist.init_process_group("nccl", device_id=device)
     use_timer = not args.no_kernel_timer
-    head = measure(F, args.expt, args.batch, args.img_size, device, rank, world, args.steps, args.warmup, args.reps,
-                   use_timer, args.force_grad_sync, args.graph)
+    if args.force_grad_sync and world == 1:       # the headline itself on the data-parallel code path (profiling runs)
+        with single_rank_rccl(device):
+            head = measure(F, args.expt, args.batch, args.img_size, device, rank, world, args.steps, args.warmup,
+                           args.reps, use_timer, True, args.graph)
+    else:
+        head = measure(F, args.expt, args.batch, args.img_size, device, rank, world, args.steps, args.warmup, args.reps,
+                       use_timer, args.force_grad_sync, args.graph)
     head_key = config_key_of(args.expt, args.batch, args.img_size)
 
     out = {
@@ -425,6 +494,15 @@ def run_rank(args):
             steps = args.steps if expt == "dc_gan" else min(args.steps, args.sub_steps)
             out["sub_configs"][key] = measure(F, expt, bs, img, device, rank, world, steps, args.warmup, args.reps,
                                               use_timer)
+        if world == 1 and not args.force_grad_sync and not args.no_gradsync_w1:
+            # The data-parallel CODE PATH on this one GPU: the same dc_gan trainer under
+            # ddp.GradSync with a single-rank RCCL communicator -- flat gradient buffers, per-parameter hooks, bucketed
+            # all-reduce calls on RCCL's stream, per-bucket optimizer steps at the layer gates, the deferred tail -- so
+            # that every driver run times it next to the plain trainer (``vs_plain`` = this / plain ms per pair).
+            try:
+                out["sub_configs"].update(gradsync_w1_records(F, args, device, use_timer, out, head_key))
+            except Exception as e:  # noqa: BLE001 -- a broken RCCL install must not take the headline number with it
+                out["sub_configs"]["dc_gan_bs128_gradsync_w1"] = {"error": "%s: %s" % (type(e).__name__, e)}
         big = out["sub_configs"].get("dc_gan_bs512")
         if big is not None and rank == 0:
             w = (big.get("roofline") or {}).get("whole_step") or {}

@@ -391,6 +391,9 @@ int gz_colsum(const float* x, float* out, int R, int L, hipStream_t stream);
 size_t gz_coldot_workspace_bytes(int R, int L);
 int gz_coldot(const float* g, const float* x, float* out, float* workspace, size_t ws_bytes, int R, int L,
               hipStream_t stream);
+/* dst[i] = src[i] for `words` 4-byte words; src may be PINNED HOST memory (device-mapped): the staging of the per-step
+ * host draws -- `noise = distn.sample(...).to(device)`, core/lightning_module.py:107-108, core/utils/utils.py:41 */
+int gz_copy_words(const void* src, void* dst, long long words, hipStream_t stream);
 /* p = clamp(p, lo, hi) in place (core/lightning_module.py:160-162) */
 int gz_clamp_(float* p, long long count, float lo, float hi, hipStream_t stream);
 
@@ -421,19 +424,22 @@ int gz_u8hwc_to_nchw(const unsigned char* in, float* out, int N, int H, int W, i
 /* ---- fused multi-tensor optimizer steps (the `optimiser` nodes of conf/expt/<name>.yaml) -------------------------
  * `count` <= GZ_OPT_MAX_TENSORS tensors per call (host arrays of device pointers and element counts);
  * grads are multiplied by grad_scale first (1/world for data-parallel means).  Formulas are torch.optim's
- * single-tensor ones (no weight decay, no amsgrad / momentum / centered). */
+ * single-tensor ones (no weight decay, no amsgrad / momentum / centered).
+ * zero_grads != 0: every gradient element is overwritten with 0 after it has been read -- the zero_grad(set_to_none=
+ * False) of the reference's harness in the same pass (the flat data-parallel exchange buffer must read zero again). */
 #define GZ_OPT_MAX_TENSORS 24
-int gz_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+int gz_adam_step(int count, float* const* params, float* const* grads, float* const* exp_avg,
                  float* const* exp_avg_sq, const long long* numel, float lr, float beta1, float beta2, float eps,
-                 int step, float grad_scale, hipStream_t stream);
+                 int step, float grad_scale, int zero_grads, hipStream_t stream);
 /* graph-capturable Adam: tick = device float[3] {step, 1 - beta1^step, sqrt(1 - beta2^step)}; gz_adam_tick advances
  * it by one step, gz_adam_step_dev reads the corrections from it (same update as gz_adam_step) */
 int gz_adam_tick(float* tick, float beta1, float beta2, hipStream_t stream);
-int gz_adam_step_dev(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+int gz_adam_step_dev(int count, float* const* params, float* const* grads, float* const* exp_avg,
                      float* const* exp_avg_sq, const long long* numel, float lr, float beta1, float beta2, float eps,
-                     const float* tick, float grad_scale, hipStream_t stream);
-int gz_rmsprop_step(int count, float* const* params, const float* const* grads, float* const* square_avg,
-                    const long long* numel, float lr, float alpha, float eps, float grad_scale, hipStream_t stream);
+                     const float* tick, float grad_scale, int zero_grads, hipStream_t stream);
+int gz_rmsprop_step(int count, float* const* params, float* const* grads, float* const* square_avg,
+                    const long long* numel, float lr, float alpha, float eps, float grad_scale, int zero_grads,
+                    hipStream_t stream);
 
 /* text of the last HIP error seen by a launcher on the calling thread ("" if none) */
 const char* gz_last_error(void);

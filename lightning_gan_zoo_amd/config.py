@@ -95,6 +95,7 @@ def _base(root):
         "loss_weight": {},
         "debug": {"verbose_shape": False, "fast_dev_run": False},
         "precision": 32,   # reference default is 16 (AMP); the parity target is fp32
+        "accumulate_grad_batches": 1,      # conf/config.yaml:57; conf/machine/*.yaml: {start_epoch, accumulation_factor}
     }
 
 

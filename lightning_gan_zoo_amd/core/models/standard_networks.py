@@ -34,11 +34,12 @@ class _GBlock(nn.Module):
     def forward(self, x):
         w = self.transpose_conv.weight
         bn = self.batch_norm
+        F.ready(w, bn.weight, bn.bias)      # data parallel: this layer's gradient bucket + optimizer step have landed
         training = bn.training or bn.running_mean is None
         stats = None
         if self.stride == 1 and self.padding == 0 and x.shape[2] == 1 and x.shape[3] == 1:
             n = x.shape[0]
-            y = F.matmul(x.reshape(n, -1), w.view(w.shape[0], -1)).view(n, w.shape[1], 4, 4)
+            y = F.matmul(x.reshape(n, -1), w.view(w.shape[0], -1), w).view(n, w.shape[1], 4, 4)
         elif self.stride == 2 and self.padding == 1:
             if training:        # the transposed convolution's epilogue also emits the BatchNorm partial sums
                 y, stats = F.conv_transpose2d_with_stats(x, w, F.K4S2P1)
@@ -67,6 +68,7 @@ class _DBlock(nn.Module):
 
     def forward(self, x, groups=1):
         slope = self.leaky_relu.negative_slope
+        F.ready(*self.parameters())
         if self.norm == "batch_norm":
             bn = self.batch_norm
             stats = None
@@ -86,11 +88,13 @@ class _DBlock(nn.Module):
 
 class _DiscStack(nn.Sequential):
     def forward(self, x, groups=1):
+        F.ready(self.conv_in.weight)
         x = F.conv2d(x, self.conv_in.weight, None, F.K4S2P1, F.ACT_LRELU, self.leaky_relu.negative_slope)
         for name, m in self.named_children():
             if name.startswith("block"):
                 x = m(x, groups)
         w = self.conv_out.weight
+        F.ready(w)
         if tuple(x.shape[2:]) != tuple(w.shape[2:]):
             raise RuntimeError("conv_out expects a %dx%d map, got %s" % (w.shape[2], w.shape[3], tuple(x.shape)))
         x = F.full_dot_conv(x, w)
@@ -101,6 +105,7 @@ class _DiscStack(nn.Sequential):
 
 class Discriminator(nn.Module):
     supports_stacked_batches = True      # forward(x, groups=G): G batches stacked along n, own BatchNorm statistics each
+    gates_parameters = True              # every layer announces its parameters with F.ready before reading them
 
     def __init__(self, channels_img, features_d, norm="batch_norm", img_size=64, final_sigmoid=True):
         super().__init__()
@@ -129,10 +134,13 @@ class _GenStack(nn.Sequential):
         for name, m in self.named_children():
             if name.startswith("block"):
                 x = m(x)
+        F.ready(self.transpose_conv_out.weight)
         return F.conv_transpose2d(x, self.transpose_conv_out.weight, None, F.K4S2P1, F.ACT_TANH, 0.0)
 
 
 class Generator(nn.Module):
+    gates_parameters = True              # see Discriminator
+
     def __init__(self, channels_noise, channels_img, features_g, img_size=64):
         super().__init__()
         n_blocks = int(math.log2(img_size / 4))

@@ -15,12 +15,15 @@ constexpr int OPT_CHUNK = 4096;     // elements per workgroup
 
 struct OptTable {
     float* p[OPT_MAX];
-    const float* g[OPT_MAX];
+    float* g[OPT_MAX];
     float* m[OPT_MAX];
     float* v[OPT_MAX];
     long long n[OPT_MAX];
     int first_block[OPT_MAX + 1];   // prefix sum of chunk counts
     int count;
+    int vec4;                       // every tensor's four arrays are 16-byte aligned: float4 loads / stores
+    int zero_grads;                 // write 0 over each gradient after reading it (== optimizer.zero_grad(set_to_none=
+                                    // False) in the same pass: the flat data-parallel exchange buffer needs zeros again)
 };
 
 __device__ __forceinline__ int find_tensor(const OptTable& t, int block) {
@@ -29,28 +32,70 @@ __device__ __forceinline__ int find_tensor(const OptTable& t, int block) {
     return k;
 }
 
-__global__ __launch_bounds__(OPT_THREADS) void adam_kernel(OptTable t, float lr, float beta1, float beta2, float eps,
-                                                           float bc1, float bc2_sqrt, float grad_scale) {
+struct AdamCoef {
+    float beta1, beta2, eps, step_size, bc2_sqrt, grad_scale;
+};
+
+// No FMA contraction in the update formulas: the float4 and the scalar loop must round identically, so that stepping a
+// parameter inside one launch or another (whole optimizer vs one gradient bucket; aligned or not) gives the same bits.
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamCoef& c) {
+#pragma clang fp contract(off)
+    const float gv = g * c.grad_scale;
+    m = m + (gv - m) * (1.f - c.beta1);                        // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * c.beta2 + (1.f - c.beta2) * gv * gv;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+    p = p - c.step_size * (m / denom);                         // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+__device__ __forceinline__ void adam_chunk(const OptTable& t, const AdamCoef& c) {
     const int k = find_tensor(t, blockIdx.x);
     const long long base = (long long)(blockIdx.x - t.first_block[k]) * OPT_CHUNK;
     float* p = t.p[k];
-    const float* g = t.g[k];
+    float* g = t.g[k];
     float* m = t.m[k];
     float* v = t.v[k];
     const long long n = t.n[k];
-    const float step_size = lr / bc1;
-    for (int i = threadIdx.x; i < OPT_CHUNK; i += OPT_THREADS) {
-        long long e = base + i;
-        if (e >= n) break;
-        float gv = g[e] * grad_scale;
-        float mv = m[e];
-        mv = mv + (gv - mv) * (1.f - beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
-        float vv = v[e] * beta2 + (1.f - beta2) * gv * gv;   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-        float denom = sqrtf(vv) / bc2_sqrt + eps;
-        p[e] = p[e] - step_size * (mv / denom);              // param.addcdiv_(exp_avg, denom, value=-step_size)
-        m[e] = mv;
-        v[e] = vv;
+    if (t.vec4) {
+        for (int i = threadIdx.x * 4; i < OPT_CHUNK; i += OPT_THREADS * 4) {
+            const long long e = base + i;
+            if (e + 4 <= n) {
+                float4 pv = *reinterpret_cast<const float4*>(p + e);
+                const float4 gv = *reinterpret_cast<const float4*>(g + e);
+                float4 mv = *reinterpret_cast<const float4*>(m + e);
+                float4 vv = *reinterpret_cast<const float4*>(v + e);
+                adam_one(pv.x, gv.x, mv.x, vv.x, c);
+                adam_one(pv.y, gv.y, mv.y, vv.y, c);
+                adam_one(pv.z, gv.z, mv.z, vv.z, c);
+                adam_one(pv.w, gv.w, mv.w, vv.w, c);
+                *reinterpret_cast<float4*>(p + e) = pv;
+                *reinterpret_cast<float4*>(m + e) = mv;
+                *reinterpret_cast<float4*>(v + e) = vv;
+                if (t.zero_grads) *reinterpret_cast<float4*>(g + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                for (long long q = e; q < n; ++q) {
+                    float pv = p[q], mv = m[q], vv = v[q];
+                    adam_one(pv, g[q], mv, vv, c);
+                    p[q] = pv; m[q] = mv; v[q] = vv;
+                    if (t.zero_grads) g[q] = 0.f;
+                }
+            }
+        }
+        return;
     }
+    for (int i = threadIdx.x; i < OPT_CHUNK; i += OPT_THREADS) {
+        const long long e = base + i;
+        if (e >= n) break;
+        float pv = p[e], mv = m[e], vv = v[e];
+        adam_one(pv, g[e], mv, vv, c);
+        p[e] = pv; m[e] = mv; v[e] = vv;
+        if (t.zero_grads) g[e] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void adam_kernel(OptTable t, float lr, float beta1, float beta2, float eps,
+                                                           float bc1, float bc2_sqrt, float grad_scale) {
+    AdamCoef c{beta1, beta2, eps, lr / bc1, bc2_sqrt, grad_scale};
+    adam_chunk(t, c);
 }
 
 // Graph-capturable Adam: the step counter and the two bias corrections live in device memory
@@ -65,27 +110,15 @@ __global__ void adam_tick_kernel(float* tick, float beta1, float beta2) {
 
 __global__ __launch_bounds__(OPT_THREADS) void adam_dev_kernel(OptTable t, float lr, float beta1, float beta2, float eps,
                                                                const float* __restrict__ tick, float grad_scale) {
-    const int k = find_tensor(t, blockIdx.x);
-    const long long base = (long long)(blockIdx.x - t.first_block[k]) * OPT_CHUNK;
-    float* p = t.p[k];
-    const float* g = t.g[k];
-    float* m = t.m[k];
-    float* v = t.v[k];
-    const long long n = t.n[k];
-    const float step_size = lr / tick[1];
-    const float bc2_sqrt = tick[2];
-    for (int i = threadIdx.x; i < OPT_CHUNK; i += OPT_THREADS) {
-        long long e = base + i;
-        if (e >= n) break;
-        float gv = g[e] * grad_scale;
-        float mv = m[e];
-        mv = mv + (gv - mv) * (1.f - beta1);
-        float vv = v[e] * beta2 + (1.f - beta2) * gv * gv;
-        float denom = sqrtf(vv) / bc2_sqrt + eps;
-        p[e] = p[e] - step_size * (mv / denom);
-        m[e] = mv;
-        v[e] = vv;
-    }
+    AdamCoef c{beta1, beta2, eps, lr / tick[1], tick[2], grad_scale};
+    adam_chunk(t, c);
+}
+
+__device__ __forceinline__ void rmsprop_one(float& p, float g, float& v, float lr, float alpha, float eps, float gs) {
+#pragma clang fp contract(off)
+    const float gv = g * gs;
+    v = v * alpha + (1.f - alpha) * gv * gv;                   // square_avg.mul_(alpha).addcmul_(grad, grad, 1 - alpha)
+    p = p - lr * (gv / (sqrtf(v) + eps));                      // param.addcdiv_(grad, avg, value=-lr)
 }
 
 __global__ __launch_bounds__(OPT_THREADS) void rmsprop_kernel(OptTable t, float lr, float alpha, float eps,
@@ -93,23 +126,50 @@ __global__ __launch_bounds__(OPT_THREADS) void rmsprop_kernel(OptTable t, float 
     const int k = find_tensor(t, blockIdx.x);
     const long long base = (long long)(blockIdx.x - t.first_block[k]) * OPT_CHUNK;
     float* p = t.p[k];
-    const float* g = t.g[k];
+    float* g = t.g[k];
     float* v = t.v[k];
     const long long n = t.n[k];
+    if (t.vec4) {
+        for (int i = threadIdx.x * 4; i < OPT_CHUNK; i += OPT_THREADS * 4) {
+            const long long e = base + i;
+            if (e + 4 <= n) {
+                float4 pv = *reinterpret_cast<const float4*>(p + e);
+                const float4 gv = *reinterpret_cast<const float4*>(g + e);
+                float4 vv = *reinterpret_cast<const float4*>(v + e);
+                rmsprop_one(pv.x, gv.x, vv.x, lr, alpha, eps, grad_scale);
+                rmsprop_one(pv.y, gv.y, vv.y, lr, alpha, eps, grad_scale);
+                rmsprop_one(pv.z, gv.z, vv.z, lr, alpha, eps, grad_scale);
+                rmsprop_one(pv.w, gv.w, vv.w, lr, alpha, eps, grad_scale);
+                *reinterpret_cast<float4*>(p + e) = pv;
+                *reinterpret_cast<float4*>(v + e) = vv;
+                if (t.zero_grads) *reinterpret_cast<float4*>(g + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                for (long long q = e; q < n; ++q) {
+                    float pv = p[q], vv = v[q];
+                    rmsprop_one(pv, g[q], vv, lr, alpha, eps, grad_scale);
+                    p[q] = pv; v[q] = vv;
+                    if (t.zero_grads) g[q] = 0.f;
+                }
+            }
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < OPT_CHUNK; i += OPT_THREADS) {
-        long long e = base + i;
+        const long long e = base + i;
         if (e >= n) break;
-        float gv = g[e] * grad_scale;
-        float vv = v[e] * alpha + (1.f - alpha) * gv * gv;   // square_avg.mul_(alpha).addcmul_(grad, grad, 1 - alpha)
-        p[e] = p[e] - lr * (gv / (sqrtf(vv) + eps));         // param.addcdiv_(grad, avg, value=-lr)
-        v[e] = vv;
+        float pv = p[e], vv = v[e];
+        rmsprop_one(pv, g[e], vv, lr, alpha, eps, grad_scale);
+        p[e] = pv; v[e] = vv;
+        if (t.zero_grads) g[e] = 0.f;
     }
 }
 
-static int fill_table(OptTable& t, int count, float* const* p, const float* const* g, float* const* m,
-                      float* const* v, const long long* n) {
+static int fill_table(OptTable& t, int count, float* const* p, float* const* g, float* const* m,
+                      float* const* v, const long long* n, int zero_grads) {
     if (count <= 0 || count > OPT_MAX) return GZ_ERR_BAD_SHAPE;
     t.count = count;
+    t.zero_grads = zero_grads ? 1 : 0;
+    t.vec4 = 1;
     int blocks = 0;
     for (int k = 0; k < count; ++k) {
         if (n[k] <= 0) return GZ_ERR_BAD_SHAPE;
@@ -118,6 +178,9 @@ static int fill_table(OptTable& t, int count, float* const* p, const float* cons
         t.m[k] = m ? m[k] : nullptr;
         t.v[k] = v[k];
         t.n[k] = n[k];
+        const unsigned long long bits = (unsigned long long)p[k] | (unsigned long long)g[k] |
+                                        (unsigned long long)v[k] | (m ? (unsigned long long)m[k] : 0ull);
+        if (bits & 15ull) t.vec4 = 0;
         t.first_block[k] = blocks;
         blocks += (int)((n[k] + OPT_CHUNK - 1) / OPT_CHUNK);
     }
@@ -131,13 +194,13 @@ using namespace gz;
 
 extern "C" {
 
-int gz_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+int gz_adam_step(int count, float* const* params, float* const* grads, float* const* exp_avg,
                  float* const* exp_avg_sq, const long long* numel, float lr, float beta1, float beta2, float eps,
-                 int step, float grad_scale, hipStream_t stream) {
+                 int step, float grad_scale, int zero_grads, hipStream_t stream) {
     gz::clear_stale_error();
     if (step < 1) return GZ_ERR_BAD_SHAPE;
     OptTable t;
-    int blocks = fill_table(t, count, params, grads, exp_avg, exp_avg_sq, numel);
+    int blocks = fill_table(t, count, params, grads, exp_avg, exp_avg_sq, numel, zero_grads);
     if (blocks < 0) return blocks;
     // bias corrections in double, as torch does with Python floats
     double bc1 = 1.0 - pow((double)beta1, (double)step);
@@ -154,24 +217,25 @@ int gz_adam_tick(float* tick, float beta1, float beta2, hipStream_t stream) {
     return launch_status();
 }
 
-int gz_adam_step_dev(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+int gz_adam_step_dev(int count, float* const* params, float* const* grads, float* const* exp_avg,
                      float* const* exp_avg_sq, const long long* numel, float lr, float beta1, float beta2, float eps,
-                     const float* tick, float grad_scale, hipStream_t stream) {
+                     const float* tick, float grad_scale, int zero_grads, hipStream_t stream) {
     gz::clear_stale_error();
     if (!tick) return GZ_ERR_BAD_SHAPE;
     OptTable t;
-    int blocks = fill_table(t, count, params, grads, exp_avg, exp_avg_sq, numel);
+    int blocks = fill_table(t, count, params, grads, exp_avg, exp_avg_sq, numel, zero_grads);
     if (blocks < 0) return blocks;
     hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(OPT_THREADS), 0, stream, t, lr, beta1, beta2, eps, tick,
                        grad_scale);
     return launch_status();
 }
 
-int gz_rmsprop_step(int count, float* const* params, const float* const* grads, float* const* square_avg,
-                    const long long* numel, float lr, float alpha, float eps, float grad_scale, hipStream_t stream) {
+int gz_rmsprop_step(int count, float* const* params, float* const* grads, float* const* square_avg,
+                    const long long* numel, float lr, float alpha, float eps, float grad_scale, int zero_grads,
+                    hipStream_t stream) {
     gz::clear_stale_error();
     OptTable t;
-    int blocks = fill_table(t, count, params, grads, nullptr, square_avg, numel);
+    int blocks = fill_table(t, count, params, grads, nullptr, square_avg, numel, zero_grads);
     if (blocks < 0) return blocks;
     hipLaunchKernelGGL(rmsprop_kernel, dim3(blocks), dim3(OPT_THREADS), 0, stream, t, lr, alpha, eps, grad_scale);
     return launch_status();

@@ -162,6 +162,10 @@ def _pack_one(w, wp, kind, geom):
 
 
 def _repack_group(gid):
+    """Re-pack every STALE image of the group in one launch.  Normally that is the whole group (the optimizer stepped
+    all of its parameters); under ddp.GradSync the parameters are stepped bucket by bucket as their all-reduce lands,
+    so a miss re-packs what has been stepped so far and the rest follows with its own bucket -- a job table is kept
+    per distinct stale set (two for the DCGAN generator: main buckets, deferred tail)."""
     live = []
     for key in sorted(_group_keys[gid]):
         e = _pack_cache.get(key)
@@ -170,10 +174,16 @@ def _repack_group(gid):
             _group_keys[gid].discard(key)
             _pack_cache.pop(key, None)
             continue
-        live.append((key, e, w))
+        if e.stale or e.version != w._version:
+            live.append((key, e, w))
+    if not live:
+        return
     sig = tuple((key, e.wp.data_ptr()) for key, e, _ in live)
-    tab = _group_table.get(gid)
-    if tab is None or tab[0] != sig:
+    tabs = _group_table.setdefault(gid, {})
+    tab = tabs.get(sig)
+    if tab is None:
+        if len(tabs) > 8:
+            tabs.clear()
         nb = lib.gz_conv2d_pack_job_bytes()
         host = (ctypes.c_char * (nb * len(live)))()
         block0 = 0
@@ -186,9 +196,9 @@ def _repack_group(gid):
             check(min(n, 0), "conv2d_pack_job")
             block0 += n
         dev = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(live[0][2].device)
-        tab = (sig, dev, len(live), block0)
-        _group_table[gid] = tab
-    check(lib.gz_conv2d_pack_multi(_p(tab[1]), tab[2], tab[3], _stream()), "conv2d_pack_multi")
+        tab = (dev, len(live), block0)
+        tabs[sig] = tab
+    check(lib.gz_conv2d_pack_multi(_p(tab[0]), tab[1], tab[2], _stream()), "conv2d_pack_multi")
     for _, e, w in live:
         e.version, e.stale = w._version, False
 
@@ -407,22 +417,20 @@ def _conv_wgrad_raw(x, g, geom, with_bias=False):
 # Double-backward graphs (create_graph=True) never take this path.
 class _SinkState:
     enabled = False
-    listener = None           # callable(param): every contribution of this backward pass has been queued
     pending = {}              # id(param) -> [param, [(slabs, nz, stride), ...]]
-    uses = {}                 # id(param) -> forward uses not yet matched by a backward contribution
-    touched = set()           # id(param): gradient written in place during this pass (BatchNorm gamma / beta)
+    deferred = frozenset()    # id(param): the weight-gradient LAUNCH itself is postponed to run_deferred_wgrads()
+    deferred_jobs = []        # (param, x, g, geom) in arrival order
 
 
 _sinks = _SinkState()
 
 
-def set_grad_sinks(enabled, listener=None):
-    """Turn the direct-to-``p.grad`` weight-gradient path on / off; returns the previous (enabled, listener)."""
-    old = (_sinks.enabled, _sinks.listener)
+def set_grad_sinks(enabled):
+    """Turn the direct-to-``p.grad`` weight-gradient path on / off; returns the previous state as a 1-tuple
+    (``set_grad_sinks(*prev)`` restores it).  Whatever is pending is flushed first."""
+    old = (_sinks.enabled,)
     flush_grad_sinks()
-    _sinks.enabled, _sinks.listener = bool(enabled), listener
-    _sinks.uses.clear()
-    _sinks.touched.clear()
+    _sinks.enabled = bool(enabled)
     return old
 
 
@@ -430,45 +438,59 @@ def grad_sinks_enabled():
     return _sinks.enabled
 
 
-def reset_grad_sink_uses():
-    """Forget forward uses that never met their backward (a graph that was dropped): called at the top of a step."""
-    _sinks.uses.clear()
+def discard_grad_sinks():
+    """Drop every pending contribution WITHOUT launching anything (a step that raised half-way: its slabs must neither
+    be reduced from half-built state nor leak into the next step's gradients)."""
+    _sinks.pending.clear()
+    _sinks.deferred_jobs.clear()
 
 
-def _sink_note_use(w):
-    if w is not None and _sinks.enabled and w.requires_grad and torch.is_grad_enabled() and isinstance(w, torch.nn.Parameter):
-        _sinks.uses[id(w)] = _sinks.uses.get(id(w), 0) + 1
+def set_deferred_wgrads(params=()):
+    """ddp.GradSync: the convolution weight gradients of these parameters are not launched where backward reaches them
+    but by ``run_deferred_wgrads()`` at the end of the pass.  They are the layers the NEXT forward needs last, so
+    their bucket can be exchanged last -- and their launches then run behind the all-reduce of everything else, which
+    the next forward needs first.  Same kernels on the same operands: results are bit-identical."""
+    _sinks.deferred = frozenset(id(p) for p in params)
+    if _sinks.deferred_jobs:
+        run_deferred_wgrads()
 
 
-def _sink_done(w):
-    """One forward use of ``w`` has delivered its gradient (through the sink or through autograd)."""
-    if w is None:
-        return
-    k = id(w)
-    n = _sinks.uses.get(k)
-    if n is None:
-        return
-    if n > 1:
-        _sinks.uses[k] = n - 1
-        return
-    del _sinks.uses[k]
-    if _sinks.listener is not None and (k in _sinks.pending or k in _sinks.touched):
-        _sinks.listener(w)
+def run_deferred_wgrads():
+    """Launch the postponed weight gradients (in arrival order) into their parameters' sinks."""
+    jobs, _sinks.deferred_jobs = _sinks.deferred_jobs, []
+    keep, _sinks.deferred = _sinks.deferred, frozenset()
+    try:
+        for (w, x, g, geom) in jobs:
+            if not _sink_conv_wgrad(w, x, g, geom):
+                _sink_fail("deferred weight gradient")
+    finally:
+        _sinks.deferred = keep
+    return len(jobs)
 
 
-def _sink_touch(p):
-    """``p.grad`` was written in place by a kernel (no pending slabs): count the use and tell the listener."""
-    k = id(p)
-    _sinks.touched.add(k)
-    n = _sinks.uses.get(k)
-    if n is None:
-        return
-    if n > 1:
-        _sinks.uses[k] = n - 1
-        return
-    del _sinks.uses[k]
-    if _sinks.listener is not None:
-        _sinks.listener(p)
+# Parameter gate (ddp.GradSync): the modules announce the parameters a layer is about to read -- ``ready(w, gamma, ..)``
+# -- so that the gradient exchange + optimizer step of the PREVIOUS pass only has to have landed bucket by bucket, at
+# the first layer that reads a bucket, instead of for the whole network at the top of its forward.
+_param_gate = None
+
+
+def set_param_gate(fn):
+    global _param_gate
+    old, _param_gate = _param_gate, fn
+    return old
+
+
+def ready(*params):
+    if _param_gate is not None:
+        _param_gate(params)
+
+
+# WHEN a sunk parameter's gradient is complete is autograd's knowledge, not counted here: the parameter's AccumulateGrad
+# node runs once per graph task, after every node that feeds it has run -- also when those nodes returned None for it,
+# and also for nodes that a double backward (WGAN-GP, R1) created -- so a ``register_post_accumulate_grad_hook`` hook
+# is the "every contribution of this pass has been queued" signal (ddp.GradSync flushes and issues a bucket from it;
+# tests/test_runner_cpu.py::test_post_accumulate_hook_fires_once_for_none_gradients pins the torch behaviour).
+# Rounds 4's own use counter ran inside Function.forward, where grad mode is always off, and never counted anything.
 
 
 def _sink_conv_wgrad(w, x, g, geom):
@@ -483,6 +505,9 @@ def _sink_conv_wgrad(w, x, g, geom):
     nbytes = lib.gz_conv2d_wgrad_workspace_bytes(N, C, H, W, K, OH, OW, geom.kh, geom.kw)
     if not nbytes:
         return False
+    if id(w) in _sinks.deferred:
+        _sinks.deferred_jobs.append((w, x, g, geom))
+        return True
     ws = _ws(nbytes // 4, x.device)
     dw = torch.empty((K, C, geom.kh, geom.kw), device=x.device, dtype=torch.float32)   # unsplit launches write here
     nz, stride = ctypes.c_int(0), ctypes.c_longlong(0)
@@ -494,38 +519,31 @@ def _sink_conv_wgrad(w, x, g, geom):
     if src[2] & 3:
         return False if nz.value <= 1 else _sink_fail("slab stride")
     _sinks.pending.setdefault(id(w), [w, []])[1].append(src)
-    _sink_done(w)
     return True
 
 
 def _sink_grad(p, g):
-    """A COMPLETE gradient contribution ``g`` of parameter ``p`` (a bias, a Linear weight, a spectral-norm weight_orig).
-    Alone it goes back to autograd, whose AccumulateGrad keeps the tensor at no cost; when ``p`` is fed by several
-    forward uses of this pass (HoloGAN's discriminator runs twice per D step: 13 ``add_`` launches) or already holds a
-    gradient (the flat exchange buffer, gradient accumulation), it is queued as a one-slab source instead and summed
-    with everything else pending by flush_grad_sinks' one launch.  True = taken (return None to autograd)."""
+    """A COMPLETE gradient contribution ``g`` of parameter ``p`` (a bias, a Linear weight, a spectral-norm weight_orig):
+    queued as a one-slab source and summed with everything else pending by flush_grad_sinks' one launch -- into a fresh
+    ``p.grad`` or onto the existing one (the flat exchange buffer, gradient accumulation).  Handing it to autograd
+    instead is free only for a parameter with ONE contribution per pass; HoloGAN's critic runs twice per D step and
+    autograd then spends an ``add`` launch (and a host-side gap) per parameter, 13 per cycle.  True = taken (the caller
+    returns None to autograd)."""
     if g is None or not _sinks.enabled or not isinstance(p, torch.nn.Parameter) or (p.numel() & 3):
-        return False
-    k = id(p)
-    if not (_sinks.uses.get(k, 0) > 1 or k in _sinks.pending or p.grad is not None):
         return False
     if p.grad is not None and (p.grad.data_ptr() & 15 or not p.grad.is_contiguous() or p.grad.dtype != torch.float32):
         return False
     g = _req(g)
-    if g.data_ptr() & 15:
+    if g.data_ptr() & 15 or g.numel() != p.numel():
         return False
-    _sinks.pending.setdefault(k, [p, []])[1].append((g, 1, p.numel()))
-    _sink_done(p)
+    _sinks.pending.setdefault(id(p), [p, []])[1].append((g, 1, p.numel()))
     return True
 
 
 def _sink_or_return(p, g):
-    """``g`` for autograd, or None when the sink took it; either way one forward use of ``p`` is delivered."""
-    if g is None:
+    """``g`` for autograd, or None when the sink took it."""
+    if g is None or _sink_grad(p, g):
         return None
-    if _sink_grad(p, g):
-        return None
-    _sink_done(p)
     return g
 
 
@@ -668,8 +686,6 @@ class _ConvF(torch.autograd.Function):
         x, w = _req(x, "x"), _req(w, "w")
         ctx.geom, ctx.act, ctx.slope = geom, act, slope
         ctx.has_bias = bias is not None
-        _sink_note_use(w)
-        _sink_note_use(bias)
         ctx.bias_ref = bias if isinstance(bias, torch.nn.Parameter) else None
         if want_stats:          # BatchNorm follows: no bias, no activation; second output = partial statistics
             y, stats = _conv_fwd_stats_raw(x, w, geom)
@@ -704,9 +720,6 @@ class _ConvF(torch.autograd.Function):
             dw = _ConvWg.apply(x, gy, geom)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _ChannelSum.apply(gy)
-            _sink_done(ctx.bias_ref)
-        if ctx.needs_input_grad[1]:
-            _sink_done(w)
         return dx, dw, db, None, None, None, None
 
     @staticmethod
@@ -720,10 +733,8 @@ class _ConvF(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if want_b:
                 dw, db = _conv_wgrad_raw(x, gy, geom, with_bias=True)
-                _sink_done(w)
             elif not _sink_conv_wgrad(w, x, gy, geom):
                 dw = _conv_wgrad_raw(x, gy, geom)
-                _sink_done(w)
         elif want_b:
             db = _channel_sum_raw(gy)
         if want_b and ctx.bias_ref is not None:
@@ -740,8 +751,6 @@ class _ConvDg(torch.autograd.Function):
         ctx.geom, ctx.act, ctx.slope = geom, act, slope
         ctx.has_bias = bias is not None
         ctx.bias_cancels = bias_cancels      # the caller normalises the output per (sample, channel): d/d bias == 0
-        _sink_note_use(w)
-        _sink_note_use(bias)
         ctx.bias_ref = bias if isinstance(bias, torch.nn.Parameter) else None
         if want_stats:
             x, stats = _conv_dgrad_stats_raw(g, w, geom, hw)
@@ -769,7 +778,6 @@ class _ConvDg(torch.autograd.Function):
             dw = None
             if ctx.needs_input_grad[1] and not _sink_conv_wgrad(w, v, g, geom):
                 dw = _conv_wgrad_raw(v, g, geom)
-                _sink_done(w)
             db = None
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = (torch.zeros(v.shape[1], device=v.device, dtype=torch.float32) if ctx.bias_cancels
@@ -787,9 +795,6 @@ class _ConvDg(torch.autograd.Function):
             dw = _ConvWg.apply(v, g, geom)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _ChannelSum.apply(v)
-            _sink_done(ctx.bias_ref)
-        if ctx.needs_input_grad[1]:
-            _sink_done(w)
         return dg, dw, db, None, None, None, None, None, None
 
 
@@ -848,12 +853,14 @@ def conv_transpose2d_with_stats(x, w, geom=K4S2P1):
 # (reference standard_networks.py:60) and nn.Linear
 # ---------------------------------------------------------------------------
 class _MatMul(torch.autograd.Function):
-    """c = a @ b for row-major a [M,K], b [K,N]."""
+    """c = a @ b for row-major a [M,K], b [K,N].  ``param``: the Parameter ``b`` is a view of (the DCGAN generator's
+    first layer): a first-order backward hands its gradient to that parameter's sink instead of autograd."""
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, param=None):
         a, b = _req(a, "a"), _req(b, "b")
         ctx.save_for_backward(a, b)
+        ctx.param = param
         return gemm(a, b)
 
     @staticmethod
@@ -864,8 +871,13 @@ class _MatMul(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             ga = _MatMulNT.apply(gc, b)            # gc @ b^T
         if ctx.needs_input_grad[1]:
-            gb = _MatMulTN.apply(a, gc)            # a^T @ gc
-        return ga, gb
+            if ctx.param is not None and not torch.is_grad_enabled() and _sinks.enabled:
+                gb = gemm(a, gc, trans_a=True)
+                if _sink_grad(ctx.param, gb.view_as(ctx.param)):
+                    gb = None
+            else:
+                gb = _MatMulTN.apply(a, gc)        # a^T @ gc
+        return ga, gb, None
 
 
 class _MatMulNT(torch.autograd.Function):
@@ -904,8 +916,8 @@ class _MatMulTN(torch.autograd.Function):
         return ga, gb
 
 
-def matmul(a, b):
-    return _MatMul.apply(a, b)
+def matmul(a, b, param=None):
+    return _MatMul.apply(a, b, param)
 
 
 def matmul_nt(a, b):
@@ -946,17 +958,25 @@ class _DotF(torch.autograd.Function):
     """y[r] = <x[r,:], w>"""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, param=None):
         x, w = _req(x, "x"), _req(w, "w")
         ctx.save_for_backward(x, w)
+        ctx.param = param          # the Parameter ``w`` is a view of: a first-order backward feeds its sink
         return _rowdot_raw(x, w, True)
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         dx = _DotDg.apply(g, w) if ctx.needs_input_grad[0] else None
-        dw = _DotWg.apply(x, g) if ctx.needs_input_grad[1] else None
-        return dx, dw
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if ctx.param is not None and not torch.is_grad_enabled() and _sinks.enabled:
+                dw = _coldot_raw(_req(g), x)
+                if _sink_grad(ctx.param, dw.view_as(ctx.param)):
+                    dw = None
+            else:
+                dw = _DotWg.apply(x, g)
+        return dx, dw, None
 
 
 class _DotDg(torch.autograd.Function):
@@ -996,7 +1016,7 @@ class _DotWg(torch.autograd.Function):
 def full_dot_conv(x, w):
     """Conv2d whose kernel covers the whole (unpadded) input: [N,C,H,W] x [1,C,H,W] -> [N,1,1,1]."""
     n = x.shape[0]
-    y = _DotF.apply(x.reshape(n, -1), w.reshape(-1))
+    y = _DotF.apply(x.reshape(n, -1), w.reshape(-1), w if isinstance(w, torch.nn.Parameter) else None)
     return y.reshape(n, 1, 1, 1)
 
 
@@ -1060,8 +1080,6 @@ class _BatchNormAct(torch.autograd.Function):
         check(lib.gz_norm_act_fwd_g(_p(x), _p(coef), _p(out), N, C, inner, 1, groups, act, slope, st), "norm_act_fwd")
         ctx.save_for_backward(x, coef, gamma, beta)
         ctx.cfg = (N, C, inner, act, slope, training, groups)
-        _sink_note_use(gamma)
-        _sink_note_use(beta)
         return out
 
     @staticmethod
@@ -1087,8 +1105,6 @@ class _BatchNormAct(torch.autograd.Function):
             dbeta = _channel_sum_raw(gp)
             sgx = _rowdot_raw(gp.view(N * C, inner), x.view(N * C, inner), False).view(N, C).sum(0)
             dgamma = rstd * (sgx - mean * dbeta)
-            for p in (gamma, beta):
-                _sink_done(p)
             return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None) + nones
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
@@ -1106,11 +1122,7 @@ class _BatchNormAct(torch.autograd.Function):
         check(lib.gz_batchnorm_act_bwd_g(_p(gout), _p(x), _p(coef), _p(dx), _p(dgamma), _p(dbeta), _p(ws), _p(kbuf), N,
                                          C, inner, act, slope, groups, accumulate, _stream()), "norm_act_bwd")
         if sunk is not None:
-            _sink_touch(gamma)
-            _sink_touch(beta)
             return (dx, None, None) + nones
-        for p in (gamma, beta):
-            _sink_done(p)
         return (dx, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None) + nones
 
 
@@ -1140,8 +1152,6 @@ class _RowNormAct(torch.autograd.Function):
                                      _stream()), "rownorm_act_fwd")
         ctx.save_for_backward(x, gamma, coef, beta)
         ctx.cfg = (N, C, inner, act, slope)
-        _sink_note_use(gamma)
-        _sink_note_use(beta)
         return out
 
     @staticmethod
@@ -1159,13 +1169,8 @@ class _RowNormAct(torch.autograd.Function):
                 check(lib.gz_rownorm_act_bwd_acc(_p(gout), _p(x), _p(coef), _p(dx), _p(sunk[0]), _p(sunk[1]), _p(ws),
                                                  _p(kbuf), N, C, inner, act, slope, sunk[2], _stream()),
                       "rownorm_act_bwd")
-                _sink_touch(gamma)
-                _sink_touch(beta)
                 return (dx if ctx.needs_input_grad[0] else None), None, None, None, None, None
         dx, dgamma, dbeta = _RowNormActBwd.apply(gout, x, gamma, coef, ctx.cfg)
-        for p in (gamma, beta):
-            if p is not None:
-                _sink_done(p)
         return (dx if ctx.needs_input_grad[0] else None,
                 dgamma if (gamma is not None and ctx.needs_input_grad[1]) else None,
                 dbeta if (gamma is not None and ctx.needs_input_grad[2]) else None, None, None, None)
@@ -1563,8 +1568,6 @@ class _LinearAct(torch.autograd.Function):
         out = gemm(x, weight, bias, trans_b=True, act=act, slope=slope)
         ctx.save_for_backward(x, weight, out if act != ACT_NONE else None)
         ctx.act, ctx.slope, ctx.has_bias = act, slope, bias is not None
-        _sink_note_use(weight)
-        _sink_note_use(bias)
         ctx.bias_ref = bias if isinstance(bias, torch.nn.Parameter) else None
         return out
 
@@ -1773,8 +1776,6 @@ class _SpectralNormMulti(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eps, geom, *wuv):
-        for w in wuv[0::3]:
-            _sink_note_use(w)
         ctx.params = wuv[0::3]
         Ws = [_req(w, "weight_orig") for w in wuv[0::3]]
         us_buf, vs_buf = wuv[1::3], wuv[2::3]
@@ -1817,7 +1818,6 @@ class _SpectralNormMulti(torch.autograd.Function):
             w, us, vs, sigma = saved[4 * k: 4 * k + 4]
             if g is None:
                 grads += [None, None, None]
-                _sink_done(ctx.params[k])
                 continue
             g = _req(g)
             R = w.shape[0]
@@ -1895,7 +1895,6 @@ class _SNConvINAct(torch.autograd.Function):
         ctx.cfg = (geom, in_eps, act, slope, groups, bias is not None)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
         ctx.param = weight_orig
-        _sink_note_use(weight_orig)
         return out
 
     @staticmethod
@@ -1920,20 +1919,13 @@ class _SNConvINAct(torch.autograd.Function):
             check(lib.gz_sn_sigma_term(_p(rowsums), _p(coef[3 * N * C:]), _p(sigma), _p(us), _p(vs), _p(coefs), _p(term),
                                        N * C, groups, R, L, in_eps, st), "sn_sigma_term")
             p = ctx.param
-            k = id(p)
-            sunk = False
-            if _sinks.enabled and isinstance(p, torch.nn.Parameter) and k in _sinks.uses and not (W.numel() & 3):
-                _sinks.uses[k] += 1                    # (keeps the listener quiet until the sigma term is queued too)
-                if _sink_conv_wgrad(p, x, g_raw, geom):
-                    _sinks.pending[k][1].append((term, 1, W.numel()))
-                    _sink_done(p)
-                    sunk = True
-                else:
-                    _sinks.uses[k] -= 1
+            # weight_orig is a leaf: the convolution's weight gradient and the sigma term join its sink as two sources
+            sunk = isinstance(p, torch.nn.Parameter) and not (W.numel() & 3) and _sink_conv_wgrad(p, x, g_raw, geom)
+            if sunk:
+                _sinks.pending[id(p)][1].append((term, 1, W.numel()))
             if not sunk:
                 dW = _conv_wgrad_raw(x, g_raw, geom)
                 dW.add_(term)
-                _sink_done(p)
         db = torch.zeros(ctx.bias_shape, device=y.device, dtype=torch.float32) \
             if (has_bias and ctx.needs_input_grad[2]) else None
         return dx, dW, db, None, None, None, None, None, None, None

@@ -92,12 +92,31 @@ class HostStager:
         if events[cur] is not None:
             events[cur].synchronize()          # the copy that last used this buffer has completed
         bufs[cur].copy_(t)
-        out = bufs[cur].to(device, non_blocking=True)
+        out = self._device_read(bufs[cur], device)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(device))
         events[cur] = ev
         slot[2] = (cur + 1) % self.depth
         return out
+
+
+    @staticmethod
+    def _device_read(pinned, device):
+        """The device copies the words out of the pinned buffer itself (gz_copy_words: a kernel on the compute stream
+        reading device-mapped host memory) -- hipMemcpyAsync's ENQUEUE cost the host 180 us per call while the stream
+        was busy, 0.35 ms of host time per G+D pair.  Falls back to the asynchronous copy for odd sizes."""
+        nbytes = pinned.numel() * pinned.element_size()
+        if nbytes % 4 or not nbytes or HostStager.zero_copy is False:
+            return pinned.to(device, non_blocking=True)
+        from ._lib import check, lib
+        import ctypes
+        with torch.cuda.device(device):
+            out = torch.empty(pinned.shape, dtype=pinned.dtype, device=device)
+            check(lib.gz_copy_words(ctypes.c_void_p(pinned.data_ptr()), ctypes.c_void_p(out.data_ptr()), nbytes // 4,
+                                    ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "copy_words")
+        return out
+
+    zero_copy = True
 
 
 _stager = HostStager()
@@ -123,18 +142,43 @@ def optimizer_schedule(frequencies):
     return order
 
 
+def accumulation_factor(schedule, epoch):
+    """Lightning's ``accumulate_grad_batches`` argument as the reference builds it (run_network.py:61-68): the int 1, or
+    ``{start_epoch: factor}`` -- GradientAccumulationScheduler semantics: the factor of the largest key <= epoch, 1 before
+    the first key."""
+    if schedule is None:
+        return 1
+    if isinstance(schedule, int):
+        return max(1, schedule)
+    factor = 1
+    for start in sorted(int(k) for k in schedule):
+        if epoch >= start:
+            factor = int(schedule[start] if start in schedule else schedule[str(start)])
+    return max(1, factor)
+
+
 class Trainer:
     """Drives ``module.training_step`` over an iterable of batches with optimizer alternation.
 
     ``grad_sync`` (optional, see ddp.GradSync) averages the active network's gradients over the
-    data-parallel ranks between backward and the optimizer step."""
+    data-parallel ranks between backward and the optimizer step.
 
-    def __init__(self, module, grad_sync=None, grad_sinks=True):
+    ``accumulate_grad_batches`` (reference run_network.py:61-68; int or ``{start_epoch: factor}``) follows the training
+    loop of the Lightning generation the reference targets: the optimizer of a batch is chosen by the running batch
+    count and the ``frequency`` entries as always; the batch's loss is divided by the factor; the optimizer steps (and
+    its gradients are cleared) only on batches with ``(batch index in the epoch + 1) % factor == 0`` or on the last
+    batch of an epoch -- on every other batch the gradients just accumulate, and under data parallelism nothing is
+    exchanged (Lightning's ``block_ddp_sync_behaviour``): the all-reduce runs on the stepping batch only."""
+
+    def __init__(self, module, grad_sync=None, grad_sinks=True, accumulate_grad_batches=1):
         self.module = module
         self.optim = module.configure_optimizers()
         self.order = optimizer_schedule([o["frequency"] for o in self.optim])
         self.grad_sync = grad_sync
-        self.batch_idx = 0
+        self.batch_idx = 0                # running batch count (Lightning's total_batch_idx): selects the optimizer
+        self.epoch_batch_idx = 0          # batch index inside the epoch: selects the stepping batches
+        self.epoch = 0
+        self.accumulate_grad_batches = accumulate_grad_batches
         # weight gradients straight into p.grad (functional.set_grad_sinks): on for the duration of each step on the
         # GPU path -- ONE slab-reduction launch per backward pass (per gradient bucket under data parallelism) instead
         # of one per layer plus autograd's `grad += new` launches
@@ -147,37 +191,55 @@ class Trainer:
         i = self.batch_idx if batch_idx is None else batch_idx
         return self.order[i % len(self.order)]
 
-    def step(self, batch):
+    def step(self, batch, last_in_epoch=False):
         idx = self.active_optimizer()
         m = self.module
+        factor = accumulation_factor(self.accumulate_grad_batches, self.epoch)
+        stepping = factor == 1 or (self.epoch_batch_idx + 1) % factor == 0 or last_in_epoch
         toggle_optimizer(m, idx)
         if self.grad_sync is not None:
-            self.grad_sync.before_step(idx)
+            self.grad_sync.before_step(idx, exchange=stepping)
         F = self._F
         if F is not None:
-            prev = F.set_grad_sinks(True, getattr(self.grad_sync, "sink_listener", None))
+            prev = F.set_grad_sinks(True)
+        opt = self.optim[idx]["optimizer"]
         try:
             loss = m.training_step(batch, self.batch_idx, idx)
-            loss.backward()
-            if F is not None:
+            (loss if factor == 1 else loss / factor).backward()
+            if self.grad_sync is not None:
+                # still inside the sink region: GradSync sums the slabs bucket by bucket, runs the weight-gradient
+                # launches it postponed (deferred tail) and issues what the backward hooks have not issued yet
+                self.grad_sync.after_backward(idx, opt, exchange=stepping)
+            elif F is not None:
                 F.flush_grad_sinks()
+        except BaseException:
+            if F is not None:             # nothing half-built is reduced, nothing leaks into the next step's gradients
+                F.discard_grad_sinks()
+            raise
         finally:
             if F is not None:
                 F.set_grad_sinks(*prev)
-        opt = self.optim[idx]["optimizer"]
-        if self.grad_sync is not None:
-            self.grad_sync.after_backward(idx, opt)
-        else:
+        if self.grad_sync is None and stepping:
             opt.step()
             opt.zero_grad(set_to_none=True)
         self.batch_idx += 1
+        self.epoch_batch_idx += 1
         return loss.detach(), idx
 
     def end_epoch(self):
+        if self.grad_sync is not None:
+            self.grad_sync.flush()        # a deferred optimizer step must use THIS epoch's learning rate
+        import warnings
         for o in self.optim:
             sch = o.get("lr_scheduler")
             if sch is not None:
-                sch.step()
+                with warnings.catch_warnings():
+                    # Lightning steps EVERY scheduler at the epoch boundary, also that of an optimizer whose turn has
+                    # not come yet (a one-batch epoch only runs the discriminator): torch's order check does not apply
+                    warnings.filterwarnings("ignore", message="Detected call of `lr_scheduler.step\\(\\)` before")
+                    sch.step()
+        self.epoch += 1
+        self.epoch_batch_idx = 0
         if hasattr(self.module, "current_epoch"):
             try:
                 self.module.current_epoch += 1
@@ -261,6 +323,9 @@ class GraphedTrainer(Trainer):
             loss = m.training_step(self.static_batch, self.batch_idx, idx)
             loss.backward()
             self._F.flush_grad_sinks()
+        except BaseException:
+            self._F.discard_grad_sinks()
+            raise
         finally:
             self._F.set_grad_sinks(*prev)
         self.optim[idx]["optimizer"].step()

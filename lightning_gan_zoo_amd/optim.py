@@ -28,6 +28,7 @@ def _check_tensor(p):
 
 class Adam(torch.optim.Optimizer):
     accepts_grad_scale = True
+    accepts_param_subset = True
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **unused):
         if weight_decay or amsgrad:
@@ -35,6 +36,11 @@ class Adam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False,
                         foreach=None, capturable=False, differentiable=False, fused=None)
         super().__init__(params, defaults)
+        self._step_py = {}          # id(param) -> step count as a Python int (mirror of state[p]["step"])
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._step_py = {}          # re-read from the loaded tensors at the next step
 
     def make_capturable(self):
         """Move the step counter to the device so that ``step()`` can be captured in a HIP graph and replayed
@@ -62,10 +68,10 @@ class Adam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] = tick[0]
 
-    def _step_capturable(self, group, grad_scale, stream):
+    def _step_capturable(self, group, grad_scale, stream, only=None, zero_grads=False):
         beta1, beta2 = group["betas"]
         tick = group["_tick"]
-        plist = [p for p in group["params"] if p.grad is not None]
+        plist = [p for p in group["params"] if p.grad is not None and (only is None or id(p) in only)]
         if not plist:
             return
         check(lib.gz_adam_tick(ctypes.c_void_p(tick.data_ptr()), float(beta1), float(beta2), stream), "adam_tick")
@@ -77,33 +83,47 @@ class Adam(torch.optim.Optimizer):
                                        _ptr_array([self.state[p]["exp_avg"] for p in chunk]),
                                        _ptr_array([self.state[p]["exp_avg_sq"] for p in chunk]), numel,
                                        float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),
-                                       ctypes.c_void_p(tick.data_ptr()), float(grad_scale), stream), "adam_step_dev")
+                                       ctypes.c_void_p(tick.data_ptr()), float(grad_scale), int(zero_grads), stream),
+                  "adam_step_dev")
         for p in plist:
             F.invalidate(p)
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0):
+    def step(self, closure=None, grad_scale=1.0, params=None, zero_grads=False):
+        """``params``: step only these (ddp.GradSync steps one gradient bucket at a time, as its all-reduce lands);
+        ``zero_grads``: the kernel also overwrites the gradients it has read with 0 (the flat exchange buffer)."""
         loss = closure() if closure is not None else None
         if getattr(self, "_pack_group", None) is None:      # the conv weights this optimizer rewrites re-pack together
             self._pack_group = F.register_pack_group([p for g in self.param_groups for p in g["params"]])
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        only = None if params is None else {id(p) for p in params}
         for group in self.param_groups:
             if group.get("_tick") is not None:
-                self._step_capturable(group, grad_scale, stream)
+                self._step_capturable(group, grad_scale, stream, only, zero_grads)
                 continue
             beta1, beta2 = group["betas"]
             by_step = {}
+            todo = []
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None or (only is not None and id(p) not in only):
                     continue
-                _check_tensor(p)
                 st = self.state[p]
                 if not st:
+                    _check_tensor(p)
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                by_step.setdefault(int(st["step"].item()), []).append(p)
+                todo.append((p, st))
+            if not todo:
+                continue
+            # the per-parameter ``state['step']`` tensors (torch.optim.Adam's layout: checkpoints interchange) advance
+            # with ONE foreach call; their values are mirrored as Python ints so that no .item() is needed per step
+            torch._foreach_add_([st["step"] for _, st in todo], 1.0)
+            for p, st in todo:
+                k = self._step_py.get(id(p))
+                k = int(st["step"].item()) if k is None else k + 1
+                self._step_py[id(p)] = k
+                by_step.setdefault(k, []).append(p)
             for step, plist in by_step.items():
                 for i in range(0, len(plist), MAX_TENSORS):
                     chunk = plist[i:i + MAX_TENSORS]
@@ -113,7 +133,7 @@ class Adam(torch.optim.Optimizer):
                                            _ptr_array([self.state[p]["exp_avg"] for p in chunk]),
                                            _ptr_array([self.state[p]["exp_avg_sq"] for p in chunk]), numel,
                                            float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), step,
-                                           float(grad_scale), stream), "adam_step")
+                                           float(grad_scale), int(zero_grads), stream), "adam_step")
                 for p in plist:
                     F.invalidate(p)         # packed conv weights of p are stale now
         return loss
@@ -121,6 +141,7 @@ class Adam(torch.optim.Optimizer):
 
 class RMSprop(torch.optim.Optimizer):
     accepts_grad_scale = True
+    accepts_param_subset = True
 
     def __init__(self, params, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0, momentum=0, centered=False, **unused):
         if weight_decay or momentum or centered:
@@ -137,15 +158,16 @@ class RMSprop(torch.optim.Optimizer):
             group["capturable"] = True
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0):
+    def step(self, closure=None, grad_scale=1.0, params=None, zero_grads=False):
         loss = closure() if closure is not None else None
         if getattr(self, "_pack_group", None) is None:      # the conv weights this optimizer rewrites re-pack together
             self._pack_group = F.register_pack_group([p for g in self.param_groups for p in g["params"]])
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        only = None if params is None else {id(p) for p in params}
         for group in self.param_groups:
             plist = []
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None or (only is not None and id(p) not in only):
                     continue
                 _check_tensor(p)
                 st = self.state[p]
@@ -161,7 +183,7 @@ class RMSprop(torch.optim.Optimizer):
                 check(lib.gz_rmsprop_step(len(chunk), _ptr_array(chunk), _ptr_array(grads),
                                           _ptr_array([self.state[p]["square_avg"] for p in chunk]), numel,
                                           float(group["lr"]), float(group["alpha"]), float(group["eps"]),
-                                          float(grad_scale), stream), "rmsprop_step")
+                                          float(grad_scale), int(zero_grads), stream), "rmsprop_step")
             for p in plist:
                 F.invalidate(p)
         return loss

@@ -369,6 +369,11 @@ def load_checkpoint(path, module, trainer):
         o["optimizer"].load_state_dict(s)
     for o, s in zip(trainer.optim, blob.get("lr_schedulers", [])):
         o["lr_scheduler"].load_state_dict(s)
+    if blob.get("global_step", 0) > 0:
+        # the optimizers HAVE stepped -- in the process that wrote the checkpoint; torch's "lr_scheduler.step() before
+        # optimizer.step()" bookkeeping is per process and would otherwise warn at the first epoch end after a resume
+        for o in trainer.optim:
+            o["optimizer"]._opt_called = True
     return blob.get("global_step", 0), blob.get("epoch", 0), blob.get("callbacks", {}).get("ModelCheckpoint")
 
 
@@ -425,20 +430,29 @@ def fit(module, cfg, data, run, sync=None, rank=0, world=1, evaluate=None, slow_
     step classes of this package (reference run_network.py:61-72).  Returns (module, trainer, global_step)."""
     from .harness import Trainer
     t = cfg.train
-    trainer = Trainer(module, grad_sync=sync)
+    # reference run_network.py:61-68: ``1`` or a ``{start_epoch, accumulation_factor}`` node -> Lightning's
+    # ``accumulate_grad_batches={start_epoch: factor}`` (GradientAccumulationScheduler)
+    acc = cfg.get("accumulate_grad_batches", 1)
+    if not isinstance(acc, int):
+        acc = {int(acc["start_epoch"]): int(acc["accumulation_factor"])}
+    trainer = Trainer(module, grad_sync=sync, accumulate_grad_batches=acc)
     n = len(data) if hasattr(data, "__len__") else 0
     steps_per_epoch = int(math.ceil(n / t.batch_size)) if n else int(run["steps_per_epoch"])
     step = epoch = 0
+    skip = 0
     ckpt_dir = t.get("ckpt_dir")
     keeper = CheckpointKeeper(ckpt_dir) if (ckpt_dir and cfg.get("save_ckpts", True)) else None
     ckpt = find_ckpt(ckpt_dir)
     if ckpt:
         step, epoch, kst = load_checkpoint(ckpt, module, trainer)
         trainer.batch_idx = step
+        trainer.epoch, trainer.epoch_batch_idx = epoch, step % steps_per_epoch
         if keeper is not None:
             keeper.load_state(kst, ckpt)
         if hasattr(data, "set_epoch"):
             data.set_epoch(epoch)         # the sampler's permutation continues at seed + epoch (Lightning: set_epoch)
+            skip = step % steps_per_epoch if n else 0     # a checkpoint cut by max_steps: the epoch continues where
+                                                          # it stopped instead of replaying its first batches
         if rank == 0:
             print("resumed from %s at step %d (epoch %d)" % (ckpt, step, epoch))
     # a full Python garbage collection walks every object torch has created (~70 ms, several training steps):
@@ -461,10 +475,17 @@ def fit(module, cfg, data, run, sync=None, rank=0, world=1, evaluate=None, slow_
         if world > 1:
             torch.distributed.barrier()
 
+    if rank == 0 and n:
+        #  the order the data is visited in is part of the run's definition: say it
+        print("data order: %s" % ("dataset order, no shuffling (reference train_dataloader, one process)" if world <= 1
+                                  else "DistributedSampler(shuffle=True, seed=0) permutation per epoch, %d ranks" % world))
     for batch in data:
+        if skip:
+            skip -= 1
+            continue
         if (max_steps is not None and step >= max_steps) or epoch >= max_epochs:
             break
-        loss, idx = trainer.step(batch)
+        loss, idx = trainer.step(batch, last_in_epoch=(step + 1) % steps_per_epoch == 0)
         last[("d_loss", "g_loss")[idx]] = loss
         step += 1
         if step % run["log_every"] == 0 and rank == 0:

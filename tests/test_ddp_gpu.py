@@ -18,8 +18,9 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize("layout", ["default", "small_buckets"])
 @pytest.mark.parametrize("expt", ["dc_gan", "wgan_gp", "hologan"])
-def test_gradsync_on_rccl_single_rank_matches_plain_trainer(expt):
+def test_gradsync_on_rccl_single_rank_matches_plain_trainer(expt, layout):
     """GradSync (gradients in the flat exchange buffer, every contribution through the sinks with beta = 1, one
     all-reduce per bucket) against the plain trainer, four steps, same parameters bit for bit.  hologan covers the
     complete-gradient sources (biases, Linear weights, spectral-norm weight_orig: functional._sink_grad) and parameters
@@ -50,7 +51,10 @@ def test_gradsync_on_rccl_single_rank_matches_plain_trainer(expt):
         results = []
         for use_sync in (True, False):
             m = build()
-            tr = Trainer(m, grad_sync=GradSync(m) if use_sync else None)
+            # small_buckets: several buckets per network, a deferred tail (round 5: the weight gradients of the last
+            # layers are launched after backward and travel last), per-bucket optimizer steps at the layer gates
+            kw = {} if layout == "default" else dict(bucket_bytes=32 << 10, tail_min_bytes=1024)
+            tr = Trainer(m, grad_sync=GradSync(m, **kw) if use_sync else None)
             torch.manual_seed(7)
             np.random.seed(7)              # (hologan's views, wgan_gp's interpolation weights)
             for k in range(4):
@@ -95,6 +99,7 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     for rec in (out, big):
         ex = rec["grad_exchange"]
         assert ex["buckets_from_hooks"] > 0 and ex["buckets_after_backward"] == 0
+        assert ex["buckets_deferred_tail"] > 0          # the generator's last layers: launched + exchanged last
         # the overlap report of the first real multi-GPU run: exposed wait per optimizer cycle and network
         ov = ex["overlap"]
         assert set(ov["exposed_wait_ms_per_step"]) == {"discriminator", "generator"} and ov["waits_per_step"] >= 2
@@ -127,3 +132,121 @@ def test_two_rank_training_run_rehearsal_on_one_gpu(tmp_path, expt):
     blob = torch.load(os.path.join(ck, "step=4.ckpt"), weights_only=False)
     assert blob["global_step"] == 4
     assert all(torch.isfinite(v).all() for v in blob["state_dict"].values() if v.is_floating_point())
+
+
+def test_deferred_tail_hides_the_generator_exchange_behind_launches():
+    """VERDICT r4 item 1b.  The stacked discriminator pass needs G(z) first, so the generator's gradient exchange used
+    to be waited for, as a whole, at the top of every discriminator step.  Now (ddp.py): the weight gradients of the
+    generator's LAST layers are launched after everything else has been issued, their bucket travels last, and a bucket
+    is only waited for at the first layer that reads it.  Asserted on the event trace of a single-rank RCCL run
+    (dc_gan, features 16, 64 KB buckets): in every generator pass the main buckets are issued BEFORE the postponed
+    launches run and the tail bucket after them; in the following discriminator step the tail bucket's wait comes after
+    the gates of at least two earlier generator layers (their kernels are queued in between); parameters equal the
+    plain trainer's bit for bit."""
+    import torch.distributed as dist
+    from helpers import FixedNoise, fill_closed_form, synthetic_noise, synthetic_real
+    from lightning_gan_zoo_amd.config import locate, make_cfg
+    from lightning_gan_zoo_amd.ddp import GradSync
+    from lightning_gan_zoo_amd.harness import Trainer
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+                      GZ_DDP_ALWAYS_REDUCE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        def build():
+            cfg = make_cfg("dc_gan", batch_size=8, features=16, noise_dim=16)
+            torch.manual_seed(42)
+            m = locate(cfg.model.lm["_target_"])(cfg, None)
+            fill_closed_form(m.generator, 1)
+            fill_closed_form(m.discriminator, 2)
+            return m.cuda()
+
+        labels = torch.zeros(8, dtype=torch.int64, device="cuda")
+        batches = [(synthetic_real(8, seed=k).cuda(), labels) for k in range(6)]
+        noises = [synthetic_noise(8, 16, 40 + k) for k in range(6)]
+        results, trace, tails = [], None, None
+        for use_sync in (True, False):
+            m = build()
+            sync = GradSync(m, bucket_bytes=64 << 10, tail_min_bytes=1024) if use_sync else None
+            if sync is not None:
+                sync.trace = trace = []
+                tails = [sorted(fg.tail_buckets) for fg in sync.flats]
+                assert sync.lazy == [True, True] and tails[1], tails
+                n_tail_params = len(sync.tails[1])
+            tr = Trainer(m, grad_sync=sync)
+            for k in range(6):
+                m.noise_distn = FixedNoise(noises[k])
+                tr.step(batches[k])
+            tr.finish()
+            torch.cuda.synchronize()
+            results.append(torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu())
+        assert torch.equal(results[0], results[1])
+        # generator passes: [issue main ...] deferred [issue tail ...]
+        k_def = [k for k, t in enumerate(trace) if t[0] == "deferred" and t[1] == 1]
+        assert len(k_def) == 3 and all(trace[k][2] == n_tail_params for k in k_def)
+        for k in k_def:
+            before = [t for t in trace[:k] if t[0] == "issue" and t[1] == 1]
+            after = [t for t in trace[k + 1:k + 1 + len(tails[1])]]
+            assert before and before[-1][2] not in tails[1]
+            assert [t[0] for t in after] == ["issue"] * len(tails[1]) and all(t[2] in tails[1] for t in after)
+        # discriminator steps that follow a generator pass: the tail bucket is waited for at ITS layers' gate
+        waits_tail = [k for k, t in enumerate(trace) if t[0] == "wait" and t[1] == 1 and t[2] in tails[1]]
+        gated = 0
+        for k in waits_tail:
+            j = k
+            while j >= 0 and not (trace[j][0] == "issue" and trace[j][1] == 1):
+                j -= 1                       # back to this pass's last issue
+            g_gates = [t for t in trace[j:k] if t[0] == "gate" and t[1] == 1]
+            if g_gates:                      # (the run's final flush lands without gates)
+                gated += 1
+                assert len(g_gates) >= 2 and g_gates[0][2] not in tails[1], g_gates
+        assert gated >= 2
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop("GZ_DDP_ALWAYS_REDUCE", None)
+
+
+def test_a_failed_step_leaves_no_pending_gradient_behind():
+    """a training_step / backward that raises must not have its half-built sink state reduced (a second error
+    that masks the first) nor leak slabs into the next step's gradients."""
+    from helpers import FixedNoise, fill_closed_form, synthetic_noise, synthetic_real
+    from lightning_gan_zoo_amd import functional as F
+    from lightning_gan_zoo_amd.config import locate, make_cfg
+    from lightning_gan_zoo_amd.harness import Trainer
+
+    def build():
+        cfg = make_cfg("dc_gan", batch_size=8, features=8, noise_dim=16)
+        torch.manual_seed(42)
+        m = locate(cfg.model.lm["_target_"])(cfg, None)
+        fill_closed_form(m.generator, 1)
+        fill_closed_form(m.discriminator, 2)
+        return m.cuda()
+
+    labels = torch.zeros(8, dtype=torch.int64, device="cuda")
+    batch = (synthetic_real(8, seed=3).cuda(), labels)
+    out = []
+    for fail in (True, False):
+        m = build()
+        tr = Trainer(m)
+        if fail:
+            real_step = m.training_step
+
+            def broken(b, i, idx):
+                loss = real_step(b, i, idx)
+                loss.backward(retain_graph=True)          # slabs are pending in the sinks now
+                raise ValueError("boom")
+
+            m.training_step = broken
+            m.noise_distn = FixedNoise(synthetic_noise(8, 16, 5))
+            with pytest.raises(ValueError, match="boom"):
+                tr.step(batch)
+            assert not F._sinks.pending and not F.grad_sinks_enabled()
+            m.training_step = real_step
+            for p in m.parameters():
+                p.grad = None
+        for k in range(2):
+            m.noise_distn = FixedNoise(synthetic_noise(8, 16, 9 + k))
+            tr.step(batch)
+        torch.cuda.synchronize()
+        out.append(torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu())
+    assert torch.equal(out[0], out[1])

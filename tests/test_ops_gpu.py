@@ -704,6 +704,68 @@ def test_fused_optimizers_match_torch(kind):
         assert rel(c, b) < 1e-6
 
 
+@pytest.mark.parametrize("kind", ["adam", "rmsprop"])
+def test_fused_optimizers_step_parameter_subsets_and_zero_the_gradients(kind):
+    """Round 5 (ddp.GradSync lands its gradient buckets one at a time): ``step(params=subset, zero_grads=True,
+    grad_scale=s)`` updates exactly the subset -- bit-identical to what a whole-optimizer step does to those parameters
+    -- leaves the others and their gradients alone, and overwrites the subset's gradients with zeros; two subset steps
+    equal one full step.  Unaligned tensors (a view that starts 4 bytes into a buffer) take the scalar path."""
+    from lightning_gan_zoo_amd import optim as O
+    torch.manual_seed(1)
+    shapes = [(64, 3, 4, 4), (128,), (33, 17), (7,), (1, 512, 4, 4)]
+
+    def make():
+        torch.manual_seed(2)
+        ps = [torch.nn.Parameter(torch.randn(s, device="cuda") * 0.05) for s in shapes]
+        odd = torch.randn(1001, device="cuda")
+        ps.append(torch.nn.Parameter(odd[1:]))                  # data_ptr % 16 == 4
+        return ps
+
+    pa, pb = make(), make()
+    mk = (lambda ps: O.RMSprop(ps, lr=5e-5)) if kind == "rmsprop" else (lambda ps: O.Adam(ps, lr=2e-4, betas=(0.5, 0.999)))
+    oa, ob = mk(pa), mk(pb)
+    for step in range(3):
+        gs = [torch.randn_like(p) * (0.1 + step) for p in pa]
+        for a, b, g in zip(pa, pb, gs):
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step(grad_scale=0.5)
+        first, second = pb[:2] + pb[5:], pb[2:5]
+        before = [p.detach().clone() for p in second]
+        ob.step(grad_scale=0.5, params=first, zero_grads=True)
+        assert all(torch.equal(p.detach(), q) for p, q in zip(second, before))          # untouched
+        assert all(float(p.grad.abs().max()) == 0.0 for p in first)                     # zeroed behind the read
+        assert all(torch.equal(p.grad, g) for p, g in zip(second, gs[2:5]))             # still there
+        ob.step(grad_scale=0.5, params=second, zero_grads=True)
+        assert all(float(p.grad.abs().max()) == 0.0 for p in pb)
+        for a, b in zip(pa, pb):
+            assert torch.equal(a.detach(), b.detach())
+    sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+    assert all(float(sa[k]["step"]) == float(sb[k]["step"]) == 3.0 for k in sa)
+
+
+def test_host_draws_reach_the_device_through_the_pinned_ring():
+    """harness.HostStager: the per-step host draws (latent noise, GP alpha, HoloGAN's view matrices; reference
+    core/lightning_module.py:107-108 ``sample(...).to(device)``) are read by the device straight out of pinned host
+    buffers (gz_copy_words) -- same values as ``.to(device)``, for more calls than the ring has slots, and for sizes
+    that are no multiple of four bytes (plain asynchronous copy)."""
+    from lightning_gan_zoo_amd.harness import HostStager
+    st = HostStager(depth=3)
+    g = torch.Generator().manual_seed(5)
+    outs, refs = [], []
+    for k in range(10):
+        t = torch.randn(128, 100, generator=g)
+        outs.append(st.to_device(t, "cuda"))
+        refs.append(t.clone())
+    a = torch.rand(37, 1, 1, 1, generator=g)
+    b = torch.arange(5, dtype=torch.uint8)
+    c = torch.arange(7, dtype=torch.int64)
+    da, db, dc = st.to_device(a, "cuda"), st.to_device(b, "cuda"), st.to_device(c, "cuda")
+    torch.cuda.synchronize()
+    assert all(o.is_cuda and torch.equal(o.cpu(), r) for o, r in zip(outs, refs))
+    assert torch.equal(da.cpu(), a) and torch.equal(db.cpu(), b) and torch.equal(dc.cpu(), c)
+    assert da.shape == a.shape and dc.dtype == torch.int64
+
+
 # ---------------------------------------------------------------------------
 # R1 / ResNet path (SURVEY.md 8-f4)
 # ---------------------------------------------------------------------------
