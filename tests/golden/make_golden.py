@@ -114,8 +114,9 @@ def run_reference(expt, size, stable, dtype, full, inputs, **scenario_kw):
     return out
 
 
-PINNED_EXPTS = ("dc_gan", "wgan", "wgan_gp")
+PINNED_EXPTS = ("dc_gan", "wgan", "wgan_gp", "hologan")
 PINNED_KW = dict(pairs=1, skip_opt=True, probe=False)
+PINNED_SIZE = "full64"        # == "full" for the standard networks; HoloGAN at the reference's default in_planes 64, bs 8
 
 
 def make_pinned(expt):
@@ -125,10 +126,10 @@ def make_pinned(expt):
     observed with a global forward hook -- tests/mask_pinning.py -- the reference is not modified).  Oracle and
     product are re-run with exactly these decisions and compared at the plain 1e-3, every gradient included."""
     from mask_pinning import MaskTape, record_module_masks
-    inputs = scenario.make_inputs(expt, "full")
+    inputs = scenario.make_inputs(expt, PINNED_SIZE)
     tape = MaskTape()
     with record_module_masks(tape):
-        out = run_reference(expt, "full", False, torch.float32, False, inputs, **PINNED_KW)
+        out = run_reference(expt, PINNED_SIZE, False, torch.float32, False, inputs, **PINNED_KW)
     blob = {"in/" + k: v.numpy() for k, v in inputs.items() if not k.startswith("real_")}
     blob["in/real_checksum"] = np.float64(sum(float(v.double().sum()) for k, v in sorted(inputs.items())
                                               if k.startswith("real_")))

@@ -25,6 +25,7 @@ class MaskTape:
         self.masks = []
         self.cursor = 0
         self.mismatches = []       # (position in the tape, number of differing entries, numel) while replaying
+        self.reserved = set()      # tape positions that are replayed out of call order (replay_at)
 
     def record(self, out):
         self.masks.append((out.detach() > 0).cpu())
@@ -53,18 +54,44 @@ class MaskTape:
     def rewind(self):
         self.cursor = 0
         self.mismatches = []
+        self.reserved = set()
         return self
 
-    def replay(self, x, slope):
-        mask = self.masks[self.cursor]
-        self.cursor += 1
-        assert mask.shape == x.shape, (self.cursor, tuple(mask.shape), tuple(x.shape))
+    def _apply(self, pos, x, slope):
+        mask = self.masks[pos]
+        assert mask.shape == x.shape, (pos, tuple(mask.shape), tuple(x.shape))
         mask = mask.to(x.device)
         natural = x.detach() > 0
         diff = int((natural != mask).sum())
         if diff:
-            self.mismatches.append((self.cursor - 1, diff, x.numel(), float(x.detach()[natural != mask].abs().max())))
+            self.mismatches.append((pos, diff, x.numel(), float(x.detach()[natural != mask].abs().max())))
         return torch.where(mask, x, x * slope)
+
+    def _skip_reserved(self):
+        while self.cursor in self.reserved:
+            self.cursor += 1
+
+    def replay(self, x, slope):
+        self._skip_reserved()
+        pos = self.cursor
+        self.cursor += 1
+        out = self._apply(pos, x, slope)
+        self._skip_reserved()
+        return out
+
+    def replay_at(self, offsets, xs, slope):
+        """Decisions that the implementation under test takes EARLIER than the tape's owner did (the product maps z
+        through HoloGAN's five ZMapping layers in one launch up front; the reference takes each of those ReLU decisions
+        right before the AdaIN it feeds): ``xs[i]`` takes the decision at tape position cursor + offsets[i], and
+        in-order replays skip those positions."""
+        self._skip_reserved()
+        base = self.cursor
+        outs = []
+        for off, x in zip(offsets, xs):
+            self.reserved.add(base + off)
+            outs.append(self._apply(base + off, x, slope))
+        self._skip_reserved()
+        return outs
 
 
 @contextlib.contextmanager
@@ -229,6 +256,24 @@ def pinned_product_masks(tape):
     wrap("instance_norm_act", 4, 5)     # (x, gamma, beta, eps, act, slope)
     wrap("conv2d", 4, 5)                # (x, w, bias, geom, act, slope)
     wrap("conv_transpose2d", 4, 5)
+    # HoloGAN's ops (round 5: hologan_full_pinned.npz)
+    wrap("linear_act", 3, 4)            # (x, weight, bias, act, slope)
+    wrap("adain_act_packed", 3, 4)      # (x, scale|shift, eps, act, slope)
+    wrap("adain_const_act", 3, 4)
+    wrap("sn_conv_in_act", 8, 9)        # (x, weight_orig, bias, sigma, us, vs, geom, in_eps, act, slope)
+
+    def multi(x, layers, act=F.ACT_NONE, slope=0.0):
+        # the five ZMapping layers of a generator forward in one launch (hologan_generator.Generator.forward); the
+        # reference decides them at positions 0, 2, 4, 7, 9 of the forward's eleven decisions (reference
+        # hologan_generator.py:122,37-41,135,139-140: zMapping, relu(AdaIn(x)), [zMapping, relu] x 2, relu(conv1x1),
+        # [zMapping, relu] x 2)
+        if act != F.ACT_RELU or len(layers) != 5:
+            return saved["linear_act_multi"](x, layers, act, slope)
+        outs = saved["linear_act_multi"](x, layers, F.ACT_NONE, 0.0)
+        return tuple(tape.replay_at((0, 2, 4, 7, 9), outs, 0.0))
+
+    saved["linear_act_multi"] = F.linear_act_multi
+    F.linear_act_multi = multi
     try:
         yield tape
     finally:

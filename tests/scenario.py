@@ -16,6 +16,7 @@ SIZES = {
     # name: (features, batch, noise_dim)
     "tiny": (8, 4, 16),
     "full": (64, 8, 100),
+    "full64": (64, 8, 100),     # == "full", except for HoloGAN: the reference's default width (in_planes 64) at bs 8
 }
 STD_EXPTS = ("dc_gan", "wgan", "wgan_gp")
 ALL_EXPTS = STD_EXPTS + ("hologan",)
@@ -24,6 +25,8 @@ R1_EXPT = "gan_stability_r1"      # SURVEY.md 8-f4 ('next' row): ResNet G/D + R1
 
 def sizes(expt, size, stable=False):
     feats, bs, zdim = SIZES[size]
+    if expt == "hologan" and size == "full64":
+        return 64, 8, 128        # the reference-pinned fixture (hologan_full_pinned.npz): plain parameters, full width
     if expt == "hologan" and size == "full":
         if stable:
             return 64, 8, 128    # the reference's own default (conf/expt/hologan.yaml: in_planes 64, z 128)

@@ -480,6 +480,66 @@ def test_product_with_reference_mask_decisions_every_gradient_at_1e3(expt):
     print(f"{expt}: product vs reference fixture, worst {w[3]} {w[1]:.1e}")
 
 
+def test_hologan_with_reference_mask_decisions_every_gradient_at_1e3():
+    """HoloGAN's counterpart of the test above -- ``hologan_full_pinned.npz`` holds the ReLU / LeakyReLU
+    decisions of the UNMODIFIED reference (in_planes 64, z 128, bs 8, plain closed-form parameters, non-right-angle
+    views; one D step and one G step; 21 M decisions).  The product takes exactly those decisions: every fused op runs
+    with ACT_NONE and the activation is where(mask, y, slope y) on the device; the five ZMapping ReLUs, which the
+    product evaluates in one launch up front, take the tape positions at which the reference decides them
+    (tests/mask_pinning.py: replay_at).  Every loss, spectral-norm buffer and gradient of both steps at the plain 1e-3:
+    in full relative L2 against the CPU oracle run live with the same decisions (oracle + these decisions == reference
+    at 1e-5: test_oracle_takes_the_reference_mask_decisions_hologan), and against the reference's own recorded numbers.
+    No conditioning slack, no second-pair floor."""
+    from mask_pinning import pinned_oracle_masks, pinned_product_masks
+    from test_oracle_golden import PINNED_KW, PINNED_SIZE, drop_exact_zero_gradients, load_pinned, pinned_scale
+    expt = "hologan"
+    inputs, golden, tape = load_pinned(expt)
+    scale = pinned_scale(expt)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    oracle = build_oracle_step(expt, PINNED_SIZE)
+    with pinned_oracle_masks(oracle, tape.rewind()):
+        cpu = scenario.run_scenario(oracle, inputs, "cpu", full=True, **PINNED_KW)
+    # (on the host the fixture was made on the oracle takes every one of these decisions by itself -- CPU suite; another
+    # CPU model / thread count moves a handful of pre-activations of ~1e-6 across zero: the replay pins them)
+    assert tape.cursor == len(tape.masks)
+    assert sum(m[1] for m in tape.mismatches) <= 64 and all(m[3] <= 1e-4 for m in tape.mismatches), tape.mismatches
+    product = build_product_step(expt, PINNED_SIZE)
+    product.real_first = False    # the reference's decisions are taped in ITS call order (G(z), D(real), D(fake))
+    product.stack_d_passes = False
+    with pinned_product_masks(tape.rewind()):
+        hip = scenario.run_scenario(product, inputs, "cuda", full=True, **PINNED_KW)
+    tape._skip_reserved()
+    assert tape.cursor == len(tape.masks), "product and reference took different numbers of mask decisions"
+    total = sum(m.numel() for m in tape.masks)
+    flips = sum(m[1] for m in tape.mismatches)
+    print(f"hologan: the product alone would decide {flips} of {total} mask entries differently "
+          f"(largest |pre-activation| among them {max([m[3] for m in tape.mismatches], default=0.0):.1e})")
+    assert flips <= 1e-4 * total and all(m[3] <= 3e-4 for m in tape.mismatches), tape.mismatches
+    cpu, hip, golden = (drop_exact_zero_gradients(d) for d in (cpu, hip, golden))
+    assert set(hip) == set(cpu) == set(golden)
+    worst = []
+    for k, ref in cpu.items():
+        got = np.asarray(hip[k], dtype=np.float64)
+        ref = np.asarray(ref, dtype=np.float64)
+        if np.asarray(cpu[k]).dtype.kind in "iu":
+            assert np.array_equal(hip[k], cpu[k]) and np.array_equal(hip[k], golden[k]), k
+            continue
+        if ref.ndim == 0:
+            e = abs(float(got) - float(ref)) / max(abs(float(ref)), scale)
+        elif k.startswith("grad"):
+            e = float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))        # full relative L2
+        else:
+            e = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+        worst.append((e, k))
+    worst.sort(reverse=True)
+    print(f"hologan: product vs pinned oracle, worst of {len(worst)}:", [(k, f"{e:.1e}") for e, k in worst[:4]])
+    assert worst[0][0] <= TOL, worst[:4]
+    summ = {k: (v if np.asarray(v).ndim == 0 or not k.startswith(("grad", "final/")) else
+                scenario.summarize(torch.from_numpy(np.asarray(v)))) for k, v in hip.items()}
+    w = compare(summ, golden, TOL, "hip hologan/full/pinned vs reference", atol_scale=scale)
+    print(f"hologan: product vs reference fixture, worst {w[3]} {w[1]:.1e}")
+
+
 @pytest.mark.parametrize("expt", ["dc_gan", "wgan", "wgan_gp", "hologan"])
 def test_real_first_order_is_bit_identical_to_the_reference_order(expt):
     """Discriminator steps launch D(real) before G(z) (``BaseGAN.real_first``: under data parallelism the generator's
