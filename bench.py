@@ -74,6 +74,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay each optimizer step from a captured HIP graph (single GPU)")
+    ap.add_argument("--fid-samples", type=int, default=50000,
+                    help="images of the FID feature pass sub-record (sub_configs.fid50k_features); 0 skips it")
     ap.add_argument("--no-gradsync-w1", action="store_true",
                     help="skip the single-rank-RCCL GradSync sub-records of the default run")
     ap.add_argument("--force-grad-sync", action="store_true",
@@ -362,6 +364,59 @@ def measure(F, expt, batch, img_size, device, rank, world, steps, warmup, reps, 
     return rec
 
 
+def fid50k_record(device, n_samples=50000, batch=250):
+    """BASELINE.json's metric also names FID@50k.  FID *numbers* need the reference's weight file (a URL; no network),
+    but the WORK of a 50 000-sample FID pass is well defined and is timed here on the HIP path: the eval-mode
+    generator sweep over fixed latents (core/callback_inception_metrics.py:183-198: clamp to [0, 1], x 255 -> integer ->
+    image file -> ToTensor: the uint8 round trip is done on the device) and the 2048-d InceptionV3 pool features of
+    every image (:204-222; bilinear resize to 299 x 299, the FID-patched torchvision network, pinned to the reference's
+    own code by tests/golden/inception_ref.npz) -- random-init weights of the right architecture, as for the training
+    benchmark.  Frechet distance / KID on the 50 000 x 2048 activations are host-side scipy arithmetic (eval.py) and
+    are not part of the timed region.  ``roofline.whole_step`` prices generator + Inception convolution FLOP per second
+    against the fp32 MFMA peak."""
+    import torch
+    from lightning_gan_zoo_amd import inception as I
+    from lightning_gan_zoo_amd.config import locate, make_cfg
+    cfg = make_cfg("dc_gan", batch_size=batch)
+    torch.manual_seed(42)
+    module = locate(cfg.model.lm["_target_"])(cfg, None).to(device).eval()
+    net = I.FIDInceptionV3().to(device)
+    g = torch.Generator().manual_seed(7)
+    z_all = torch.randn(n_samples, cfg.model.noise_dim, generator=g)
+    feats = torch.empty(n_samples, 2048, device=device)
+
+    @torch.no_grad()
+    def sweep(lo, hi):
+        for i in range(lo, hi, batch):
+            z = z_all[i:i + batch].to(device, non_blocking=True)
+            x = torch.clamp(module.generator(z), 0, 1)
+            x = (x * 255).to(torch.int32).to(torch.float32) / 255           # PNG round trip: truncation to 8 bits
+            feats[i:i + len(z)] = net(x)
+
+    sweep(0, 2 * batch)                      # warm-up: allocator, folded weights
+    torch.cuda.synchronize()
+    I.FLOPS = [0.0]
+    sweep(0, batch)
+    inception_flop_per_image = I.FLOPS[0] / batch
+    I.FLOPS = None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sweep(0, n_samples)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    g_flop = 2 * 410_583_040                 # SURVEY 8: generator forward, 64x64
+    flop = (inception_flop_per_image + g_flop) * n_samples
+    ok = bool(torch.isfinite(feats).all())
+    del module, net, feats
+    torch.cuda.empty_cache()
+    return {"workload": "FID@50k feature pass: DCGAN generator sweep (eval mode) + InceptionV3 pool3 features of %d "
+                        "images at 299x299, batches of %d, fp32, random-init weights" % (n_samples, batch),
+            "seconds": round(dt, 3), "value": round(n_samples / dt, 1), "unit": "images/s", "finite": ok,
+            "flop_per_image": {"inception": inception_flop_per_image, "generator": g_flop},
+            "roofline": {"whole_step": {"flop_per_step": flop, "achieved": round(flop / dt / 1e12, 2),
+                                        "frac": round(flop / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}}}
+
+
 class single_rank_rccl:
     """A one-rank RCCL communicator with GZ_DDP_ALWAYS_REDUCE (ddp.GradSync then really issues its all-reduces) and
     GZ_DDP_MEASURE (events around every wait for a bucket): the data-parallel code path on one GPU."""
@@ -503,6 +558,11 @@ def run_rank(args):
                 out["sub_configs"].update(gradsync_w1_records(F, args, device, use_timer, out, head_key))
             except Exception as e:  # noqa: BLE001 -- a broken RCCL install must not take the headline number with it
                 out["sub_configs"]["dc_gan_bs128_gradsync_w1"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and args.fid_samples > 0:
+            try:
+                out["sub_configs"]["fid50k_features"] = fid50k_record(device, args.fid_samples)
+            except Exception as e:  # noqa: BLE001
+                out["sub_configs"]["fid50k_features"] = {"error": "%s: %s" % (type(e).__name__, e)}
         big = out["sub_configs"].get("dc_gan_bs512")
         if big is not None and rank == 0:
             w = (big.get("roofline") or {}).get("whole_step") or {}

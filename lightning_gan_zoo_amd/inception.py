@@ -31,6 +31,7 @@ def _pool(x, ks, stride, pad, mode):
 
 
 MAX, AVG_NOPAD, AVG = 0, 1, 2
+FLOPS = None          # bench.py: a one-element list that accumulates the convolutions' algorithmic FLOP (2 x MAC)
 
 
 class BasicConv2d(nn.Module):
@@ -67,6 +68,8 @@ class BasicConv2d(nn.Module):
         (KH, KW), (SH, SW), (PH, PW) = c.kernel_size, c.stride, c.padding
         OH, OW = (H + 2 * PH - KH) // SH + 1, (W + 2 * PW - KW) // SW + 1
         y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
+        if FLOPS is not None:
+            FLOPS[0] += 2.0 * N * OH * OW * K * C * KH * KW
         ws, nbytes = F._scratch(lib.gz_conv2d_fwd_any_workspace_bytes(N, C, H, W, K, OH, OW, KH, KW, SH, SW, PH, PW),
                                 x.device)
         check(lib.gz_conv2d_fwd_any(_p(x), _p(wp), _p(b), _p(y), _p(ws), nbytes, N, C, H, W, K, OH, OW, KH, KW, SH, SW,
@@ -203,13 +206,32 @@ class FIDInceptionV3(nn.Module):
         return _pool(x, x.shape[2], 1, 0, AVG).reshape(N, -1)
 
 
-def load_fid_weights(path, device="cuda"):
+FID_WEIGHTS_SHA256_PREFIX = "6726825d"       # pt_inception-2015-12-05-<sha256[:8]>.pth (reference inception.py:13)
+
+
+def fid_weights_state(path, check_hash=True):
+    """The state dict of the reference's weight file.  ``check_hash``: the file must be the published one -- torch.hub
+    names its files ``<name>-<first 8 hex digits of the sha256>.pth`` and ``load_state_dict_from_url(check_hash=...)``
+    verifies exactly that prefix; a different file gives FID numbers that compare with nobody's."""
+    if check_hash:
+        import hashlib
+        h = hashlib.sha256()
+        with open(path, "rb") as f:
+            for block in iter(lambda: f.read(1 << 20), b""):
+                h.update(block)
+        if not h.hexdigest().startswith(FID_WEIGHTS_SHA256_PREFIX):
+            raise RuntimeError("lightning_gan_zoo_amd: %s is not pytorch-fid's pt_inception-2015-12-05 weight file "
+                               "(sha256 %s..., expected %s...); pass check_hash=False to load it anyway"
+                               % (path, h.hexdigest()[:8], FID_WEIGHTS_SHA256_PREFIX))
+    state = torch.load(path, map_location="cpu")
+    return state.get("state_dict", state) if isinstance(state, dict) else state
+
+
+def load_fid_weights(path, device="cuda", check_hash=True):
     """The reference's weight file (pytorch-fid's ``pt_inception-2015-12-05-6726825d.pth``: a torchvision-keyed
     state_dict) -> a ready feature extractor."""
     net = FIDInceptionV3()
-    state = torch.load(path, map_location="cpu")
-    state = state.get("state_dict", state) if isinstance(state, dict) else state
-    net.load_state_dict(state)
+    net.load_state_dict(fid_weights_state(path, check_hash))
     return net.to(device)
 
 

@@ -35,7 +35,7 @@ from .config import ConfigError, compose_tree, locate, make_cfg, parse_value
 
 # keys of this runner, not of the reference's config (accepted with or without Hydra's "+")
 RUNNER_KEYS = {"max_steps": None, "log_every": 10, "dataset_path": None, "seed": 42, "steps_per_epoch": 100,
-               "inception_weights": None}
+               "inception_weights": None, "inception_check_hash": True}
 BUILTIN_DATASETS = ("synthetic", "image_folder", "tensor_file", "celeb_a")
 LIGHTNING_VERSION_TAG = "1.2.0"       # envelope layout written below (Lightning 1.1 / 1.2 generation)
 
@@ -575,7 +575,8 @@ def make_fid_evaluator(cfg, run, module, device):
         return None
     from . import eval as E
     from .inception import InceptionFeatures, load_fid_weights
-    features = InceptionFeatures(load_fid_weights(run["inception_weights"], device))
+    features = InceptionFeatures(load_fid_weights(run["inception_weights"], device,
+                                                  check_hash=bool(run.get("inception_check_hash", True))))
     n = int((cfg.get("val") or {}).get("fid_n_samples", 5000))
     dump = E.SampleDump(module, n_samples=n, batch_size=16)          # host RNG draw, right after the module is built
     # before training starts, persisted next to the images: a resume or the next launch loads it, and under data

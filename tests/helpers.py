@@ -83,3 +83,25 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     denom = max(np.abs(b).max(), 1e-30)
     return float(np.abs(a - b).max() / denom)
+
+
+def seeded_inception_state(net, seed=0):
+    """A state dict for an InceptionV3 (torchvision keys): He-scaled convolution weights, BatchNorm affine / running
+    statistics away from their defaults.  Drawn key by key in state_dict order from ONE seeded host generator, so the
+    reference-built network (tests/golden/make_inception_golden.py), the CPU oracle and the product get the same
+    numbers as long as their state_dict key order agrees -- which the fixture also pins."""
+    g = torch.Generator().manual_seed(seed)
+    sd = net.state_dict()
+    for k, v in sd.items():
+        if k.endswith("conv.weight"):
+            fan_in = v[0].numel()
+            sd[k] = torch.randn(v.shape, generator=g) * (2.0 / fan_in) ** 0.5
+        elif k.endswith("bn.weight"):
+            sd[k] = 1 + 0.2 * (torch.rand(v.shape, generator=g) - 0.5)
+        elif k.endswith("bn.bias"):
+            sd[k] = 0.2 * (torch.rand(v.shape, generator=g) - 0.5)
+        elif k.endswith("running_mean"):
+            sd[k] = 0.2 * torch.randn(v.shape, generator=g)
+        elif k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(v.shape, generator=g)
+    return sd

@@ -1,6 +1,15 @@
-"""the FID / KID feature extractor (InceptionV3 with the FID patches) on the HIP convolution family
-against the CPU oracle (oracle/inception_cpu.py) with seeded weights, plus its three new operators against torch.
-The real weight file comes from a URL (no network here): what is pinned is the ARCHITECTURE and the arithmetic."""
+"""the FID / KID feature extractor (InceptionV3 with the FID patches) on the HIP convolution family.
+
+Round 5: pinned to the REFERENCE'S OWN network code.  tests/golden/inception_ref.npz holds the 2048-d pool features (and
+logits) that ``InceptionV3([3])`` of /root/reference/core/submodules/gan_stability/metrics/inception.py -- run unmodified
+by tests/golden/make_inception_golden.py over torchvision's layer definitions (restated in
+oracle/torchvision_inception.py: torchvision is absent) -- produces for seeded weights and seeded inputs;
+inception_state_keys.json is the state_dict listing of the network that code builds.  The CPU oracle
+(oracle/inception_cpu.py) and the HIP network are both held to those numbers.  The real weight FILE comes from a URL (no
+network here): what is pinned is the architecture and the arithmetic; ``load_fid_weights`` verifies the file's sha256
+prefix (the ``6726825d`` of its published name) when a user supplies it."""
+import json
+import os
 import numpy as np
 import pytest
 import torch
@@ -14,23 +23,60 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-def seeded_state(net, seed=0):
-    """He-scaled convolution weights, BatchNorm affine / running statistics away from their defaults."""
-    g = torch.Generator().manual_seed(seed)
-    sd = net.state_dict()
-    for k, v in sd.items():
-        if k.endswith("conv.weight"):
-            fan_in = v[0].numel()
-            sd[k] = torch.randn(v.shape, generator=g) * (2.0 / fan_in) ** 0.5
-        elif k.endswith("bn.weight"):
-            sd[k] = 1 + 0.2 * (torch.rand(v.shape, generator=g) - 0.5)
-        elif k.endswith("bn.bias"):
-            sd[k] = 0.2 * (torch.rand(v.shape, generator=g) - 0.5)
-        elif k.endswith("running_mean"):
-            sd[k] = 0.2 * torch.randn(v.shape, generator=g)
-        elif k.endswith("running_var"):
-            sd[k] = 0.5 + torch.rand(v.shape, generator=g)
-    return sd
+from helpers import seeded_inception_state as seeded_state  # noqa: E402
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ((64, 2), (299, 2), (32, 3), (128, 1))       # tests/golden/make_inception_golden.py
+
+
+def reference_features():
+    blob = np.load(os.path.join(GOLDEN, "inception_ref.npz"))
+    return int(blob["seed"]), {size: torch.from_numpy(blob["pool3/%d" % size]) for size, _ in CASES}
+
+
+def test_state_dict_listing_is_the_one_the_reference_code_builds():
+    """Key order, shapes and dtypes of the product network and of the CPU oracle == the state_dict of
+    ``fid_inception_v3()`` as the reference's code builds it (inception_state_keys.json): the weight file the reference
+    downloads loads into either without renaming."""
+    from lightning_gan_zoo_amd.inception import FIDInceptionV3
+    from oracle.inception_cpu import FIDInceptionV3 as Oracle
+    with open(os.path.join(GOLDEN, "inception_state_keys.json")) as f:
+        ref = json.load(f)
+    assert ref["weights_url"].endswith("pt_inception-2015-12-05-6726825d.pth")
+    want = [(k, tuple(shape), dt) for k, shape, dt in ref["keys"]]
+    for net in (FIDInceptionV3(), Oracle()):
+        got = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in net.state_dict().items()]
+        assert got == want
+
+
+def test_oracle_inception_matches_the_reference_fixture():
+    """oracle/inception_cpu.py (the flat restatement the GPU box uses as its checker) against the features the
+    reference's own InceptionV3 produced: same seeded weights, same seeded inputs, 1e-5."""
+    from oracle.inception_cpu import FIDInceptionV3 as Oracle
+    torch.set_num_threads(4)
+    seed, feats = reference_features()
+    oracle = Oracle().eval()
+    oracle.load_state_dict(seeded_state(oracle, seed))
+    for size, n in CASES:
+        x = torch.rand(n, 3, size, size, generator=torch.Generator().manual_seed(size))
+        with torch.no_grad():
+            out = oracle(x)
+        assert out.shape == feats[size].shape and rel(out, feats[size]) < 1e-5, (size, rel(out, feats[size]))
+
+
+def test_fid_weight_file_hash_is_checked(tmp_path):
+    """``load_fid_weights``: a file that is not the published one (sha256 prefix 6726825d, the suffix of its name in
+    the reference's URL, inception.py:13) is refused unless the caller opts out."""
+    from lightning_gan_zoo_amd import inception as I
+    from oracle.inception_cpu import FIDInceptionV3 as Oracle
+    path = str(tmp_path / "pt_inception-2015-12-05-6726825d.pth")
+    torch.save(seeded_state(Oracle(), 1), path)
+    with pytest.raises(RuntimeError, match="sha256"):
+        I.fid_weights_state(path)
+    sd = I.fid_weights_state(path, check_hash=False)
+    assert "Mixed_7c.branch_pool.bn.running_var" in sd
+    assert I.FID_WEIGHTS_SHA256_PREFIX == "6726825d"
 
 
 def test_state_dict_layout_is_torchvisions():
@@ -98,6 +144,23 @@ def test_pool_and_resize():
         out = torch.empty(2, 3, OH, OW, device="cuda")
         check(lib.gz_resize_bilinear(F._p(img.cuda()), F._p(out), 6, H, W, OH, OW, 2.0, -1.0, F._stream()), "resize")
         assert rel(out, ref) < 1e-5
+
+
+@pytest.mark.gpu
+def test_inception_pool_features_match_the_reference_fixture():
+    """The HIP network against the features the reference's own InceptionV3 code produced (inception_ref.npz): 64x64,
+    299x299, 32x32 and 128x128 inputs, seeded weights, 1e-3."""
+    from lightning_gan_zoo_amd.inception import FIDInceptionV3
+    seed, feats = reference_features()
+    net = FIDInceptionV3()
+    net.load_state_dict(seeded_state(net, seed))
+    net.cuda()
+    for size, n in CASES:
+        x = torch.rand(n, 3, size, size, generator=torch.Generator().manual_seed(size))
+        out = net(x.cuda())
+        err = rel(out, feats[size])
+        print(f"inception features at {size}x{size} vs the reference fixture: rel err {err:.1e}")
+        assert out.shape == feats[size].shape and err < TOL
 
 
 @pytest.mark.gpu
