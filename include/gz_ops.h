@@ -343,6 +343,12 @@ int gz_batchnorm_stats_g(const float* x, const float* gamma, const float* beta, 
 int gz_batchnorm_finalize_g(const float* partials, int rows, long long count, const float* gamma, const float* beta,
                             float* coef, float* running_mean, float* running_var, long long* num_batches_tracked,
                             int C, float eps, float momentum, int groups, hipStream_t stream);
+/* round 5: training-mode BatchNorm + activation forward with the finalize folded into the apply launch (one launch
+ * when the producing convolution supplied `partials`; partials == NULL: row sums of x into `workspace` first) */
+int gz_batchnorm_act_fwd_fused(const float* x, const float* partials, int rows, long long count, const float* gamma,
+                               const float* beta, float* coef, float* running_mean, float* running_var,
+                               long long* num_batches_tracked, void* workspace, float* out, int N, int C, int inner,
+                               float eps, float momentum, int groups, int act, float slope, hipStream_t stream);
 int gz_norm_act_fwd_g(const float* x, const float* coef, float* out, int N, int C, int inner, int per_channel,
                       int groups, int act, float slope, hipStream_t stream);
 int gz_rownorm_act_bwd_acc(const float* gout, const float* x, const float* coef, float* dx, float* dgamma, float* dbeta,

@@ -2588,6 +2588,15 @@ static const char* tile_text(TileId t) {
     }
 }
 
+// does this igemm2 launch run two wave groups per workgroup (gz_igemm.h: igemm2_use_kg2)?  The launcher's own arithmetic.
+static bool kg2_applies(TileId t, long long M, long long N, int ny, int kdim, int splits, bool rows_loader) {
+    if (!rows_loader || !(t == T256x128 || t == T256x64)) return false;
+    const int chunks = (kdim + BK - 1) / BK;
+    const int cps = (chunks + (splits < 1 ? 1 : splits) - 1) / (splits < 1 ? 1 : splits);
+    const int nz = (chunks + cps - 1) / cps;
+    return igemm2_use_kg2(tile_count(t, M, N, ny) * nz, cps);
+}
+
 template <class G>
 static int describe_fwd(const ConvShape& s, char* b, size_t n) {
     if (G::kh == 3 && G::kw == 3 && G::s == 1 && G::p == 1 && conv3_smallch_ok(s.N, s.C, s.K, s.H, s.W))
@@ -2598,9 +2607,10 @@ static int describe_fwd(const ConvShape& s, char* b, size_t n) {
     if (is_tile2(sp.tile)) {
         const bool rowsA = fwd2_ok<G>(s);
         const int kdim = rowsA ? s.C * 16 : G::kh * G::kw * round_bk(s.C);
-        return snprintf(b, n, "F igemm2<%s> %s slabs=%d bn_stats_rows=%d", tile_text(sp.tile),
+        const bool kg2 = kg2_applies(sp.tile, (long long)s.N * s.OH * s.OW, s.K, 1, kdim, sp.splits, rowsA);
+        return snprintf(b, n, "F igemm2<%s> %s slabs=%d bn_stats_rows=%d%s", tile_text(sp.tile),
                         rowsA ? "ConvFwdA2(raw rows, LDS-DMA 16B)" : "ConvTapA2(gather, LDS-DMA 4B)",
-                        split_nz(kdim, sp.splits), rows);
+                        split_nz(kdim, sp.splits), rows, kg2 ? " wave_groups=2" : "");
     }
     const char* loader = "ConvFwdALoader";
     const int bm = sp.tile == T64x64 ? 64 : 128;
@@ -2633,8 +2643,11 @@ static int describe_dgrad(const ConvShape& s, char* b, size_t n) {
     const int kk = tapm ? round_bk(s.K) : s.K;
     if (is_tile2(sp.tile)) {
         const bool rowsA = dgrad2_ok<G>(s);
-        return snprintf(b, n, "Dg igemm2<%s> %s splits=%d bn_stats_rows=%d", tile_text(sp.tile),
-                        rowsA ? "ConvDgA2(row-shared, LDS-DMA 16B)" : "ConvDgTapA2(gather, LDS-DMA 4B)", sp.splits, rows);
+        const bool kg2 = kg2_applies(sp.tile, (long long)s.N * (s.H / G::s) * (s.W / G::s), s.C, G::s * G::s, 4 * s.K,
+                                     sp.splits, rowsA);
+        return snprintf(b, n, "Dg igemm2<%s> %s splits=%d bn_stats_rows=%d%s", tile_text(sp.tile),
+                        rowsA ? "ConvDgA2(row-shared, LDS-DMA 16B)" : "ConvDgTapA2(gather, LDS-DMA 4B)", sp.splits, rows,
+                        kg2 ? " wave_groups=2" : "");
     }
     const char* loader = "ConvDgALoader";
     if (tapm && !(G::kh % G::s == 0 && G::kw % G::s == 0 && BK % TAPS == 0)) loader = "ConvDgALoaderTap";

@@ -2816,12 +2816,23 @@ struct fwd_ow_of<AL, std::void_t<decltype(AL::OW_C)>> { static constexpr int val
 template <class AL>
 constexpr int fwd_ow() { return fwd_ow_of<AL>::value; }
 
-template <class Cfg, class AL, class BL, class Epi>
-__global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Params pa, typename BL::Params pb,
-                                                              typename Epi::Params pe, GridMap gm) {
+// KG = 2 (round 5): TWO wave groups of four wavefronts in one 512-thread workgroup work on the SAME output tile, each on
+// half of the workgroup's reduction range with an LDS ring of its own, and meet in LDS at the end (group 1 parks its
+// accumulators, group 0 adds them and runs the epilogue).  For launches whose tiles x reduction splits give a CU only
+// one workgroup: the CU then still holds two wavefronts per SIMD -- the second one is what hides the non-MFMA
+// instructions of the k-step -- without the slabs + finish pass that a global split of the reduction costs.
+template <class Cfg, class AL, class BL, int KG>
+constexpr int igemm2_ring_floats() {
+    return ((STAGES2 * (AL::ROWS * AL::LD + igemm2_a_extra<AL>() + BL::ROWS * BL::LD) + 63) / 64) * 64;
+}
+
+template <class Cfg, class AL, class BL, class Epi, int KG = 1>
+__global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel(typename AL::Params pa, typename BL::Params pb,
+                                                                              typename Epi::Params pe, GridMap gm) {
     constexpr int LDA = AL::LD, LDB = BL::LD;
     constexpr int TM = Cfg::TM, TN = Cfg::TN;
     static_assert(TM == 4 && (TN == 1 || TN == 2 || TN == 4), "fragment registers of the hand-ordered k-step");
+    static_assert(KG == 1 || (KG == 2 && TN <= 2), "two wave groups: the parked accumulators must fit the LDS");
     constexpr bool RS = is_rowshare<AL>::value;
     constexpr bool FR = is_fwdrows<AL>::value;
     constexpr int A_EXTRA = igemm2_a_extra<AL>();
@@ -2829,14 +2840,15 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
     constexpr int STAGE = A_ELEMS + B_ELEMS;
     constexpr int PAD = 16;
     extern __shared__ __attribute__((aligned(16))) float smem2[];
-    float* const ring = smem2 + PAD;                     // stage i: [B image][A image]
+    const int kg = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);      // wave group
+    float* const ring = smem2 + PAD + kg * igemm2_ring_floats<Cfg, AL, BL, KG>();   // stage i: [B image][A image]
     GZ2_STAMP(st0);
 #ifdef GZ2_STAMPS
     const unsigned long long sr0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long st1 = st0, st2 = st0;
 #endif
 
-    const int tid = threadIdx.x;
+    const int tid = KG == 1 ? (int)threadIdx.x : ((int)threadIdx.x & (NT - 1));     // inside the wave group
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
     // (experiment, off by default -- see launch_igemm2)  The first-round workgroup in the CU's odd thread-group slot
@@ -2865,9 +2877,18 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
     const int tile_n = bid % gm.tiles_n;
     const int tile_m = bid / gm.tiles_n;
     const int z = blockIdx.z;
-    const int kc0 = z * gm.chunks_per_split;
-    const int kc1 = min(gm.var_chunks ? gm.phase_chunks[y] : gm.chunks, kc0 + gm.chunks_per_split);
-    if (gm.slab && gm.var_chunks && kc0 >= kc1) return;      // past this phase's last slab (uniform per workgroup)
+    const int kcA = z * gm.chunks_per_split;                 // the workgroup's reduction range [kcA, kcB)
+    const int kcB = min(gm.var_chunks ? gm.phase_chunks[y] : gm.chunks, kcA + gm.chunks_per_split);
+    if (gm.slab && gm.var_chunks && kcA >= kcB) return;      // past this phase's last slab (uniform per workgroup)
+    // this wave group's share: chunks [kc0, kc1) are live; the loop runs to kend in BOTH groups (same barrier count),
+    // the chunks past kc1 arrive as zeros (out-of-range LDS-DMA) and add nothing
+    int kc0 = kcA, kc1 = kcB, kend = kcB;
+    if constexpr (KG == 2) {
+        const int h = (kcB - kcA + 1) >> 1;
+        kc0 = kcA + kg * h;
+        kend = kc0 + h;
+        kc1 = min(kcB, kend);
+    }
 
     AL al;
     BL bl;
@@ -2964,9 +2985,9 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
     };
     auto mask = [&](float (&)[TM]) {};      // (row-shared images: the zero column replaces the register masks)
 
-    if (kc0 < kc1) {
+    if (kcA < kcB) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) issue_piece(kc0, 0, p, true);
+        for (int p = 0; p < NP; ++p) issue_piece(kc0, 0, p, kc0 < kc1);
 #pragma unroll
         for (int p = 0; p < NP; ++p) issue_piece(kc0 + 1, 1, p, kc0 + 1 < kc1);
         // lgkmcnt(0) as well: the zeroed pad columns / A_EXTRA region above were plain ds_writes, and gfx950's back-off
@@ -2988,7 +3009,7 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
         lgkm_done(af[0], bf[0]);
         mask(af[0]);
         int stage = 0;
-        for (int kc = kc0; kc < kc1; ++kc) {
+        for (int kc = kc0; kc < kend; ++kc) {
             int s1 = stage + 1; if (s1 >= STAGES2) s1 -= STAGES2;
             int s2 = s1 + 1; if (s2 >= STAGES2) s2 -= STAGES2;
             const uint32_t so = (uint32_t)(stage * STAGE * 4), sno = (uint32_t)(s1 * STAGE * 4);
@@ -3067,6 +3088,29 @@ __global__ __launch_bounds__(NT, Cfg::OCC) void igemm2_kernel(typename AL::Param
 #endif
     }
 
+    if constexpr (KG == 2) {
+        // the two halves of the reduction meet: group 1 parks its accumulators in LDS (the rings are done with:
+        // [register][thread], conflict-free), group 0 adds them -- a + b, the same bits whichever group held which half
+        // -- and alone runs the epilogue
+        __syncthreads();
+        float* const park = smem2;
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) park[((i * TN + j) * 16 + r) * NT + tid] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += park[((i * TN + j) * 16 + r) * NT + tid];
+    }
 #ifdef GZ2_EXP_NOSTORE   // timing experiment: keep one store so the accumulators stay live
     if (acc[0][0][0] == 123456.789f)
 #endif
@@ -3608,6 +3652,24 @@ template <class Cfg, class AL, class BL>
 constexpr size_t igemm2_lds_bytes() {
     return (size_t)(STAGES2 * (AL::ROWS * AL::LD + igemm2_a_extra<AL>() + BL::ROWS * BL::LD) + 32) * 4;
 }
+template <class Cfg, class AL, class BL>
+constexpr size_t igemm2_lds_bytes_kg2() {
+    const size_t rings = (size_t)(2 * igemm2_ring_floats<Cfg, AL, BL, 2>() + 32) * 4;
+    const size_t park = (size_t)Cfg::TM * Cfg::TN * 16 * NT * 4;
+    return rings > park ? rings : park;
+}
+
+// Which launches run two wave groups per workgroup (igemm2_kernel<.., KG = 2>): the k4 s2 p1 loaders of the DCGAN
+// layers, 128- or 64-wide tiles, when the grid gives a CU at most ONE workgroup and each group still has a reduction
+// worth pipelining.  Pure host logic: gz_conv2d_plan reports it, tests/golden/dispatch_plan.json pins it.
+template <class Cfg, class AL>
+constexpr bool igemm2_kg2_built() {
+    return Cfg::TN <= 2 && Cfg::WM * Cfg::WN == 4 && Cfg::WN == 2 && (is_rowshare<AL>::value || is_fwdrows<AL>::value);
+}
+inline bool igemm2_use_kg2(long long workgroups, int chunks_per_workgroup) {
+    if (knobs().no_kg2) return false;
+    return workgroups <= cus() && chunks_per_workgroup >= knobs().kg2_min_chunks;
+}
 
 // same contract as launch_igemm
 template <class Cfg, class AL, class BL, class Epi>
@@ -3661,6 +3723,22 @@ inline int launch_igemm2(const typename AL::Params& pa, const typename BL::Param
         at += n;
     }
     const size_t lds_extra = (size_t)knobs().igemm2_lds;   // experiment:
+    bool launched = false;
+    if constexpr (igemm2_kg2_built<Cfg, AL>()) {
+        if (igemm2_use_kg2((long long)grid.x * nz, gm.chunks_per_split)) {
+            const size_t lds2 = igemm2_lds_bytes_kg2<Cfg, AL, BL>();
+            auto kern2 = igemm2_kernel<Cfg, AL, BL, Epi, 2>;
+            static bool attr2_done = false;
+            if (!attr2_done) {
+                if (hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+                    return launch_status();
+                attr2_done = true;
+            }
+            hipLaunchKernelGGL(kern2, grid, dim3(2 * NT), lds2, stream, pa, pb, pe, gm);
+            launched = true;
+        }
+    }
+    if (!launched) {
     const size_t lds = igemm2_lds_bytes<Cfg, AL, BL>() + lds_extra;             // throttles workgroups per CU
     auto kern = igemm2_kernel<Cfg, AL, BL, Epi>;
     static bool attr_done = false;       // per instantiation
@@ -3670,6 +3748,7 @@ inline int launch_igemm2(const typename AL::Params& pa, const typename BL::Param
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, pa, pb, pe, gm);
+    }
     if (gm.slab) {
         const int fm = (M + 31) / 32, fn = (N + 31) / 32;
         if (nz > 16)

@@ -30,6 +30,8 @@ namespace gz {
     X(bool, no_igemm2wg, "GZ_NO_IGEMM2WG", false)           /* ... its generic-geometry image only */               \
     X(int, igemm2_tile, "GZ_IGEMM2_TILE", 0)                /* 128 / 256: force the igemm2 N tile */                 \
     X(bool, no_tile64, "GZ_NO_TILE64", false)               /* round 4's 256x64 igemm2 tile off */                   \
+    X(bool, no_kg2, "GZ_NO_KG2", false)                     /* round 5's two wave groups per workgroup off */        \
+    X(int, kg2_min_chunks, "GZ_KG2_MIN_CHUNKS", 32)         /* ... chunks per workgroup at least */                  \
     X(int, tap64_min_chunks, "GZ_TAP64_MIN_CHUNKS", 32)     /* gather-loader launches too small for 256x128 take 256x64 tiles with >= this many chunks per piece (0: off) */ \
     X(int, tile, "GZ_TILE", -1)                             /* 0..3: force the igemm_kernel tile */                  \
     X(int, min_wgs, "GZ_MIN_WGS", 0)                        /* > 0: the round-1 tile rule with this target */        \

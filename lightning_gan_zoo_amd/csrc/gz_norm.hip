@@ -196,6 +196,111 @@ __global__ __launch_bounds__(PW_THREADS) void norm_act_apply_kernel(const float*
     }
 }
 
+// ---------------------------------------------------------------------------
+// BatchNorm (training): finalize + apply in ONE launch (round 5)
+// ---------------------------------------------------------------------------
+// A G+D pair at bs 128 ran 12 bn_finalize + 10 bn_bwd_finalize launches of ~5 us each whose only job was to turn partial
+// sums into per-channel coefficients for the kernel right behind them -- 0.11 ms of kernels plus a dependent-launch gap
+// each.  Here the consumer does it itself: workgroup (channel c, statistics group g, slice s of the group's samples)
+// reduces the partial rows of its own (g, c) -- a few KB, cache-resident, fp64 like the separate kernel -- and then
+// streams its slice of channel c's planes.  The workgroup with g = 0, s = 0 ("owner") reduces EVERY group: it writes
+// the coefficient array the backward pass reads and updates the running buffers group after group (real, then fake),
+// as the separate finalize did.
+struct BnFuse {
+    int N, C, q4, groups, Ng, S, P;     // S slices per (channel, group), P samples per slice
+    FastDiv div_q4;
+};
+
+static BnFuse bn_fuse_geom(int N, int C, int inner, int groups) {
+    BnFuse f;
+    f.N = N; f.C = C; f.q4 = inner / 4; f.groups = groups; f.Ng = N / groups;
+    f.div_q4 = make_fastdiv(f.q4);
+    // >= ~1024 workgroups, each with >= 512 float4 where the tensor allows
+    long long per_cg = (long long)f.Ng * f.q4;
+    int S = 1;
+    while ((long long)C * groups * S < 1024 && S * 2 <= f.Ng && per_cg / (S * 2) >= 512) S *= 2;
+    f.S = S;
+    f.P = (f.Ng + S - 1) / S;
+    return f;
+}
+
+__device__ __forceinline__ void block_sum2_d(double& s1, double& s2, double (*part)[2]) {
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    __syncthreads();                       // (the previous use of `part` is over)
+    if ((threadIdx.x & 63) == 0) {
+        part[threadIdx.x >> 6][0] = s1;
+        part[threadIdx.x >> 6][1] = s2;
+    }
+    __syncthreads();
+    s1 = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
+    s2 = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
+}
+
+__global__ __launch_bounds__(PW_THREADS) void bn_apply_fused_kernel(
+    const float* __restrict__ x, const f32x2* __restrict__ sums, int rows, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ coef, float* running_mean, float* running_var, long long* nbt,
+    float* __restrict__ out, BnFuse f, int inner, float eps, float momentum, int act, float slope) {
+    __shared__ double part[4][2];
+    __shared__ float mine[2];
+    const int tid = threadIdx.x;
+    const int s = blockIdx.x % f.S, cg = blockIdx.x / f.S, g = cg % f.groups, c = cg / f.groups;
+    const bool owner = g == 0 && s == 0;
+    const int Rg = rows / f.groups, NC = f.groups * f.C;
+    for (int gg = 0; gg < f.groups; ++gg) {
+        if (!owner && gg != g) continue;                       // (uniform per workgroup)
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = tid; r < Rg; r += PW_THREADS) {
+            const f32x2 v = sums[(long long)(gg * Rg + r) * f.C + c];
+            s1 += (double)v.x;
+            s2 += (double)v.y;
+        }
+        block_sum2_d(s1, s2, part);
+        if (tid == 0) {
+            const double cnt = count > 0.0 ? count : (double)f.Ng * inner;
+            const double mean = s1 / cnt;
+            double var = s2 / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+            const float scale = ga * rstd, shift = be - (float)mean * scale;
+            if (gg == g) {
+                mine[0] = scale;
+                mine[1] = shift;
+            }
+            if (owner) {
+                const int ci = gg * f.C + c;
+                coef[ci] = scale;
+                coef[NC + ci] = shift;
+                coef[2 * NC + ci] = (float)mean;
+                coef[3 * NC + ci] = rstd;
+                if (running_mean) {
+                    const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+                    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+                    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+                }
+            }
+        }
+    }
+    if (owner && c == 0 && tid == 0 && nbt) *nbt += f.groups;
+    __syncthreads();
+    const float sc = mine[0], sh = mine[1];
+    const int n0 = g * f.Ng + s * f.P;
+    const int n1 = min(g * f.Ng + f.Ng, n0 + f.P);
+    const int total = (n1 - n0) * f.q4;
+    const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x);
+    f32x4* __restrict__ o4 = reinterpret_cast<f32x4*>(out);
+    for (int i = tid; i < total; i += PW_THREADS) {
+        const uint32_t p = fdiv((uint32_t)i, f.div_q4);
+        const long long idx = ((long long)(n0 + (int)p) * f.C + c) * f.q4 + (i - (int)p * f.q4);
+        const f32x4 v = x4[idx];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = act_fwd(v[k] * sc + sh, act, slope);
+        o4[idx] = o;
+    }
+}
+
 // Per-row statistics, their finalize and the apply in ONE launch (InstanceNorm / AdaIN; round 2): the sub-wave that
 // summed a row turns the sums into (scale, shift, mean, rstd) itself (gamma / beta per channel, per row, or per row
 // from a packed [N][2C] array: affine_per_row 0 / 1 / 2; unbiased = 1 uses var * n/(n-1)) and streams the row again while it is still in this CU's cache.  Replaces row_sums + row_finalize +
@@ -456,6 +561,73 @@ __global__ __launch_bounds__(PW_THREADS) void norm_bwd_apply_kernel(const float*
             o[q] = sc * (dz - k1 - xh * k2);
         }
         reinterpret_cast<f32x4*>(dx)[i] = o;
+    }
+}
+
+// BatchNorm backward, finalize + apply in ONE launch (see bn_apply_fused_kernel): workgroup (c, g, s) sums the row sums
+// (sum dz, sum dz xh) of its (g, c) over the group's samples, forms k1, k2 and streams dx for its slice; the owner
+// (g = 0, s = 0) also writes / adds dgamma[c], dbeta[c] summed over all groups (and k, for callers that read it).
+__global__ __launch_bounds__(PW_THREADS) void bn_bwd_apply_fused_kernel(
+    const float* __restrict__ gout, const float* __restrict__ x, const float* __restrict__ coef,
+    const f32x2* __restrict__ sums, float* __restrict__ kout, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ dx, BnFuse f, int inner, int act, float slope, int accumulate) {
+    __shared__ double part[4][2];
+    __shared__ float mine[2];
+    const int tid = threadIdx.x;
+    const int s = blockIdx.x % f.S, cg = blockIdx.x / f.S, g = cg % f.groups, c = cg / f.groups;
+    const bool owner = g == 0 && s == 0;
+    const int NC = f.groups * f.C;
+    double t1 = 0.0, t2 = 0.0;
+    for (int gg = 0; gg < f.groups; ++gg) {
+        if (!owner && gg != g) continue;
+        double s1 = 0.0, s2 = 0.0;
+        for (int n = tid; n < f.Ng; n += PW_THREADS) {
+            const f32x2 v = sums[(long long)(gg * f.Ng + n) * f.C + c];
+            s1 += (double)v.x;
+            s2 += (double)v.y;
+        }
+        block_sum2_d(s1, s2, part);
+        if (tid == 0) {
+            const double cnt = (double)f.Ng * inner;
+            const float k1 = (float)(s1 / cnt), k2 = (float)(s2 / cnt);
+            if (gg == g) {
+                mine[0] = k1;
+                mine[1] = k2;
+            }
+            if (owner && kout) {
+                kout[gg * f.C + c] = k1;
+                kout[NC + gg * f.C + c] = k2;
+            }
+            t1 += s1;
+            t2 += s2;
+        }
+    }
+    if (owner && tid == 0) {
+        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)t2;
+        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)t1;
+    }
+    __syncthreads();
+    const float k1 = mine[0], k2 = mine[1];
+    const int ci = g * f.C + c;
+    const float sc = coef[ci], sh = coef[NC + ci], mean = coef[2 * NC + ci], rstd = coef[3 * NC + ci];
+    const int n0 = g * f.Ng + s * f.P;
+    const int n1 = min(g * f.Ng + f.Ng, n0 + f.P);
+    const int total = (n1 - n0) * f.q4;
+    const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(gout);
+    f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(dx);
+    for (int i = tid; i < total; i += PW_THREADS) {
+        const uint32_t p = fdiv((uint32_t)i, f.div_q4);
+        const long long idx = ((long long)(n0 + (int)p) * f.C + c) * f.q4 + (i - (int)p * f.q4);
+        const f32x4 xv = x4[idx], gv = g4[idx];
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float dz = gv[q] * act_grad_z(xv[q] * sc + sh, act, slope);
+            const float xh = (xv[q] - mean) * rstd;
+            o[q] = sc * (dz - k1 - xh * k2);
+        }
+        d4[idx] = o;
     }
 }
 
@@ -839,6 +1011,35 @@ int gz_batchnorm_finalize_g(const float* partials, int rows, long long count, co
     return launch_status();
 }
 
+/* Training-mode BatchNorm + activation forward in as few launches as the statistics allow: with the producing
+ * convolution's partial rows (`partials`, rows, count per group) ONE launch (bn_apply_fused_kernel: finalize + apply);
+ * without (partials == NULL) the row sums of x first (workspace: gz_norm_workspace_bytes).  Same coefficient array,
+ * running-buffer update and group semantics as gz_batchnorm_finalize_g / gz_batchnorm_stats_g + gz_norm_act_fwd_g. */
+int gz_batchnorm_act_fwd_fused(const float* x, const float* partials, int rows, long long count, const float* gamma,
+                               const float* beta, float* coef, float* running_mean, float* running_var,
+                               long long* num_batches_tracked, void* workspace, float* out, int N, int C, int inner,
+                               float eps, float momentum, int groups, int act, float slope, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (!norm_shape_ok(N, C, inner) || !groups_ok(N, groups)) return GZ_ERR_BAD_SHAPE;
+    const f32x2* sums = (const f32x2*)partials;
+    double cnt = (double)count;
+    if (!partials) {
+        if (!workspace) return GZ_ERR_WORKSPACE;
+        RowGeom g = row_geom((long long)N * C, inner);
+        hipLaunchKernelGGL(row_sums_kernel, dim3(row_grid(g)), dim3(PW_THREADS), 0, stream, x, (f32x2*)workspace, g);
+        sums = (const f32x2*)workspace;
+        rows = N;
+        cnt = 0.0;
+    } else if (rows <= 0 || count <= 0 || rows % groups) {
+        return GZ_ERR_BAD_SHAPE;
+    }
+    const BnFuse f = bn_fuse_geom(N, C, inner, groups);
+    hipLaunchKernelGGL(bn_apply_fused_kernel, dim3(C * groups * f.S), dim3(PW_THREADS), 0, stream, x, sums, rows, cnt,
+                       gamma, beta, coef, running_mean, running_var, num_batches_tracked, out, f, inner, eps, momentum,
+                       act, slope);
+    return launch_status();
+}
+
 int gz_batchnorm_finalize(const float* partials, int rows, long long count, const float* gamma, const float* beta,
                           float* coef, float* running_mean, float* running_var, long long* num_batches_tracked, int C,
                           float eps, float momentum, hipStream_t stream) {
@@ -1004,6 +1205,12 @@ static int norm_act_bwd_impl(const float* gout, const float* x, const float* coe
     }
     hipLaunchKernelGGL(norm_bwd_rowsums_kernel, dim3(row_grid(rg)), dim3(PW_THREADS), 0, stream, gout, x, coef,
                        (f32x2*)workspace, rg, C, per_channel, g.ncoef, act, slope, g.group_rows);
+    if (per_channel && dx && !unfused) {
+        const BnFuse f = bn_fuse_geom(N, C, inner, groups);
+        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel, dim3(C * groups * f.S), dim3(PW_THREADS), 0, stream, gout, x, coef,
+                           (const f32x2*)workspace, kbuf, dgamma, dbeta, dx, f, inner, act, slope, accumulate);
+        return launch_status();
+    }
     if (per_channel) {
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, stream, (const f32x2*)workspace, kbuf, dgamma,
                            dbeta, N, C, inner, groups, accumulate);

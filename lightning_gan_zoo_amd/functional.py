@@ -294,6 +294,7 @@ def _conv_fwd_raw(x, w, bias, geom, act, slope):
 
 
 _NO_BN_FUSE = bool(os.environ.get("GZ_NO_BN_FUSE"))      # experiment: statistics by a separate pass, as in round 1
+_NORM_UNFUSED = bool(os.environ.get("GZ_BN_FINALIZE_LAUNCH"))    # experiment: the separate bn_finalize launch (round 4)
 
 
 def _conv_fwd_stats_raw(x, w, geom):
@@ -1064,6 +1065,18 @@ class _BatchNormAct(torch.autograd.Function):
             raise RuntimeError("statistics groups need training mode and a batch that is a multiple of the group count")
         coef = torch.empty(4 * groups * C, device=x.device, dtype=torch.float32)
         st = _stream()
+        if training and not _NORM_UNFUSED:
+            # finalize + apply in one launch (the statistics come from the convolution's epilogue, or from a row-sum pass)
+            out = torch.empty_like(x)
+            fused = stats is not None and stats.numel()
+            ws = None if fused else _norm_ws(x, N, C)
+            check(lib.gz_batchnorm_act_fwd_fused(_p(x), _p(stats) if fused else None, stats.shape[0] if fused else 0,
+                                                 (N // groups) * inner if fused else 0, _p(gamma), _p(beta), _p(coef),
+                                                 _p(running_mean), _p(running_var), _p(nbt), _p(ws), _p(out), N, C, inner,
+                                                 eps, momentum, groups, act, slope, st), "batchnorm_act_fwd_fused")
+            ctx.save_for_backward(x, coef, gamma, beta)
+            ctx.cfg = (N, C, inner, act, slope, training, groups)
+            return out
         if training and stats is not None and stats.numel():
             # partial sums written by the producing convolution's epilogue (conv2d_with_stats)
             check(lib.gz_batchnorm_finalize_g(_p(stats), stats.shape[0], (N // groups) * inner, _p(gamma), _p(beta),
