@@ -234,6 +234,10 @@ int gz_pair_loss(const float* x, float* loss, int n_each, float t0, float t1, in
 int gz_pair_loss_bwd(const float* x, const float* gloss, float* dx, int n_each, float t0, float t1, int mode,
                      hipStream_t stream);
 /* loss[0] = mean((a - b)^2): HoloGAN's q_loss (:226,234);  da[i] = 2 (a[i] - b[i]) gloss[0] / n */
+/* WGAN-GP penalty tail, core/utils/utils.py:55-57: out[0] = mean_n (sqrt(sumsq[n]) - 1)^2 and its gradient
+ * dsumsq[n] = gout[0] (sqrt(s) - 1) / (sqrt(s) N), 0 where s == 0 (torch.norm's subgradient at the origin) */
+int gz_gp_penalty(const float* sumsq, float* out, int n, hipStream_t stream);
+int gz_gp_penalty_bwd(const float* sumsq, const float* gout, float* dsumsq, int n, hipStream_t stream);
 int gz_mse_mean(const float* a, const float* b, float* loss, int n, hipStream_t stream);
 int gz_mse_mean_bwd(const float* a, const float* b, const float* gloss, float* da, int n, hipStream_t stream);
 /* torch.nn.utils.spectral_norm (core/models/hologan_discriminator.py:15): out = x / max(||x||, eps) (in place

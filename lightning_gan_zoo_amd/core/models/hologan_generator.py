@@ -124,6 +124,7 @@ class Generator(nn.Module):
         self.relu = nn.ReLU()
         self.tanh = nn.Tanh()
         self.staged_minv = None     # harness.GraphedTrainer: the step's inverse view matrices, already on the device
+        self._prefetched = None     # harness.Trainer: (matrices on the device, numpy state before, after, batch size)
 
     def sample_view(self, batch_size):
         """Transformation parameters from numpy's global generator, reference :80-114 (call order kept)."""
@@ -142,6 +143,32 @@ class Generator(nn.Module):
         view[:, 3], view[:, 4], view[:, 5] = shift
         return view
 
+    def prefetch_view(self, batch_size):
+        """Draw and invert the NEXT forward's view matrices now (harness.Trainer calls this at the end of a step, with
+        the whole backward pass still queued on the GPU): the ~0.3 ms of small host operations otherwise sit at the top
+        of the next forward, where the queue holds only the first few small kernels and runs dry (0.13 ms idle per
+        forward in the kernel trace, three forwards per optimizer cycle).  numpy's stream is consumed in the same order
+        -- one draw per forward -- and the draw is provisional: if anything touches numpy's generator before the next
+        forward (a reseed, another draw), or that forward has another batch size, the state is rolled back and the view
+        is drawn where the reference draws it."""
+        before = np.random.get_state()
+        minv = view_inverse_matrices(self.sample_view(batch_size)).reshape(batch_size, 16).contiguous()
+        after = np.random.get_state()
+        self._prefetched = (draw_on_host(lambda: minv, self.x.device), before, after, batch_size)
+
+    def _take_prefetched(self, n):
+        item, self._prefetched = self._prefetched, None
+        if item is None:
+            return None
+        minv, before, after, bs = item
+        now = np.random.get_state()
+        untouched = now[0] == after[0] and now[2:] == after[2:] and np.array_equal(now[1], after[1])
+        if untouched and bs == n:
+            return minv
+        if untouched:                    # another batch size (an epoch's last batch), or an explicit view: undo the
+            np.random.set_state(before)  # provisional draw
+        return None                      # (generator touched by someone else: their state stands)
+
     def forward(self, z, view_in=None):
         n = z.shape[0]
         dev = self.x.device
@@ -156,7 +183,10 @@ class Generator(nn.Module):
         # ~0.3 ms of small host ops during which the GPU would otherwise sit idle at every step boundary.  It is the
         # only numpy draw of a forward pass (reference :118-119 samples it first), so its place in numpy's stream --
         # and nothing else -- is unchanged.
-        if view_in is None and self.staged_minv is not None and self.staged_minv.shape[0] == n:
+        pre = self._take_prefetched(n if view_in is None else -1)      # (an explicit view consumes no draw)
+        if pre is not None:
+            minv = pre                       # drawn at the end of the previous step (prefetch_view)
+        elif view_in is None and self.staged_minv is not None and self.staged_minv.shape[0] == n:
             minv = self.staged_minv          # drawn and inverted on the host by the trainer, in the reference's order
         else:
             if view_in is None:

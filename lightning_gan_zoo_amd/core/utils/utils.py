@@ -78,16 +78,14 @@ def gradient_penalty(critic, real, fake, device="cpu", alpha=None):
     gradient = torch.autograd.grad(
         inputs=interpolated_images,
         outputs=mixed_scores,
-        grad_outputs=torch.ones_like(mixed_scores),
+        grad_outputs=F.ones_like_const(mixed_scores),
         create_graph=True,
         retain_graph=True,
     )[0]
     sumsq = F.row_sumsq(gradient.reshape(bs, -1))
-    # torch.norm's subgradient at an exactly-zero gradient is 0 (reference :55); a bare sqrt would give 0.5 / 0 = inf
-    # there and NaN after the chain rule
-    nonzero = sumsq > 0
-    gradient_norm = torch.where(nonzero, sumsq, torch.ones_like(sumsq)).sqrt() * nonzero
-    return torch.mean((gradient_norm - 1) ** 2)
+    # mean((||g_n|| - 1)^2) and its gradient in one launch each (gz_gp_penalty); torch.norm's subgradient at an
+    # exactly-zero gradient is 0 (reference :55), kept by the kernel -- a bare sqrt would give 0.5 / 0 there
+    return F.gp_penalty(sumsq)
 
 
 def compute_grad2(d_out, x_in):

@@ -2311,12 +2311,17 @@ size_t gz_reduce_multi_table_bytes(void) { return sizeof(ReduceTable); }
 int gz_reduce_multi_add(void* table_host, float* out, long long count, int beta, const float* slabs, int nz,
                         long long stride) {
     ReduceTable* t = reinterpret_cast<ReduceTable*>(table_host);
-    if (!t || !out || !slabs || count <= 0 || (count & 3) || (stride & 3) || nz < 1 ||
+    // slabs == NULL, nz == 0: a contribution that is exactly ZERO (a bias in front of a normalisation over its own
+    // plane): the job exists -- with beta = 0 the gradient is written as zeros by the same launch that sums the others,
+    // instead of a fill launch per such parameter -- but reads nothing
+    const bool zero_src = !slabs && nz == 0;
+    if (!t || !out || (!slabs && !zero_src) || count <= 0 || (count & 3) || (stride & 3) || (!zero_src && nz < 1) ||
         (((uintptr_t)out | (uintptr_t)slabs) & 15))
         return GZ_ERR_BAD_SHAPE;
     for (int j = 0; j < t->njobs; ++j)
         if (t->jobs[j].out == out) {            // another contribution to the same gradient
             ReduceJob& jb = t->jobs[j];
+            if (zero_src) return jb.count == count ? GZ_OK : GZ_ERR_UNSUPPORTED;
             if (jb.count != count || jb.nsrc >= REDUCE_MAX_SRC) return GZ_ERR_UNSUPPORTED;
             jb.src[jb.nsrc++] = ReduceSrc{slabs, stride, nz, 0};
             return GZ_OK;
@@ -2326,7 +2331,7 @@ int gz_reduce_multi_add(void* table_host, float* out, long long count, int beta,
     jb.out = out;
     jb.count = count;
     jb.beta = beta ? 1 : 0;
-    jb.nsrc = 1;
+    jb.nsrc = zero_src ? 0 : 1;
     jb.block0 = 0;
     jb.src[0] = ReduceSrc{slabs, stride, nz, 0};
     return GZ_OK;
@@ -2607,7 +2612,9 @@ static int describe_fwd(const ConvShape& s, char* b, size_t n) {
     if (is_tile2(sp.tile)) {
         const bool rowsA = fwd2_ok<G>(s);
         const int kdim = rowsA ? s.C * 16 : G::kh * G::kw * round_bk(s.C);
-        const bool kg2 = kg2_applies(sp.tile, (long long)s.N * s.OH * s.OW, s.K, 1, kdim, sp.splits, rowsA);
+        // (the 1x1 plane loader has no two-group form; every other igemm2 forward loader does)
+        const bool plane = !rowsA && G::kh * G::kw == 1 && G::s == 1 && G::p == 0 && !knobs().no_plane_a && ((s.H * s.W) & 3) == 0;
+        const bool kg2 = kg2_applies(sp.tile, (long long)s.N * s.OH * s.OW, s.K, 1, kdim, sp.splits, !plane);
         return snprintf(b, n, "F igemm2<%s> %s slabs=%d bn_stats_rows=%d%s", tile_text(sp.tile),
                         rowsA ? "ConvFwdA2(raw rows, LDS-DMA 16B)" : "ConvTapA2(gather, LDS-DMA 4B)",
                         split_nz(kdim, sp.splits), rows, kg2 ? " wave_groups=2" : "");
@@ -2643,8 +2650,10 @@ static int describe_dgrad(const ConvShape& s, char* b, size_t n) {
     const int kk = tapm ? round_bk(s.K) : s.K;
     if (is_tile2(sp.tile)) {
         const bool rowsA = dgrad2_ok<G>(s);
-        const bool kg2 = kg2_applies(sp.tile, (long long)s.N * (s.H / G::s) * (s.W / G::s), s.C, G::s * G::s, 4 * s.K,
-                                     sp.splits, rowsA);
+        constexpr int TYX = ((G::kh + G::s - 1) / G::s) * ((G::kw + G::s - 1) / G::s);
+        const bool plane = !rowsA && G::kh * G::kw == 1 && G::s == 1 && G::p == 0 && !knobs().no_plane_a && ((s.OH * s.OW) & 3) == 0;
+        const bool kg2 = kg2_applies(sp.tile, (long long)s.N * (s.H / G::s) * (s.W / G::s), s.C, G::s * G::s,
+                                     rowsA ? 4 * s.K : TYX * round_bk(s.K), sp.splits, !plane);
         return snprintf(b, n, "Dg igemm2<%s> %s splits=%d bn_stats_rows=%d%s", tile_text(sp.tile),
                         rowsA ? "ConvDgA2(row-shared, LDS-DMA 16B)" : "ConvDgTapA2(gather, LDS-DMA 4B)", sp.splits, rows,
                         kg2 ? " wave_groups=2" : "");

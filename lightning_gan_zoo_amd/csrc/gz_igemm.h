@@ -2413,6 +2413,7 @@ struct ConvFwdA2 {
 // the tap changes (once every C/16 chunks).  Fragment reads are igemm_kernel's plain [k][m] ones: no VALU in the loop.
 template <int BM, int KH, int KW, int S, int P>
 struct ConvTapA2 {
+    static constexpr bool TAPGATHER = true;      // (igemm2_kg2_built: the two-wave-group form is instantiated)
     using Params = typename ConvFwdALoader<BM, KH, KW, S, P>::Params;
     static constexpr int LD = BM, ROWS = BK;
     static constexpr int G = BM / 64;                      // 64-pixel groups per LDS row
@@ -2478,6 +2479,7 @@ struct ConvTapA2 {
 // A[k = (tap, ko)][m = (n, a, b)] = y[n][ko][oy0 - ty][ox0 - tx].  Phases have their own chunk counts.
 template <int BM, int KH, int KW, int S, int P>
 struct ConvDgTapA2 {
+    static constexpr bool TAPGATHER = true;      // (igemm2_kg2_built: the two-wave-group form is instantiated)
     static constexpr int TY = (KH + S - 1) / S, TX = (KW + S - 1) / S;
     using Params = typename ConvDgALoaderTap<BM, KH, KW, S, P>::Params;
     static constexpr int LD = BM, ROWS = BK;
@@ -3662,9 +3664,14 @@ constexpr size_t igemm2_lds_bytes_kg2() {
 // Which launches run two wave groups per workgroup (igemm2_kernel<.., KG = 2>): the k4 s2 p1 loaders of the DCGAN
 // layers, 128- or 64-wide tiles, when the grid gives a CU at most ONE workgroup and each group still has a reduction
 // worth pipelining.  Pure host logic: gz_conv2d_plan reports it, tests/golden/dispatch_plan.json pins it.
+template <class T, class = void>
+struct is_tapgather : std::false_type {};
+template <class T>
+struct is_tapgather<T, std::void_t<decltype(T::TAPGATHER)>> : std::true_type {};
 template <class Cfg, class AL>
 constexpr bool igemm2_kg2_built() {
-    return Cfg::TN <= 2 && Cfg::WM * Cfg::WN == 4 && Cfg::WN == 2 && (is_rowshare<AL>::value || is_fwdrows<AL>::value);
+    return Cfg::TN <= 2 && Cfg::WM * Cfg::WN == 4 && Cfg::WN == 2 &&
+           (is_rowshare<AL>::value || is_fwdrows<AL>::value || is_tapgather<AL>::value);
 }
 inline bool igemm2_use_kg2(long long workgroups, int chunks_per_workgroup) {
     if (knobs().no_kg2) return false;

@@ -97,6 +97,30 @@ __global__ __launch_bounds__(LT) void mse_mean_bwd_kernel(const float* __restric
     for (int i = blockIdx.x * LT + threadIdx.x; i < n; i += gridDim.x * LT) da[i] = (a[i] - b[i]) * scale;
 }
 
+// WGAN-GP tail (reference core/utils/utils.py:55-57): gradient_norm = ||g_n||_2 per sample, penalty = mean((norm - 1)^2),
+// from the per-sample sums of squares s_n.  torch.norm's subgradient at an exactly-zero vector is 0, so d/ds_n =
+// (sqrt(s_n) - 1) / (sqrt(s_n) N) for s_n > 0 and 0 at s_n == 0.  One launch each way instead of ~8 framework operators
+// (compare, where, sqrt, mul, sub, pow, mean and their autograd mirrors).
+__global__ __launch_bounds__(LT) void gp_penalty_kernel(const float* __restrict__ sumsq, float* __restrict__ out, int n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += LT) {
+        const float d = sqrtf(sumsq[i]) - 1.f;
+        s += d * d;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s / (float)n;
+}
+
+__global__ __launch_bounds__(LT) void gp_penalty_bwd_kernel(const float* __restrict__ sumsq, const float* __restrict__ g,
+                                                           float* __restrict__ ds, int n) {
+    const float scale = g[0] / (float)n;
+    for (int i = blockIdx.x * LT + threadIdx.x; i < n; i += gridDim.x * LT) {
+        const float r = sqrtf(sumsq[i]);
+        ds[i] = r > 0.f ? (r - 1.f) / r * scale : 0.f;
+    }
+}
+
 // out = out2 = x / max(||x||, eps);  norm_out[0] = ||x||.  One workgroup (n <= a few thousand).  `out` may be the
 // module's persistent buffer (updated in place like torch's spectral_norm does) and `out2` the private copy the
 // autograd node keeps; either may be NULL.
@@ -415,6 +439,20 @@ int gz_mse_mean_bwd(const float* a, const float* b, const float* gloss, float* d
     gz::clear_stale_error();
     if (n <= 0) return GZ_ERR_BAD_SHAPE;
     hipLaunchKernelGGL(mse_mean_bwd_kernel, dim3(grid_for(n)), dim3(LT), 0, stream, a, b, gloss, da, n);
+    return launch_status();
+}
+
+int gz_gp_penalty(const float* sumsq, float* out, int n, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (n <= 0 || !sumsq || !out) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(gp_penalty_kernel, dim3(1), dim3(LT), 0, stream, sumsq, out, n);
+    return launch_status();
+}
+
+int gz_gp_penalty_bwd(const float* sumsq, const float* gout, float* dsumsq, int n, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (n <= 0 || !sumsq || !gout || !dsumsq) return GZ_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(gp_penalty_bwd_kernel, dim3(grid_for(n)), dim3(LT), 0, stream, sumsq, gout, dsumsq, n);
     return launch_status();
 }
 

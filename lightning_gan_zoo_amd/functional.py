@@ -541,6 +541,18 @@ def _sink_grad(p, g):
     return True
 
 
+def _sink_zero(p, shape, device):
+    """The gradient of ``p`` from this use is EXACTLY zero (a convolution bias in front of a normalisation over its own
+    plane).  With sinks on, the parameter joins the flush as a job without sources -- written as zeros by the launch
+    that sums everything else, or left alone when ``p.grad`` already holds contributions -- and None goes back to
+    autograd; otherwise a zero tensor (one fill launch per such bias: HoloGAN had 11 per optimizer cycle)."""
+    if (_sinks.enabled and isinstance(p, torch.nn.Parameter) and not (p.numel() & 3)
+            and (p.grad is None or (p.grad.is_contiguous() and p.grad.dtype == torch.float32 and not p.grad.data_ptr() & 15))):
+        _sinks.pending.setdefault(id(p), [p, []])
+        return None
+    return torch.zeros(shape, device=device, dtype=torch.float32)
+
+
 def _sink_or_return(p, g):
     """``g`` for autograd, or None when the sink took it."""
     if g is None or _sink_grad(p, g):
@@ -579,6 +591,10 @@ def flush_grad_sinks(params=None):
         if njobs >= max_jobs:
             check(lib.gz_reduce_multi(table, st), "reduce_multi")
             table, njobs = (ctypes.c_char * nb)(), 0
+        if not srcs:
+            if not fresh:
+                continue          # an exact-zero contribution to a gradient that already exists: nothing to do
+            check(lib.gz_reduce_multi_add(table, _p(target), w.numel(), 0, None, 0, 0), "reduce_multi_add(zero)")
         for (slabs, nz, stride) in srcs[:max_src]:
             check(lib.gz_reduce_multi_add(table, _p(target), w.numel(), 0 if fresh else 1, _p(slabs), nz, stride),
                   "reduce_multi_add")
@@ -781,10 +797,12 @@ class _ConvDg(torch.autograd.Function):
                 dw = _conv_wgrad_raw(v, g, geom)
             db = None
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = (torch.zeros(v.shape[1], device=v.device, dtype=torch.float32) if ctx.bias_cancels
-                      else _channel_sum_raw(v))
-            if db is not None and ctx.bias_ref is not None:
-                db = _sink_or_return(ctx.bias_ref, db)
+                if ctx.bias_cancels:
+                    db = _sink_zero(ctx.bias_ref, (v.shape[1],), v.device)
+                else:
+                    db = _channel_sum_raw(v)
+                    if ctx.bias_ref is not None:
+                        db = _sink_or_return(ctx.bias_ref, db)
             return dg, dw, db, None, None, None, None, None, None
         dg = dw = db = None
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
@@ -968,7 +986,7 @@ class _DotF(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        dx = _DotDg.apply(g, w) if ctx.needs_input_grad[0] else None
+        dx = _DotDg.apply(g, w, ctx.param) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             if ctx.param is not None and not torch.is_grad_enabled() and _sinks.enabled:
@@ -984,17 +1002,25 @@ class _DotDg(torch.autograd.Function):
     """x[r,:] = g[r] * w"""
 
     @staticmethod
-    def forward(ctx, g, w):
+    def forward(ctx, g, w, param=None):
         g, w = _req(g, "g"), _req(w, "w")
         ctx.save_for_backward(g, w)
+        ctx.param = param
         return _rowscale_raw(w, g, g.numel(), w.numel(), True)
 
     @staticmethod
     def backward(ctx, v):
         g, w = ctx.saved_tensors
-        dg = _DotF.apply(v, w) if ctx.needs_input_grad[0] else None
-        dw = _DotWg.apply(v, g) if ctx.needs_input_grad[1] else None
-        return dg, dw
+        dg = _DotF.apply(v, w, ctx.param) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if ctx.param is not None and not torch.is_grad_enabled() and _sinks.enabled:
+                dw = _coldot_raw(_req(g), _req(v))                # == _DotWg(v, g)
+                if _sink_grad(ctx.param, dw.view_as(ctx.param)):
+                    dw = None
+            else:
+                dw = _DotWg.apply(v, g)
+        return dg, dw, None
 
 
 class _DotWg(torch.autograd.Function):
@@ -1228,6 +1254,8 @@ class _RowNormActBwd(torch.autograd.Function):
         ws = _norm_ws(x, N, C)
         check(lib.gz_rownorm_act_bwd2(_p(gout), _p(v), _p(x), _p(coef), _p(gg), _p(gx), _p(ggamma), _p(ws), N, C,
                                       inner, act, slope, _stream()), "rownorm_act_bwd2")
+        if ggamma is not None:
+            ggamma = _sink_or_return(gamma, ggamma)       # (second-order contribution: joins gamma's sink, no add launch)
         return gg, gx, ggamma, None, None
 
 
@@ -1316,6 +1344,45 @@ def row_sumsq(x):
     return _RowDot.apply(x, x)
 
 
+class _GPPenalty(torch.autograd.Function):
+    """mean((sqrt(sumsq) - 1)^2): the tail of the gradient penalty in one launch each way (gz_gp_penalty)."""
+
+    @staticmethod
+    def forward(ctx, sumsq):
+        sumsq = _req(sumsq, "sumsq")
+        out = torch.empty((), device=sumsq.device, dtype=torch.float32)
+        check(lib.gz_gp_penalty(_p(sumsq), _p(out), sumsq.numel(), _stream()), "gp_penalty")
+        ctx.save_for_backward(sumsq)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (sumsq,) = ctx.saved_tensors
+        ds = torch.empty_like(sumsq)
+        check(lib.gz_gp_penalty_bwd(_p(sumsq), _p(_req(g)), _p(ds), sumsq.numel(), _stream()), "gp_penalty_bwd")
+        return ds
+
+
+def gp_penalty(sumsq):
+    """``torch.mean((norm - 1) ** 2)`` with ``norm = sqrt(sumsq)`` per sample (reference core/utils/utils.py:55-57);
+    the subgradient at an exactly-zero gradient is 0, as torch.norm's."""
+    return _GPPenalty.apply(sumsq.reshape(-1))
+
+
+_ones = {}
+
+
+def ones_like_const(t):
+    """A read-only tensor of ones shaped like ``t`` (``grad_outputs=torch.ones_like(scores)``, reference utils.py:51):
+    cached per shape and device instead of a fill launch per step.  Never written by anyone."""
+    key = (tuple(t.shape), t.device, t.dtype)
+    o = _ones.get(key)
+    if o is None:
+        o = _ones[key] = torch.ones(t.shape, device=t.device, dtype=t.dtype)
+    return o
+
+
 @torch.no_grad()
 def clamp_(t, lo, hi):
     """in-place clamp of a parameter tensor (WGAN weight clipping, lightning_module.py:160-162)."""
@@ -1399,6 +1466,7 @@ class _Conv3DDg(torch.autograd.Function):
         ctx.save_for_backward(g, w)
         ctx.has_bias = bias is not None
         ctx.bias_cancels = bias_cancels
+        ctx.bias_ref = bias if isinstance(bias, torch.nn.Parameter) else None
         return _conv3d_dgrad_raw(g, w, bias, ACT_NONE, 0.0)
 
     @staticmethod
@@ -1410,7 +1478,7 @@ class _Conv3DDg(torch.autograd.Function):
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if ctx.bias_cancels and not torch.is_grad_enabled():
-                db = torch.zeros(v.shape[1], device=v.device, dtype=torch.float32)
+                db = _sink_zero(ctx.bias_ref, (v.shape[1],), v.device)
             else:
                 db = _ChannelSum.apply(v) if torch.is_grad_enabled() else _channel_sum_raw(v)
         return dg, dw, db, None
@@ -1907,6 +1975,7 @@ class _SNConvINAct(torch.autograd.Function):
         ctx.save_for_backward(x, W, y, coef, sigma, us, vs)
         ctx.cfg = (geom, in_eps, act, slope, groups, bias is not None)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        ctx.bias_ref = bias if isinstance(bias, torch.nn.Parameter) else None
         ctx.param = weight_orig
         return out
 
@@ -1939,8 +2008,7 @@ class _SNConvINAct(torch.autograd.Function):
             if not sunk:
                 dW = _conv_wgrad_raw(x, g_raw, geom)
                 dW.add_(term)
-        db = torch.zeros(ctx.bias_shape, device=y.device, dtype=torch.float32) \
-            if (has_bias and ctx.needs_input_grad[2]) else None
+        db = _sink_zero(ctx.bias_ref, ctx.bias_shape, y.device) if (has_bias and ctx.needs_input_grad[2]) else None
         return dx, dW, db, None, None, None, None, None, None, None
 
 

@@ -222,6 +222,9 @@ class Trainer:
         if self.grad_sync is None and stepping:
             opt.step()
             opt.zero_grad(set_to_none=True)
+        gen = getattr(m, "generator", None)
+        if self._F is not None and hasattr(gen, "prefetch_view") and torch.is_tensor(batch[0]):
+            gen.prefetch_view(len(batch[0]))       # HoloGAN: the next forward's view matrices, while the GPU is busy
         self.batch_idx += 1
         self.epoch_batch_idx += 1
         return loss.detach(), idx

@@ -199,7 +199,8 @@ def test_hologan_bs64_stacked_critic_step_matches_two_calls(img):
     orders (128-row vs 64-row tiles) put on different sides of zero (2.5e-3 per entry, see the test above)."""
     import numpy as np
     from helpers import FixedNoise
-    res = {}
+    from mask_pinning import MaskTape, record_product_masks
+    res, tapes = {}, {}
     for stacked in (True, False):
         cfg = make_cfg("hologan", batch_size=64, features=64, noise_dim=128, img_size=img)
         torch.manual_seed(42)
@@ -215,10 +216,18 @@ def test_hologan_bs64_stacked_critic_step_matches_two_calls(img):
         np.random.seed(5)
         scenario._toggle(step, 0)
         step.zero_grad(set_to_none=True)
-        loss = step.training_step((real, labels), 0, 0)
+        tapes[stacked] = MaskTape()
+        with record_product_masks(tapes[stacked]):
+            loss = step.training_step((real, labels), 0, 0)
         loss.backward()
         res[stacked] = (float(loss.detach()), {n: p.grad.detach().clone() for n, p in step.discriminator.named_parameters()},
                         {n: b.detach().clone() for n, b in step.discriminator.named_buffers()})
+    # LeakyReLU decisions of the critic that the two summation orders (128-row vs 64-row launches, other tiles / wave
+    # groups) put on different sides of zero: the generator's 11 decisions first, then the critic's 5 per call
+    one, two = tapes[True].masks, tapes[False].masks
+    assert len(one) == 11 + 5 and len(two) == 11 + 5 + 5
+    flips = sum(int((one[11 + k] != torch.cat([two[11 + k], two[16 + k]])).sum()) for k in range(5))
+    assert all(torch.equal(a, b) for a, b in zip(one[:11], two[:11]))
     (la, ga, ba), (lb, gb, bb) = res[True], res[False]
     assert abs(la - lb) <= 1e-5 * max(1.0, abs(lb)), (la, lb)
     for n in bb:
@@ -230,5 +239,10 @@ def test_hologan_bs64_stacked_critic_step_matches_two_calls(img):
             continue
         worst[n] = float((ga[n] - gb[n]).norm() / gb[n].norm().clamp_min(1e-30))
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
-    print(f"hologan {img}x{img} bs64 stacked vs two calls:", [(k, f"{v:.1e}") for k, v in top])
-    assert top[0][1] <= 5e-3, top
+    print(f"hologan {img}x{img} bs64 stacked vs two calls: {flips} critic mask entries differ;",
+          [(k, f"{v:.1e}") for k, v in top])
+    # a differing entry moves a layer's gradient by up to ~1e-3 (the first convolution's bias, which sums all of a
+    # channel's positions, most); without any, the two forms agree to rounding.  Differing entries are pre-activations
+    # within rounding of zero: a few in 10^6
+    entries = sum(m.numel() for m in one[11:])
+    assert flips <= 2e-5 * entries and top[0][1] <= min(2e-2, max(1e-3, 1e-3 * flips)), (flips, entries, top)

@@ -743,6 +743,49 @@ def test_fused_optimizers_step_parameter_subsets_and_zero_the_gradients(kind):
     assert all(float(sa[k]["step"]) == float(sb[k]["step"]) == 3.0 for k in sa)
 
 
+def test_gp_penalty_tail_matches_torch():
+    """functional.gp_penalty(sumsq) == mean((sqrt(sumsq) - 1)^2) of the reference (core/utils/utils.py:55-57:
+    ``gradient.norm(2, dim=1)``, ``torch.mean((gradient_norm - 1) ** 2)``) and its gradient, including the zero
+    subgradient of torch.norm at an exactly-zero row."""
+    F = _F()
+    g = rnd(37, 500, seed=5) * 0.05
+    g[3] = 0.0                                   # a sample whose input gradient vanishes
+    g[7] *= 40.0
+    gr = g.clone().requires_grad_()
+    ref = torch.mean((gr.norm(2, dim=1) - 1) ** 2)
+    ref.backward()
+    gd = g.cuda().requires_grad_()
+    out = F.gp_penalty(F.row_sumsq(gd))
+    out.backward()
+    assert rel(out, ref) < 1e-6 and rel(gd.grad, gr.grad) < 1e-5
+    assert float(gd.grad[3].abs().max()) == 0.0 and torch.isfinite(gd.grad).all()
+    ones = F.ones_like_const(out.reshape(1, 1))
+    assert ones is F.ones_like_const(out.reshape(1, 1)) and float(ones) == 1.0
+
+
+def test_exact_zero_bias_gradients_join_the_sink_flush():
+    """A bias in front of a per-plane normalisation (``bias_cancels``): with sinks on no zero tensor is created -- the
+    flush writes zeros into a fresh ``p.grad`` (a job without sources) or leaves an existing gradient alone."""
+    F = _F()
+    x = rnd(2, 8, 4, 4, seed=1).cuda().requires_grad_()
+    w = torch.nn.Parameter(rnd(8, 12, 4, 4, seed=2).cuda() * 0.1)
+    b = torch.nn.Parameter(rnd(12, seed=3).cuda())
+    prev = F.set_grad_sinks(True)
+    try:
+        y = F.conv_transpose2d(x, w, b, F.K4S2P1, bias_cancels=True)
+        y.sum().backward()
+        assert b.grad is None and id(b) in F._sinks.pending       # nothing launched for it yet
+        F.flush_grad_sinks()
+        assert b.grad is not None and float(b.grad.abs().max()) == 0.0 and w.grad is not None
+        b.grad.fill_(2.0)                                           # an existing gradient is left alone
+        y = F.conv_transpose2d(x, w, b, F.K4S2P1, bias_cancels=True)
+        y.sum().backward()
+        F.flush_grad_sinks()
+        assert float((b.grad - 2.0).abs().max()) == 0.0
+    finally:
+        F.set_grad_sinks(*prev)
+
+
 def test_host_draws_reach_the_device_through_the_pinned_ring():
     """harness.HostStager: the per-step host draws (latent noise, GP alpha, HoloGAN's view matrices; reference
     core/lightning_module.py:107-108 ``sample(...).to(device)``) are read by the device straight out of pinned host
