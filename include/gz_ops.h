@@ -441,6 +441,16 @@ int gz_u8hwc_to_nchw(const unsigned char* in, float* out, int N, int H, int W, i
 int gz_adam_step(int count, float* const* params, float* const* grads, float* const* exp_avg,
                  float* const* exp_avg_sq, const long long* numel, float lr, float beta1, float beta2, float eps,
                  int step, float grad_scale, int zero_grads, hipStream_t stream);
+/* Adam reading UNREDUCED weight-gradient slabs (gz_conv2d_wgrad_partial) instead of a gradient tensor: the slab sum of
+ * gz_reduce_multi and the update in one launch (harness.Trainer outside data parallelism).  A zero-initialised host
+ * table of gz_adam_src_table_bytes() bytes takes <= gz_adam_src_max_tensors() parameters with <= 4 sources each
+ * (gz_adam_src_add per (parameter, source)); the gradient has the bits gz_reduce_multi would have written. */
+int gz_adam_src_max_tensors(void);
+size_t gz_adam_src_table_bytes(void);
+int gz_adam_src_add(void* table_host, float* param, float* exp_avg, float* exp_avg_sq, long long numel,
+                    const float* slabs, int nz, long long stride);
+int gz_adam_step_from_slabs(void* table_host, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                            hipStream_t stream);
 /* graph-capturable Adam: tick = device float[3] {step, 1 - beta1^step, sqrt(1 - beta2^step)}; gz_adam_tick advances
  * it by one step, gz_adam_step_dev reads the corrections from it (same update as gz_adam_step) */
 int gz_adam_tick(float* tick, float beta1, float beta2, hipStream_t stream);

@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "gz_igemm.h"
+#include "gz_reduce.h"
 #include "../../include/gz_ops.h"
 
 namespace gz {
@@ -388,12 +389,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void reduce_slabs_kernel(const float
 // + 11 framework `add_` launches of gradient accumulation by 2-4 launches.  The table travels as a kernel argument
 // (no staging copy).  Summation order is fixed: wavefront w of a workgroup takes slabs w, w+4, ... of source 0, then
 // of source 1, ...; the four partial sums meet in LDS in wavefront order.
-constexpr int REDUCE_MAX_JOBS = 24, REDUCE_MAX_SRC = 4;
-struct ReduceSrc {
-    const float* p;
-    long long stride;          // floats between consecutive slabs
-    int nz, pad;
-};
+constexpr int REDUCE_MAX_JOBS = 24;
 struct ReduceJob {
     float* out;
     long long count;           // floats, a multiple of 4
@@ -414,27 +410,9 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(ReduceTable t) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long i = ((long long)(b - jb.block0) * 64 + lane) * 4;
     const bool live = i < jb.count;
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-    if (live) {
-        for (int q = 0; q < jb.nsrc; ++q) {
-            const float* p = jb.src[q].p + i;
-            const long long st = jb.src[q].stride;
-            const int nz = jb.src[q].nz;
-            int z = wave;
-            for (; z + 12 < nz; z += 16) {          // four independent 16-byte loads in flight per lane
-                a0 += *reinterpret_cast<const f32x4*>(p + (long long)z * st);
-                a1 += *reinterpret_cast<const f32x4*>(p + (long long)(z + 4) * st);
-                a2 += *reinterpret_cast<const f32x4*>(p + (long long)(z + 8) * st);
-                a3 += *reinterpret_cast<const f32x4*>(p + (long long)(z + 12) * st);
-            }
-            for (; z < nz; z += 4) a0 += *reinterpret_cast<const f32x4*>(p + (long long)z * st);
-        }
-    }
-    a0 = (a0 + a1) + (a2 + a3);
-    if (wave > 0) part[wave - 1][lane] = a0;
-    __syncthreads();
+    const f32x4 r0 = reduce_sources(jb.src, jb.nsrc, i, live, lane, wave, part);
     if (wave == 0 && live) {
-        f32x4 r = ((a0 + part[0][lane]) + part[1][lane]) + part[2][lane];
+        f32x4 r = r0;
         f32x4* o = reinterpret_cast<f32x4*>(jb.out + i);
         if (jb.beta) r += *o;
         *o = r;

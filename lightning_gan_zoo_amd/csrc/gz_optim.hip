@@ -5,6 +5,7 @@
 // the ~14 passes of the foreach implementation.  Arithmetic follows torch's single-tensor formulas
 // (lerp for the first moment, bias corrections folded the same way) so results agree to rounding.
 #include "gz_common.h"
+#include "gz_reduce.h"
 #include "../../include/gz_ops.h"
 
 namespace gz {
@@ -164,6 +165,51 @@ __global__ __launch_bounds__(OPT_THREADS) void rmsprop_kernel(OptTable t, float 
     }
 }
 
+// Adam straight from UNREDUCED weight-gradient slabs (round 5): harness.Trainer's sink flush used to sum the slabs of
+// every split weight-gradient launch into p.grad (gz_reduce_multi: one write of all gradients) for the optimizer to read
+// them back one launch later.  Here the optimizer's workgroup sums the slabs of its 64 float4 itself -- reduce_sources,
+// the very code of gz_reduce_multi, so the gradient has the same bits -- and wavefront 0 applies the update.  The
+// gradient tensor is never materialised; nothing outside the trainer's step could have seen it (zero_grad(set_to_none)
+// follows the step).  One launch instead of two per optimizer step and 2 x 4 bytes per parameter less traffic.
+constexpr int SRC_MAX_TENSORS = 12;
+struct SrcTensor {
+    float* p;
+    float* m;
+    float* v;
+    long long n;               // floats, a multiple of 4
+    int nsrc, block0;
+    ReduceSrc src[REDUCE_MAX_SRC];
+};
+struct SrcTable {
+    int count, pad;
+    SrcTensor t[SRC_MAX_TENSORS];
+};
+
+__global__ __launch_bounds__(256) void adam_from_slabs_kernel(SrcTable tab, float lr, float beta1, float beta2, float eps,
+                                                              float bc1, float bc2_sqrt, float grad_scale) {
+    __shared__ f32x4 part[3][64];
+    const int b = blockIdx.x;
+    int k = 0;
+    while (k + 1 < tab.count && tab.t[k + 1].block0 <= b) ++k;
+    const SrcTensor& t = tab.t[k];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long i = ((long long)(b - t.block0) * 64 + lane) * 4;
+    const bool live = i < t.n;
+    const f32x4 g = reduce_sources(t.src, t.nsrc, i, live, lane, wave, part);
+    if (wave != 0 || !live) return;
+    const AdamCoef c{beta1, beta2, eps, lr / bc1, bc2_sqrt, grad_scale};
+    float4 pv = *reinterpret_cast<const float4*>(t.p + i);
+    float4 mv = *reinterpret_cast<const float4*>(t.m + i);
+    float4 vv = *reinterpret_cast<const float4*>(t.v + i);
+    adam_one(pv.x, g[0], mv.x, vv.x, c);
+    adam_one(pv.y, g[1], mv.y, vv.y, c);
+    adam_one(pv.z, g[2], mv.z, vv.z, c);
+    adam_one(pv.w, g[3], mv.w, vv.w, c);
+    *reinterpret_cast<float4*>(t.p + i) = pv;
+    *reinterpret_cast<float4*>(t.m + i) = mv;
+    *reinterpret_cast<float4*>(t.v + i) = vv;
+}
+
 static int fill_table(OptTable& t, int count, float* const* p, float* const* g, float* const* m,
                       float* const* v, const long long* n, int zero_grads) {
     if (count <= 0 || count > OPT_MAX) return GZ_ERR_BAD_SHAPE;
@@ -207,6 +253,49 @@ int gz_adam_step(int count, float* const* params, float* const* grads, float* co
     double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(OPT_THREADS), 0, stream, t, lr, beta1, beta2, eps, (float)bc1,
                        (float)sqrt(bc2), grad_scale);
+    return launch_status();
+}
+
+int gz_adam_src_max_tensors(void) { return SRC_MAX_TENSORS; }
+size_t gz_adam_src_table_bytes(void) { return sizeof(SrcTable); }
+
+/* table_host: zero-initialised gz_adam_src_table_bytes() bytes.  One call per (parameter, slab source): the first call
+ * for a parameter registers it (params / exp_avg / exp_avg_sq, numel a multiple of 4, everything 16-byte aligned) */
+int gz_adam_src_add(void* table_host, float* param, float* exp_avg, float* exp_avg_sq, long long numel,
+                    const float* slabs, int nz, long long stride) {
+    SrcTable* tab = reinterpret_cast<SrcTable*>(table_host);
+    if (!tab || !param || !exp_avg || !exp_avg_sq || !slabs || numel <= 0 || (numel & 3) || (stride & 3) || nz < 1 ||
+        (((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)slabs) & 15))
+        return GZ_ERR_BAD_SHAPE;
+    for (int k = 0; k < tab->count; ++k)
+        if (tab->t[k].p == param) {
+            SrcTensor& t = tab->t[k];
+            if (t.n != numel || t.nsrc >= REDUCE_MAX_SRC) return GZ_ERR_UNSUPPORTED;
+            t.src[t.nsrc++] = ReduceSrc{slabs, stride, nz, 0};
+            return GZ_OK;
+        }
+    if (tab->count >= SRC_MAX_TENSORS) return GZ_ERR_UNSUPPORTED;
+    SrcTensor& t = tab->t[tab->count++];
+    t.p = param; t.m = exp_avg; t.v = exp_avg_sq; t.n = numel; t.nsrc = 1; t.block0 = 0;
+    t.src[0] = ReduceSrc{slabs, stride, nz, 0};
+    return GZ_OK;
+}
+
+int gz_adam_step_from_slabs(void* table_host, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                            hipStream_t stream) {
+    gz::clear_stale_error();
+    SrcTable* tab = reinterpret_cast<SrcTable*>(table_host);
+    if (!tab || tab->count <= 0 || tab->count > SRC_MAX_TENSORS || step < 1) return GZ_ERR_BAD_SHAPE;
+    long long blocks = 0;
+    for (int k = 0; k < tab->count; ++k) {
+        tab->t[k].block0 = (int)blocks;
+        blocks += (tab->t[k].n + 255) / 256;
+    }
+    if (blocks <= 0 || blocks >= (1ll << 31)) return GZ_ERR_TOO_LARGE;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_from_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, *tab, lr, beta1, beta2, eps,
+                       (float)bc1, (float)sqrt(bc2), grad_scale);
     return launch_status();
 }
 

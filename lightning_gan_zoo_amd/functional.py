@@ -564,6 +564,23 @@ def _sink_fail(what):
     raise RuntimeError("lightning_gan_zoo_amd: gradient sink cannot take this launch (%s)" % what)
 
 
+def take_grad_sinks(params):
+    """Hand the pending slab sources of ``params`` to the caller INSTEAD of reducing them into ``p.grad`` (the fused
+    optimizers sum the slabs themselves: optim.Adam.step(sink_sources=...)).  Only parameters whose gradient of this pass
+    consists of the pending sources alone -- ``p.grad`` is None -- and that have at least one source are taken;
+    everything else stays for flush_grad_sinks.  -> {id(p): (p, [(slabs, nz, stride), ...])}"""
+    out = {}
+    max_src = lib.gz_reduce_multi_max_sources()
+    for p in params:
+        item = _sinks.pending.get(id(p))
+        if item is None or p.grad is not None or not item[1] or len(item[1]) > max_src or (p.numel() & 3):
+            continue
+        if p.data_ptr() & 15 or any((s[0].data_ptr() & 15) or (s[2] & 3) for s in item[1]):
+            continue
+        out[id(p)] = (p, _sinks.pending.pop(id(p))[1])
+    return out
+
+
 def flush_grad_sinks(params=None):
     """Sum the queued weight-gradient slabs into ``p.grad`` -- of ``params`` (an iterable) or of everything pending --
     with as few gz_reduce_multi launches as the table size allows."""

@@ -203,6 +203,7 @@ class Trainer:
         if F is not None:
             prev = F.set_grad_sinks(True)
         opt = self.optim[idx]["optimizer"]
+        taken = None
         try:
             loss = m.training_step(batch, self.batch_idx, idx)
             (loss if factor == 1 else loss / factor).backward()
@@ -211,6 +212,9 @@ class Trainer:
                 # launches it postponed (deferred tail) and issues what the backward hooks have not issued yet
                 self.grad_sync.after_backward(idx, opt, exchange=stepping)
             elif F is not None:
+                if stepping and factor == 1 and getattr(opt, "accepts_sink_sources", False):
+                    # the fused optimizer sums the weight-gradient slabs itself: no reduce launch, no gradient tensor
+                    taken = F.take_grad_sinks([p for g in opt.param_groups for p in g["params"]])
                 F.flush_grad_sinks()
         except BaseException:
             if F is not None:             # nothing half-built is reduced, nothing leaks into the next step's gradients
@@ -220,7 +224,10 @@ class Trainer:
             if F is not None:
                 F.set_grad_sinks(*prev)
         if self.grad_sync is None and stepping:
-            opt.step()
+            if taken:
+                opt.step(sink_sources=taken)
+            else:
+                opt.step()
             opt.zero_grad(set_to_none=True)
         gen = getattr(m, "generator", None)
         if self._F is not None and hasattr(gen, "prefetch_view") and torch.is_tensor(batch[0]):

@@ -29,6 +29,7 @@ def _check_tensor(p):
 class Adam(torch.optim.Optimizer):
     accepts_grad_scale = True
     accepts_param_subset = True
+    accepts_sink_sources = True
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **unused):
         if weight_decay or amsgrad:
@@ -41,6 +42,46 @@ class Adam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._step_py = {}          # re-read from the loaded tensors at the next step
+
+    def _step_from_slabs(self, sources, grad_scale):
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        max_t, nb = lib.gz_adam_src_max_tensors(), lib.gz_adam_src_table_bytes()
+        for group in self.param_groups:
+            if group.get("_tick") is not None:
+                raise RuntimeError("capturable fused Adam does not take sink sources")
+            beta1, beta2 = group["betas"]
+            todo = [(p, sources[id(p)][1]) for p in group["params"] if id(p) in sources]
+            if not todo:
+                continue
+            for p, _ in todo:
+                st = self.state[p]
+                if not st:
+                    _check_tensor(p)
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            torch._foreach_add_([self.state[p]["step"] for p, _ in todo], 1.0)
+            by_step = {}
+            for p, srcs in todo:
+                k = self._step_py.get(id(p))
+                k = int(self.state[p]["step"].item()) if k is None else k + 1
+                self._step_py[id(p)] = k
+                by_step.setdefault(k, []).append((p, srcs))
+            for step, items in by_step.items():
+                for i in range(0, len(items), max_t):
+                    table = (ctypes.c_char * nb)()
+                    for p, srcs in items[i:i + max_t]:
+                        st = self.state[p]
+                        for (slabs, nz, stride) in srcs:
+                            check(lib.gz_adam_src_add(table, ctypes.c_void_p(p.data_ptr()),
+                                                      ctypes.c_void_p(st["exp_avg"].data_ptr()),
+                                                      ctypes.c_void_p(st["exp_avg_sq"].data_ptr()), p.numel(),
+                                                      ctypes.c_void_p(slabs.data_ptr()), nz, stride), "adam_src_add")
+                    check(lib.gz_adam_step_from_slabs(table, float(group["lr"]), float(beta1), float(beta2),
+                                                      float(group["eps"]), step, float(grad_scale), stream),
+                          "adam_step_from_slabs")
+                for p, _ in items:
+                    F.invalidate(p)
 
     def make_capturable(self):
         """Move the step counter to the device so that ``step()`` can be captured in a HIP graph and replayed
@@ -89,10 +130,14 @@ class Adam(torch.optim.Optimizer):
             F.invalidate(p)
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0, params=None, zero_grads=False):
+    def step(self, closure=None, grad_scale=1.0, params=None, zero_grads=False, sink_sources=None):
         """``params``: step only these (ddp.GradSync steps one gradient bucket at a time, as its all-reduce lands);
-        ``zero_grads``: the kernel also overwrites the gradients it has read with 0 (the flat exchange buffer)."""
+        ``zero_grads``: the kernel also overwrites the gradients it has read with 0 (the flat exchange buffer);
+        ``sink_sources`` (functional.take_grad_sinks): parameters whose gradient exists only as unreduced slabs -- the
+        kernel sums them itself (gz_adam_step_from_slabs; same bits as reduce-then-step)."""
         loss = closure() if closure is not None else None
+        if sink_sources:
+            self._step_from_slabs(sink_sources, grad_scale)
         if getattr(self, "_pack_group", None) is None:      # the conv weights this optimizer rewrites re-pack together
             self._pack_group = F.register_pack_group([p for g in self.param_groups for p in g["params"]])
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -152,3 +152,47 @@ def test_norm_affine_gradients_are_written_in_place(norm):
     finally:
         F.set_grad_sinks(*prev)
     assert _rel(gamma.grad, plain[0]) < 1e-5 and _rel(beta.grad, plain[1]) < 1e-5
+
+
+@pytest.mark.parametrize("expt", ["dc_gan", "wgan_gp", "hologan"])
+def test_adam_from_slabs_equals_reduce_then_step(expt):
+    """Round 5: outside data parallelism the trainer hands the pending weight-gradient slabs to the fused Adam
+    (functional.take_grad_sinks -> optim.Adam.step(sink_sources=...): gz_adam_step_from_slabs sums them with
+    gz_reduce_multi's own code) instead of reducing them into p.grad first.  Same bits: four optimizer cycles with
+    and without (an optimizer that does not accept sources) leave identical parameters and Adam moments."""
+    import numpy as np
+    from helpers import synthetic_real
+    from lightning_gan_zoo_amd.config import locate, make_cfg
+    from lightning_gan_zoo_amd.harness import Trainer
+    res = {}
+    for fused in (True, False):
+        cfg = make_cfg(expt, batch_size=8, features=16, noise_dim=16)
+        torch.manual_seed(42)
+        module = locate(cfg.model.lm["_target_"])(cfg, None).to("cuda")
+        trainer = Trainer(module)
+        took = []
+        for o in trainer.optim:
+            opt = o["optimizer"]
+            assert opt.accepts_sink_sources
+            if not fused:
+                opt.accepts_sink_sources = False
+            else:
+                inner = opt._step_from_slabs
+                opt._step_from_slabs = lambda src, gs, inner=inner: (took.append(len(src)), inner(src, gs))[1]
+        torch.manual_seed(7)
+        np.random.seed(7)
+        labels = torch.zeros(8, dtype=torch.int64, device="cuda")
+        for k in range(4 * len(trainer.order)):
+            trainer.step((synthetic_real(8, seed=900 + k).cuda(), labels))
+        torch.cuda.synchronize()
+        if fused:
+            assert took and min(took) >= 3, took              # every step handed several conv weights over
+        state = [module.state_dict()[k].detach().clone() for k in sorted(module.state_dict())]
+        for o in trainer.optim:
+            for p in o["optimizer"].param_groups[0]["params"]:
+                st = o["optimizer"].state[p]
+                state += [st["exp_avg"].clone(), st["exp_avg_sq"].clone(), st["step"].clone().cuda()]
+        res[fused] = state
+    assert len(res[True]) == len(res[False])
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)

@@ -1069,7 +1069,7 @@ def test_group_repack_equals_single_packs():
     """gz_conv2d_pack_multi (one launch for every packed image of an optimizer's weights) writes exactly what the
     per-image pack launches write: all four layouts (forward / transposed, reduction in (c, tap) or tap-major order)."""
     F = _F()
-    F.clear_pack_cache()
+    F.set_pack_cache(True)       # (a GraphedTrainer test that ran earlier in the process leaves the cache off)
     geoms = [F.K4S2P1, F.Geom(5, 5, 2, 2), F.Geom(3, 3, 1, 1), F.Geom(5, 5, 2, 2)]
     shapes = [(24, 12, 4, 4), (40, 32, 5, 5), (16, 20, 3, 3), (6, 3, 5, 5)]
     ws = [torch.nn.Parameter(rnd(*s, seed=300 + i).cuda()) for i, s in enumerate(shapes)]

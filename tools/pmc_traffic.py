@@ -73,6 +73,18 @@ if __name__ == "__main__":
     except Exception:  # noqa: BLE001
         table = {}
     table[key] = traffic
+    # stamp the table with the kernel sources it was measured on (bench.py: roofline.traffic_stale when the running
+    # library was built from other sources)
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from lightning_gan_zoo_amd.build import source_digest
+        stamps = table.get("_source_digest")
+        if not isinstance(stamps, dict):
+            stamps = {}
+        stamps[key] = source_digest()
+        table["_source_digest"] = stamps
+    except Exception as e:  # noqa: BLE001
+        print("(no source digest: %r)" % (e,), file=sys.stderr)
     json.dump(table, open(sys.argv[3], "w"), indent=1)
     try:
         alld = json.load(open(sys.argv[4]))
