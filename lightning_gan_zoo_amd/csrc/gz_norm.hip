@@ -207,56 +207,74 @@ __global__ __launch_bounds__(PW_THREADS) void norm_act_apply_kernel(const float*
 // the coefficient array the backward pass reads and updates the running buffers group after group (real, then fake),
 // as the separate finalize did.
 struct BnFuse {
-    int N, C, q4, groups, Ng, S, P;     // S slices per (channel, group), P samples per slice
-    FastDiv div_q4;
+    int N, C, q4, groups, Ng, S, P;     // S slices per (channel block, group), P samples per slice
+    int CB, run4;                       // channels per workgroup (a power of two <= 16), float4 per sample run = CB * q4
+    FastDiv div_q4, div_run;
 };
 
+// Channel blocks: with small maps (4 x 4, 8 x 8) one channel's plane is 64 / 256 bytes, and a workgroup that walked ONE
+// channel touched a 64-byte piece per sample (13.3 us per launch against 9.7 for the flat apply).  CB neighbouring
+// channels of a sample are contiguous in NCHW, so a workgroup that owns CB = 64 / q4 channels streams >= 1 KB runs.
 static BnFuse bn_fuse_geom(int N, int C, int inner, int groups) {
     BnFuse f;
     f.N = N; f.C = C; f.q4 = inner / 4; f.groups = groups; f.Ng = N / groups;
+    int cb = 1;
+    while (cb < 16 && cb * f.q4 < 64 && C % (cb * 2) == 0) cb *= 2;
+    f.CB = cb;
+    f.run4 = cb * f.q4;
     f.div_q4 = make_fastdiv(f.q4);
+    f.div_run = make_fastdiv(f.run4);
     // >= ~1024 workgroups, each with >= 512 float4 where the tensor allows
-    long long per_cg = (long long)f.Ng * f.q4;
+    const long long per_cg = (long long)f.Ng * f.run4;
+    const long long blocks = (long long)(C / cb) * groups;
     int S = 1;
-    while ((long long)C * groups * S < 1024 && S * 2 <= f.Ng && per_cg / (S * 2) >= 512) S *= 2;
+    while (blocks * S < 1024 && S * 2 <= f.Ng && per_cg / (S * 2) >= 512) S *= 2;
     f.S = S;
     f.P = (f.Ng + S - 1) / S;
     return f;
 }
 
-__device__ __forceinline__ void block_sum2_d(double& s1, double& s2, double (*part)[2]) {
-    s1 = wave_sum_d(s1);
-    s2 = wave_sum_d(s2);
-    __syncthreads();                       // (the previous use of `part` is over)
-    if ((threadIdx.x & 63) == 0) {
-        part[threadIdx.x >> 6][0] = s1;
-        part[threadIdx.x >> 6][1] = s2;
+// sums of (x, y) pairs over `count` entries strided by `stride` f32x2, for the CB channels of this workgroup: thread t
+// takes channel t % CB and entries t / CB, t / CB + 256 / CB, ...; the partial sums meet in LDS by halving.  Result for
+// channel cb in red[cb] (valid for all threads after the call).
+__device__ __forceinline__ void block_channel_sums(const f32x2* __restrict__ base, long long stride, int count, int CB,
+                                                   double (*red)[2]) {
+    const int tid = threadIdx.x, cb = tid % CB, rr = tid / CB, lanes = PW_THREADS / CB;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = rr; r < count; r += lanes) {
+        const f32x2 v = base[(long long)r * stride + cb];
+        s1 += (double)v.x;
+        s2 += (double)v.y;
     }
+    __syncthreads();                       // (the previous use of `red` is over)
+    red[tid][0] = s1;
+    red[tid][1] = s2;
     __syncthreads();
-    s1 = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
-    s2 = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
+    for (int h = lanes >> 1; h >= 1; h >>= 1) {
+        if (rr < h) {
+            red[tid][0] += red[tid + h * CB][0];
+            red[tid][1] += red[tid + h * CB][1];
+        }
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(PW_THREADS) void bn_apply_fused_kernel(
     const float* __restrict__ x, const f32x2* __restrict__ sums, int rows, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ coef, float* running_mean, float* running_var, long long* nbt,
     float* __restrict__ out, BnFuse f, int inner, float eps, float momentum, int act, float slope) {
-    __shared__ double part[4][2];
-    __shared__ float mine[2];
+    __shared__ double red[PW_THREADS][2];
+    __shared__ float mine[16][2];
     const int tid = threadIdx.x;
-    const int s = blockIdx.x % f.S, cg = blockIdx.x / f.S, g = cg % f.groups, c = cg / f.groups;
+    const int s = blockIdx.x % f.S, bg = blockIdx.x / f.S, g = bg % f.groups, c0 = (bg / f.groups) * f.CB;
     const bool owner = g == 0 && s == 0;
     const int Rg = rows / f.groups, NC = f.groups * f.C;
     for (int gg = 0; gg < f.groups; ++gg) {
         if (!owner && gg != g) continue;                       // (uniform per workgroup)
-        double s1 = 0.0, s2 = 0.0;
-        for (int r = tid; r < Rg; r += PW_THREADS) {
-            const f32x2 v = sums[(long long)(gg * Rg + r) * f.C + c];
-            s1 += (double)v.x;
-            s2 += (double)v.y;
-        }
-        block_sum2_d(s1, s2, part);
-        if (tid == 0) {
+        block_channel_sums(sums + (long long)gg * Rg * f.C + c0, f.C, Rg, f.CB, red);
+        if (tid < f.CB) {
+            const int c = c0 + tid;
+            const double s1 = red[tid][0], s2 = red[tid][1];
             const double cnt = count > 0.0 ? count : (double)f.Ng * inner;
             const double mean = s1 / cnt;
             double var = s2 / cnt - mean * mean;
@@ -265,8 +283,8 @@ __global__ __launch_bounds__(PW_THREADS) void bn_apply_fused_kernel(
             const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
             const float scale = ga * rstd, shift = be - (float)mean * scale;
             if (gg == g) {
-                mine[0] = scale;
-                mine[1] = shift;
+                mine[tid][0] = scale;
+                mine[tid][1] = shift;
             }
             if (owner) {
                 const int ci = gg * f.C + c;
@@ -282,17 +300,19 @@ __global__ __launch_bounds__(PW_THREADS) void bn_apply_fused_kernel(
             }
         }
     }
-    if (owner && c == 0 && tid == 0 && nbt) *nbt += f.groups;
+    if (owner && c0 == 0 && tid == 0 && nbt) *nbt += f.groups;
     __syncthreads();
-    const float sc = mine[0], sh = mine[1];
     const int n0 = g * f.Ng + s * f.P;
     const int n1 = min(g * f.Ng + f.Ng, n0 + f.P);
-    const int total = (n1 - n0) * f.q4;
+    const int total = (n1 - n0) * f.run4;
     const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x);
     f32x4* __restrict__ o4 = reinterpret_cast<f32x4*>(out);
     for (int i = tid; i < total; i += PW_THREADS) {
-        const uint32_t p = fdiv((uint32_t)i, f.div_q4);
-        const long long idx = ((long long)(n0 + (int)p) * f.C + c) * f.q4 + (i - (int)p * f.q4);
+        const uint32_t p = fdiv((uint32_t)i, f.div_run);
+        const uint32_t rem = (uint32_t)i - p * (uint32_t)f.run4;
+        const uint32_t cb = fdiv(rem, f.div_q4);
+        const long long idx = ((long long)(n0 + (int)p) * f.C + c0) * f.q4 + rem;
+        const float sc = mine[cb][0], sh = mine[cb][1];
         const f32x4 v = x4[idx];
         f32x4 o;
 #pragma unroll
@@ -564,61 +584,64 @@ __global__ __launch_bounds__(PW_THREADS) void norm_bwd_apply_kernel(const float*
     }
 }
 
-// BatchNorm backward, finalize + apply in ONE launch (see bn_apply_fused_kernel): workgroup (c, g, s) sums the row sums
-// (sum dz, sum dz xh) of its (g, c) over the group's samples, forms k1, k2 and streams dx for its slice; the owner
-// (g = 0, s = 0) also writes / adds dgamma[c], dbeta[c] summed over all groups (and k, for callers that read it).
+// BatchNorm backward, finalize + apply in ONE launch (see bn_apply_fused_kernel): workgroup (channel block, g, s) sums
+// the row sums (sum dz, sum dz xh) of its channels over the group's samples, forms k1, k2 and streams dx for its slice;
+// the owner (g = 0, s = 0) also writes / adds dgamma, dbeta summed over all groups (and k, for callers that read it).
 __global__ __launch_bounds__(PW_THREADS) void bn_bwd_apply_fused_kernel(
     const float* __restrict__ gout, const float* __restrict__ x, const float* __restrict__ coef,
     const f32x2* __restrict__ sums, float* __restrict__ kout, float* __restrict__ dgamma, float* __restrict__ dbeta,
     float* __restrict__ dx, BnFuse f, int inner, int act, float slope, int accumulate) {
-    __shared__ double part[4][2];
-    __shared__ float mine[2];
+    __shared__ double red[PW_THREADS][2];
+    __shared__ float mine[16][6];          // k1, k2, scale, shift, mean, rstd
     const int tid = threadIdx.x;
-    const int s = blockIdx.x % f.S, cg = blockIdx.x / f.S, g = cg % f.groups, c = cg / f.groups;
+    const int s = blockIdx.x % f.S, bg = blockIdx.x / f.S, g = bg % f.groups, c0 = (bg / f.groups) * f.CB;
     const bool owner = g == 0 && s == 0;
     const int NC = f.groups * f.C;
     double t1 = 0.0, t2 = 0.0;
     for (int gg = 0; gg < f.groups; ++gg) {
         if (!owner && gg != g) continue;
-        double s1 = 0.0, s2 = 0.0;
-        for (int n = tid; n < f.Ng; n += PW_THREADS) {
-            const f32x2 v = sums[(long long)(gg * f.Ng + n) * f.C + c];
-            s1 += (double)v.x;
-            s2 += (double)v.y;
-        }
-        block_sum2_d(s1, s2, part);
-        if (tid == 0) {
+        block_channel_sums(sums + (long long)gg * f.Ng * f.C + c0, f.C, f.Ng, f.CB, red);
+        if (tid < f.CB) {
+            const double s1 = red[tid][0], s2 = red[tid][1];
             const double cnt = (double)f.Ng * inner;
             const float k1 = (float)(s1 / cnt), k2 = (float)(s2 / cnt);
             if (gg == g) {
-                mine[0] = k1;
-                mine[1] = k2;
+                mine[tid][0] = k1;
+                mine[tid][1] = k2;
             }
             if (owner && kout) {
-                kout[gg * f.C + c] = k1;
-                kout[NC + gg * f.C + c] = k2;
+                kout[gg * f.C + c0 + tid] = k1;
+                kout[NC + gg * f.C + c0 + tid] = k2;
             }
             t1 += s1;
             t2 += s2;
         }
     }
-    if (owner && tid == 0) {
-        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)t2;
-        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)t1;
+    if (tid < f.CB) {
+        const int c = c0 + tid, ci = g * f.C + c;
+        if (owner) {
+            if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)t2;
+            if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)t1;
+        }
+        mine[tid][2] = coef[ci];
+        mine[tid][3] = coef[NC + ci];
+        mine[tid][4] = coef[2 * NC + ci];
+        mine[tid][5] = coef[3 * NC + ci];
     }
     __syncthreads();
-    const float k1 = mine[0], k2 = mine[1];
-    const int ci = g * f.C + c;
-    const float sc = coef[ci], sh = coef[NC + ci], mean = coef[2 * NC + ci], rstd = coef[3 * NC + ci];
     const int n0 = g * f.Ng + s * f.P;
     const int n1 = min(g * f.Ng + f.Ng, n0 + f.P);
-    const int total = (n1 - n0) * f.q4;
+    const int total = (n1 - n0) * f.run4;
     const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x);
     const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(gout);
     f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(dx);
     for (int i = tid; i < total; i += PW_THREADS) {
-        const uint32_t p = fdiv((uint32_t)i, f.div_q4);
-        const long long idx = ((long long)(n0 + (int)p) * f.C + c) * f.q4 + (i - (int)p * f.q4);
+        const uint32_t p = fdiv((uint32_t)i, f.div_run);
+        const uint32_t rem = (uint32_t)i - p * (uint32_t)f.run4;
+        const uint32_t cb = fdiv(rem, f.div_q4);
+        const long long idx = ((long long)(n0 + (int)p) * f.C + c0) * f.q4 + rem;
+        const float k1 = mine[cb][0], k2 = mine[cb][1], sc = mine[cb][2], sh = mine[cb][3], mean = mine[cb][4],
+                    rstd = mine[cb][5];
         const f32x4 xv = x4[idx], gv = g4[idx];
         f32x4 o;
 #pragma unroll
@@ -1034,7 +1057,7 @@ int gz_batchnorm_act_fwd_fused(const float* x, const float* partials, int rows, 
         return GZ_ERR_BAD_SHAPE;
     }
     const BnFuse f = bn_fuse_geom(N, C, inner, groups);
-    hipLaunchKernelGGL(bn_apply_fused_kernel, dim3(C * groups * f.S), dim3(PW_THREADS), 0, stream, x, sums, rows, cnt,
+    hipLaunchKernelGGL(bn_apply_fused_kernel, dim3((C / f.CB) * groups * f.S), dim3(PW_THREADS), 0, stream, x, sums, rows, cnt,
                        gamma, beta, coef, running_mean, running_var, num_batches_tracked, out, f, inner, eps, momentum,
                        act, slope);
     return launch_status();
@@ -1207,7 +1230,7 @@ static int norm_act_bwd_impl(const float* gout, const float* x, const float* coe
                        (f32x2*)workspace, rg, C, per_channel, g.ncoef, act, slope, g.group_rows);
     if (per_channel && dx && !unfused) {
         const BnFuse f = bn_fuse_geom(N, C, inner, groups);
-        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel, dim3(C * groups * f.S), dim3(PW_THREADS), 0, stream, gout, x, coef,
+        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel, dim3((C / f.CB) * groups * f.S), dim3(PW_THREADS), 0, stream, gout, x, coef,
                            (const f32x2*)workspace, kbuf, dgamma, dbeta, dx, f, inner, act, slope, accumulate);
         return launch_status();
     }
