@@ -37,13 +37,26 @@ def main():
             print("(no usable API trace: %r)" % (e,))
     rows = rows[len(rows) // 2:]
     span = (int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])) / 1e3
-    busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows) / 1e3
+    # (union of the kernels' intervals: under data parallelism RCCL's kernels run on a second stream and overlap)
+    busy, cur_end = 0.0, None
+    for r in rows:
+        a_, b_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if cur_end is None or a_ >= cur_end:
+            busy += (b_ - a_) / 1e3
+            cur_end = b_
+        elif b_ > cur_end:
+            busy += (b_ - cur_end) / 1e3
+            cur_end = b_
     by = defaultdict(lambda: [0, 0.0, 0, 0.0])          # name -> [gaps, us, host-late gaps, host-late us]
     hist = defaultdict(lambda: [0, 0.0])
     edges = ((0, 1), (1, 2), (2, 3), (3, 4), (4, 6), (6, 10), (10, 20), (20, 50), (50, 1e9))
     tot = host_us = 0.0
     host_n = known = 0
+    front = None                       # the kernel whose end is the latest so far (several streams may overlap)
     for a, b in zip(rows, rows[1:]):
+        if front is None or int(a["End_Timestamp"]) > int(front["End_Timestamp"]):
+            front = a
+        a = front
         g = (int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3
         if g <= 0:
             continue
@@ -72,6 +85,8 @@ def main():
         names[r["Kernel_Name"]] += 1
     steps = sum(n for k, n in names.items() if "adam_kernel" in k or "rmsprop_kernel" in k)
     cycles = steps / per_cycle if steps else 0      # one fused optimizer launch per batch of the cycle
+    if len(sys.argv) > 4:                           # the caller knows how many optimizer cycles the WHOLE trace holds
+        cycles = float(sys.argv[4]) / 2.0           # (per-bucket optimizer launches under ddp.GradSync; half = this window)
     print("dispatches %d, span %.1f us, kernel time %.1f us (%.2f %% busy), idle %.1f us (%.2f %%)"
           % (len(rows), span, busy, 100 * busy / span, tot, 100 * tot / span))
     if cycles:
