@@ -225,3 +225,28 @@ def test_runner_trains_from_an_image_folder(tmp_path):
     assert step == 4 and all(torch.isfinite(p).all() for p in module.parameters())
     # 6 images, batch 3 -> 2 steps per epoch -> the 4 steps were 2 epochs
     assert trainer.optim[0]["lr_scheduler"].last_epoch == 2
+
+
+def test_accumulate_grad_batches_reaches_the_trainer_in_both_forms():
+    """reference run_network.py:61-68: ``accumulate_grad_batches`` is the int 1 (conf/config.yaml:57) or a ``{start_epoch,
+    accumulation_factor}`` node (conf/machine/*.yaml) that becomes Lightning's ``{start_epoch: factor}`` scheduler.  Both
+    forms go through the runner's command line into harness.Trainer, and change the trajectory as they should: factor 2
+    from epoch 0 differs from no accumulation from the first epoch on, factor 2 from epoch 1 equals no accumulation for
+    the whole first epoch."""
+    torch.set_num_threads(2)
+    base = SMALL + ["train.batch_size=2", "steps_per_epoch=4"]
+
+    def params(extra, steps):
+        module, trainer, step, cfg = run_on_cpu("dc_gan", base + ["max_steps=%d" % steps] + extra)
+        assert step == steps
+        return torch.cat([p.detach().reshape(-1) for p in module.parameters()]), trainer
+
+    plain4, _ = params([], 4)
+    plain8, tr = params([], 8)
+    assert tr.accumulate_grad_batches == 1
+    acc4, tr = params(["accumulate_grad_batches=2"], 4)
+    assert tr.accumulate_grad_batches == 2 and not torch.equal(acc4, plain4)
+    late4, tr = params(["accumulate_grad_batches={start_epoch: 1, accumulation_factor: 2}"], 4)
+    assert tr.accumulate_grad_batches == {1: 2} and torch.equal(late4, plain4)       # epoch 0: factor 1
+    late8, _ = params(["accumulate_grad_batches={start_epoch: 1, accumulation_factor: 2}"], 8)
+    assert not torch.equal(late8, plain8)                                            # epoch 1: factor 2
