@@ -127,6 +127,18 @@ int gz_conv2d_plan(int op, int N, int C, int H, int W, int K, int OH, int OW, in
 int gz_conv2d_wgrad_partial(const float* x, const float* y, float* dw, float* workspace, size_t ws_bytes, int N, int C,
                             int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, int* nz_out,
                             long long* stride_out, hipStream_t stream);
+/* Round 5 -- the first-order backward of `act(conv(x) + bias)` for the critics' first layer (k4 s2 p1, <= 4 image
+ * channels, act = ReLU / LeakyReLU; reference core/models/standard_networks.py:62-66: Conv2d(3, features_d, 4, 2, 1) +
+ * LeakyReLU(0.2)) in ONE launch: gy is the gradient with respect to the activation's OUTPUT, masked on load with the
+ * saved forward output fwd_out; every slab row holds the K * C * 16 weight-gradient partial sums followed, at
+ * *bias_offset_out, by the K bias-gradient partial sums.  Always partial: sum the *nz_out rows (*stride_out floats
+ * apart) with gz_reduce_multi or hand them to gz_adam_step_from_slabs.  workspace: gz_conv2d_wgrad_workspace_bytes.
+ * gz_conv2d_wgrad_act_fuses reports whether the shape takes this path (otherwise: gz_act_bwd + gz_conv2d_wgrad). */
+int gz_conv2d_wgrad_act_fuses(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, int act);
+int gz_conv2d_wgrad_act_partial(const float* x, const float* gy, const float* fwd_out, int act, float slope,
+                                float* workspace, size_t ws_bytes, int N, int C, int H, int W, int K, int OH, int OW,
+                                int KH, int KW, int S, int P, int* nz_out, long long* stride_out,
+                                long long* bias_offset_out, hipStream_t stream);
 int gz_reduce_multi_max_jobs(void);
 int gz_reduce_multi_max_sources(void);
 size_t gz_reduce_multi_table_bytes(void);

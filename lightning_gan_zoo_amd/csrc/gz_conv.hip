@@ -775,18 +775,24 @@ __global__ __launch_bounds__(256) void dgrad_smallc_k4s2p1_kernel(const float* _
 // wavefronts); their partial sums meet in LDS and wavefront 0 applies bias / activation and stores.
 // KH = 5 (round 3): the 5x5 s2 p2 transposed convolution has the same 3 x 3 neighbourhood (rows a-1 .. a+1) and
 // 9 / 6 / 6 / 4 taps per phase; its weights come in the tap-major pack (pack_dgrad_tap: [phase][tap][ko padded][4]).
-template <int C, int KS, int KH = 4>      // KS = 4: channel loop split over the workgroup's wavefronts; KS = 1: 256 lane positions
-__global__ __launch_bounds__(256) void dgrad_smallc4_k4s2p1_kernel(const float* __restrict__ y,
+// Round 5: the wavefront index is read into a scalar register (readfirstlane).  As a per-lane value it made the
+// channel index "divergent" for the compiler: the 16 weight rows of a channel were fetched with sixteen 64-lane
+// vector loads of ONE address each (1 KB through the vector cache per instruction, 16 KB per channel and wavefront --
+// the vector cache, not the 96 packed FMAs, set the pace: 41 us at bs 128) and every y load sat in a waterfall loop.
+// With a uniform index they are scalar loads into SGPRs again, as in the unsplit form.  KS = 8 (512 threads): eight
+// wavefronts per 64 lane positions -- 4 per SIMD at bs 128 instead of 2; partial sums meet in a binary tree in LDS.
+template <int C, int KS, int KH = 4>      // KS = 4 / 8: channel loop split over the workgroup's wavefronts; KS = 1: 256 lane positions
+__global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void dgrad_smallc4_k4s2p1_kernel(const float* __restrict__ y,
                                                                    const float* __restrict__ wp,
                                                                    const float* __restrict__ bias,
                                                                    float* __restrict__ x, ConvShape s,
                                                                    FastDiv div_ohw4, FastDiv div_ow4, int act,
                                                                    float slope) {
     constexpr int P = KH == 4 ? 1 : 2, TMAX = (KH + 1) / 2;
-    __shared__ float part[KS > 1 ? 3 : 1][KS > 1 ? 16 * C : 1][64];
+    __shared__ float part[KS > 1 ? KS / 2 : 1][KS > 1 ? 16 * C : 1][64];
     const int OW4 = s.OW >> 2, OHW = s.OH * s.OW;
     const uint32_t M4 = (uint32_t)s.N * s.OH * OW4;
-    const int lane = threadIdx.x & 63, wave = KS > 1 ? threadIdx.x >> 6 : 0;
+    const int lane = threadIdx.x & 63, wave = KS > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
     const uint32_t m = KS > 1 ? blockIdx.x * 64u + lane : blockIdx.x * 256u + threadIdx.x;
     const bool m_ok = m < M4;
     const uint32_t n = fdiv(m, div_ohw4);
@@ -874,7 +880,37 @@ __global__ __launch_bounds__(256) void dgrad_smallc4_k4s2p1_kernel(const float* 
             }
     }
     if constexpr (KS > 1) {
-        if (wave > 0) {
+        // binary tree, fixed order: wavefronts [h, 2h) hand their sums to wavefronts [0, h), h = KS/2 .. 1
+#pragma unroll
+        for (int h = KS / 2; h >= 1; h >>= 1) {
+            if (wave >= h && wave < 2 * h) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int c = 0; c < C; ++c)
+                                part[wave - h][((q * 2 + i) * 2 + j) * C + c][lane] = acc[q][i][j][c];
+            }
+            __syncthreads();
+            if (wave < h) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int c = 0; c < C; ++c)
+                                acc[q][i][j][c] += part[wave][((q * 2 + i) * 2 + j) * C + c][lane];
+            }
+            __syncthreads();
+        }
+        // the totals go back through LDS once more so that bias, activation (tanh in G's last layer: ~60 instructions
+        // per value) and the 16-byte stores are shared by all KS wavefronts instead of wavefront 0 doing all 16 * C
+        if (wave == 0) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -882,22 +918,22 @@ __global__ __launch_bounds__(256) void dgrad_smallc4_k4s2p1_kernel(const float* 
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int c = 0; c < C; ++c)
-                            part[wave - 1][((q * 2 + i) * 2 + j) * C + c][lane] = acc[q][i][j][c];
+                        for (int c = 0; c < C; ++c) part[0][((q * 2 + i) * 2 + j) * C + c][lane] = acc[q][i][j][c];
         }
         __syncthreads();
-        if (wave > 0) return;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        const int e = ((q * 2 + i) * 2 + j) * C + c;
-                        acc[q][i][j][c] += (part[0][e][lane] + part[1][e][lane]) + part[2][e][lane];
-                    }
+        if (!m_ok) return;
+        for (int g = wave; g < 4 * C; g += KS) {           // g = (c, py, h): one 16-byte store each
+            const int c = g >> 2, py = (g >> 1) & 1, h = g & 1;
+            const float bv = bias ? bias[c] : 0.f;
+            float* dst = x + (((long long)n * C + c) * s.H + (2 * a + py)) * s.W + 2 * b;
+            f32x4 o;
+            o.x = act_fwd(part[0][(((2 * h) * 2 + py) * 2 + 0) * C + c][lane] + bv, act, slope);
+            o.y = act_fwd(part[0][(((2 * h) * 2 + py) * 2 + 1) * C + c][lane] + bv, act, slope);
+            o.z = act_fwd(part[0][(((2 * h + 1) * 2 + py) * 2 + 0) * C + c][lane] + bv, act, slope);
+            o.w = act_fwd(part[0][(((2 * h + 1) * 2 + py) * 2 + 1) * C + c][lane] + bv, act, slope);
+            *reinterpret_cast<f32x4*>(dst + 4 * h) = o;
+        }
+        return;
     }
     if (!m_ok) return;
 #pragma unroll
@@ -919,6 +955,16 @@ __global__ __launch_bounds__(256) void dgrad_smallc4_k4s2p1_kernel(const float* 
     }
 }
 
+// How many wavefronts share the channel loop of 64 lane positions (the KS of dgrad_smallc4_k4s2p1_kernel): enough that
+// every SIMD has about four wavefronts to switch between -- a launch has M4 / 64 * KS of them on 1024 SIMDs.
+static int smallc_split(long long M4, int K) {
+    const int forced = knobs().smallc_ks;
+    if (forced == 1 || forced == 4 || forced == 8) return K >= 2 * forced || forced == 1 ? forced : 1;
+    if (K < 16) return 1;
+    if (M4 < knobs().smallc_split8_below && K >= 32) return 8;
+    return M4 < knobs().smallc_split_below ? 4 : 1;
+}
+
 // 5x5 s2 p2 onto <= 4 channels (HoloGAN's critic: the gradient of its first convolution with respect to the image):
 // the four-positions kernel only (rows of OW/4 lanes inside a wavefront, 16-byte aligned tensors, tap-major pack)
 static bool dgrad_direct5_ok(const float* y, const float* x, const ConvShape& s) {
@@ -931,8 +977,11 @@ template <int C>
 static int run_dgrad_smallc5(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s, int act,
                              float slope, hipStream_t st) {
     const long long M4 = (long long)s.N * s.OH * s.OW / 4;
-    const long long split_below = knobs().smallc_split_below;
-    if (M4 < split_below)
+    const int ks = smallc_split(M4, s.K);
+    if (ks == 8)
+        hipLaunchKernelGGL((dgrad_smallc4_k4s2p1_kernel<C, 8, 5>), dim3((unsigned)((M4 + 63) / 64)), dim3(512), 0, st, y, wp,
+                           bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope);
+    else if (ks == 4)
         hipLaunchKernelGGL((dgrad_smallc4_k4s2p1_kernel<C, 4, 5>), dim3((unsigned)((M4 + 63) / 64)), dim3(256), 0, st, y, wp,
                            bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope);
     else
@@ -953,8 +1002,11 @@ static int run_dgrad_smallc(const float* y, const float* wp, const float* bias, 
         // (0.080 -> 0.056 ms there; at bs 512 the unsplit form is 2x faster)
         // (round 3: measured crossover between bs 128 and bs 160 at 32x32 feature maps -- 32768 / 40960 lane positions;
         // bs 256: 114 -> 91 us for G's last layer without the split)
-        const long long split_below = knobs().smallc_split_below;
-        if (M4 < split_below && s.K >= 16)
+        const int ks = smallc_split(M4, s.K);
+        if (ks == 8)
+            hipLaunchKernelGGL((dgrad_smallc4_k4s2p1_kernel<C, 8>), dim3((unsigned)((M4 + 63) / 64)), dim3(512), 0, st, y,
+                               wp, bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope);
+        else if (ks == 4)
             hipLaunchKernelGGL((dgrad_smallc4_k4s2p1_kernel<C, 4>), dim3((unsigned)((M4 + 63) / 64)), dim3(256), 0, st, y,
                                wp, bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope);
         else
@@ -1809,6 +1861,202 @@ static int launch_wgrad(const typename AL::Params& pa, const typename BL::Params
     return rc;
 }
 
+// ---------------------------------------------------------------------------
+// Wg of k4 s2 p1 layers with <= 4 channels on the image side (the critics' first convolution and -- as the adjoint --
+// G's last transposed convolution): dw[k][c][ky][kx] = sum over (n, oy, ox) of y[n][k][oy][ox] *
+// x[n][c][2 oy - 1 + ky][2 ox - 1 + kx], a K x (C * 16) result from a reduction over all N * OH * OW pixels.  On the
+// implicit-GEMM skeleton that is ONE 64 x 64 or 128 x 64 tile split 512 ways: prologue, epilogue and a BK-chunk per
+// workgroup (36 / 28 us at bs 128 for 5 / 9 us of HBM time).  Here v_mfma_f32_16x16x4_f32 runs with k = 4 pixels:
+// A[channel k][pixel] comes from ONE 16-byte load per lane, 16-channel block and 16-pixel segment (component j of the
+// vector feeds MFMA j: pixel ox0 + 4 q + j -- any assignment of pixels to k slots is as good as another, as long as B
+// uses the same); B[pixel][(ky, kx)] = x[c][2 oy - 1 + ky][2 (ox0 + 4 q + j) - 1 + kx] is one dword load per lane, c
+// and j (padding columns are out-of-range voffsets, padding rows wave-uniform).  A wavefront walks its share of the
+// (n, oy, segment) items with the next item's loads in flight; the four wavefronts of a workgroup meet in an LDS tree
+// and wavefront 0 writes the workgroup's slab (the same slabs gz_reduce_multi / the optimizer read).  In the step at
+// bs 128 (inputs cold): D.conv_in 36 -> 27 us.  (Issuing the loads of four items at once measured 35 us.)
+// ---------------------------------------------------------------------------
+// FUSE (round 5, the first-order backward of `LeakyReLU(conv(x) + bias)`): the operand is the gradient with respect to
+// the ACTIVATION's output, masked on load with the saved forward output (g * (out > 0 ? 1 : slope) -- the act_bwd
+// launch and its write + re-read of the 34 MB gradient disappear), and a (C+1)-th column block multiplies it with a
+// column of ones: D[k][0] = sum over the pixels = the bias gradient, which lands behind the K * C * 16 weight-gradient
+// values of the workgroup's slab (a channel_sum launch and its second read of the gradient disappear).
+template <int C, int KT, bool FUSE>      // image channels; 16-channel blocks on the feature side
+__global__ __launch_bounds__(256) void wgrad_k4s2p1_fewc_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                const float* __restrict__ fwd_out, float* __restrict__ slab,
+                                                                int N, int K, int H, int W, int OH, int OW, int items,
+                                                                FastDiv div_seg, FastDiv div_oh, int act, float slope,
+                                                                long long slab_stride) {
+    constexpr int CB = FUSE ? C + 1 : C;
+    __shared__ float part[2][KT * CB * 4][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    const int ky = i >> 2, kx = i & 3;
+    const int HW = H * W, OHW = OH * OW;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (uint32_t)N * C * HW * 4u);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(y, (uint32_t)N * K * OHW * 4u);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(FUSE ? fwd_out : y, (uint32_t)N * K * OHW * 4u);
+    const float neg = act == ACT_RELU ? 0.f : slope;
+    const float ones = i == 0 ? 1.f : 0.f;
+    const int segs = OW >> 4;
+    const int nwaves = gridDim.x * 4;
+    auto fetch = [&](int g, f32x4 (&ya)[KT], f32x4 (&oa)[FUSE ? KT : 1], float (&xb)[C][4]) {
+        const uint32_t rowid = fdiv((uint32_t)g, div_seg);               // n * OH + oy
+        const int ox0 = (g - (int)rowid * segs) << 4;
+        const uint32_t n = fdiv(rowid, div_oh);
+        const int oy = (int)(rowid - n * (uint32_t)OH);
+        const uint32_t vy = ((n * (uint32_t)K + i) * (uint32_t)OHW + (uint32_t)(oy * OW + ox0 + 4 * q)) * 4u;
+#pragma unroll
+        for (int a = 0; a < KT; ++a) {
+            ya[a] = bload4(ry, vy, (uint32_t)(a * 16 * OHW) * 4u);
+            if constexpr (FUSE) oa[a] = bload4(ro, vy, (uint32_t)(a * 16 * OHW) * 4u);
+        }
+        const int row = 2 * oy - 1 + ky;
+        const bool rok = (unsigned)row < (unsigned)H;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = 2 * (ox0 + 4 * q + j) - 1 + kx;
+            const uint32_t vx = (rok && (unsigned)col < (unsigned)W)
+                                    ? (n * (uint32_t)(C * HW) + (uint32_t)(row * W + col)) * 4u : OOB;
+#pragma unroll
+            for (int c = 0; c < C; ++c) xb[c][j] = bload(rx, vx, (uint32_t)(c * HW) * 4u);
+        }
+    };
+    f32x4 acc[KT][CB];
+#pragma unroll
+    for (int a = 0; a < KT; ++a)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int g = blockIdx.x * 4 + wave;
+    if (g < items) {
+        f32x4 yc[KT], yn[KT], oc[FUSE ? KT : 1], on[FUSE ? KT : 1];
+        float xc[C][4], xn[C][4];
+        fetch(g, yc, oc, xc);
+        for (; g < items; g += nwaves) {
+            const bool more = g + nwaves < items;
+            if (more) fetch(g + nwaves, yn, on, xn);      // in flight during this item's 4 * KT * CB MFMAs
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < KT; ++a) {
+                    float av = yc[a][j];
+                    if constexpr (FUSE) av = oc[a][j] > 0.f ? av : av * neg;
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xc[c][j], acc[a][c], 0, 0, 0);
+                    if constexpr (FUSE) acc[a][C] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ones, acc[a][C], 0, 0, 0);
+                }
+            if (more) {
+#pragma unroll
+                for (int a = 0; a < KT; ++a) {
+                    yc[a] = yn[a];
+                    if constexpr (FUSE) oc[a] = on[a];
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xc[c][j] = xn[c][j];
+            }
+        }
+    }
+    // binary tree over the four wavefronts, fixed order
+#pragma unroll
+    for (int h = 2; h >= 1; h >>= 1) {
+        if (wave >= h && wave < 2 * h) {
+#pragma unroll
+            for (int a = 0; a < KT; ++a)
+#pragma unroll
+                for (int c = 0; c < CB; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part[wave - h][(a * CB + c) * 4 + r][lane] = acc[a][c][r];
+        }
+        __syncthreads();
+        if (wave < h) {
+#pragma unroll
+            for (int a = 0; a < KT; ++a)
+#pragma unroll
+                for (int c = 0; c < CB; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[a][c][r] += part[wave][(a * CB + c) * 4 + r][lane];
+        }
+        __syncthreads();
+    }
+    if (wave > 0) return;
+    // D[row = channel 16 a + 4 q + r][column = (ky, kx)]  ->  dw[k][c][ky][kx]; the ones column -> dbias[k]
+    float* out = slab + (long long)blockIdx.x * slab_stride;
+#pragma unroll
+    for (int a = 0; a < KT; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) out[((a * 16 + 4 * q + r) * C + c) * 16 + i] = acc[a][c][r];
+            if constexpr (FUSE) {
+                if (i == 0) out[K * C * 16 + a * 16 + 4 * q + r] = acc[a][C][r];
+            }
+        }
+}
+
+static bool wgrad_k4s2p1_fewc_ok(const ConvShape& s) {
+    // (K = 128, G's last layer: 29 us against the tile path's 28 in the step at bs 128 -- not taken)
+    return !knobs().no_fewc_wg && s.C <= 4 && (s.K == 16 || s.K == 32 || s.K == 64) &&
+           s.H == 2 * s.OH && s.W == 2 * s.OW && s.OW % 16 == 0 && (long long)s.N * s.K * s.OH * s.OW < (1ll << 29) &&
+           (long long)s.N * s.OH * (s.OW >> 4) >= 1024;
+}
+
+static int wgrad_k4s2p1_fewc_blocks(const ConvShape& s) {
+    const long long items = (long long)s.N * s.OH * (s.OW >> 4);
+    long long blocks = items / (4 * 4);                       // >= 4 items per wavefront
+    const long long cap = knobs().fewc_wg_blocks;
+    if (blocks > cap) blocks = cap;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+// fwd_out != nullptr: the fused form (y = gradient w.r.t. the activation output, masked with fwd_out; slab rows carry
+// the K bias-gradient values behind the K * C * 16 weight-gradient values).  The fused form is always left unreduced
+// (gz_conv2d_wgrad_act_partial).
+static int run_wgrad_k4s2p1_fewc(const float* x, const float* y, const float* fwd_out, int act, float slope, float* dw,
+                                 float* ws, size_t ws_bytes, const ConvShape& s, hipStream_t st) {
+    const bool fuse = fwd_out != nullptr;
+    const long long count = (long long)s.K * s.C * 16;
+    const long long stride = count + (fuse ? s.K : 0);
+    int blocks = wgrad_k4s2p1_fewc_blocks(s);
+    const long long room = (long long)(ws_bytes / 4) / stride;
+    if (room < 1 || !ws) return GZ_ERR_WORKSPACE;
+    if (blocks > room) blocks = (int)room;
+    const int items = s.N * s.OH * (s.OW >> 4);
+    const FastDiv dseg = make_fastdiv(s.OW >> 4), doh = make_fastdiv(s.OH);
+#define GZ_FEWC(C_, KT_, F_)                                                                                         \
+    hipLaunchKernelGGL((wgrad_k4s2p1_fewc_kernel<C_, KT_, F_>), dim3((unsigned)blocks), dim3(256), 0, st, x, y, fwd_out, \
+                       ws, s.N, s.K, s.H, s.W, s.OH, s.OW, items, dseg, doh, act, slope, stride)
+#define GZ_FEWC_C(KT_, F_)                                                                                           \
+    switch (s.C) {                                                                                                   \
+        case 1: GZ_FEWC(1, KT_, F_); break;                                                                          \
+        case 2: GZ_FEWC(2, KT_, F_); break;                                                                          \
+        case 3: GZ_FEWC(3, KT_, F_); break;                                                                          \
+        default: GZ_FEWC(4, KT_, F_);                                                                                \
+    }
+#define GZ_FEWC_K(F_)                                                                                                \
+    switch (s.K / 16) {                                                                                              \
+        case 1: GZ_FEWC_C(1, F_); break;                                                                             \
+        case 2: GZ_FEWC_C(2, F_); break;                                                                             \
+        default: GZ_FEWC_C(4, F_);                                                                                   \
+    }
+    if (fuse) { GZ_FEWC_K(true) } else { GZ_FEWC_K(false) }
+#undef GZ_FEWC_K
+#undef GZ_FEWC_C
+#undef GZ_FEWC
+    int rc = launch_status();
+    if (rc != GZ_OK) return rc;
+    if (defer_reduce(blocks, stride)) return rc;
+    if (fuse) return GZ_ERR_UNSUPPORTED;
+    if (blocks <= 8)
+        hipLaunchKernelGGL(reduce_few_slabs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ws, dw, blocks,
+                           count);
+    else
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64 * RS_WAVES), 0, st, ws, dw,
+                           blocks, count, count, (float*)nullptr, 0ll);
+    return launch_status();
+}
+
 // Weight gradient on the igemm2 skeleton (register-staged transposing loaders, two LDS stages).  Tile 256 (output
 // channels) x 128 ((c, ky, kx) columns); the reduction over the pixels is split so that >= 512 workgroups exist.
 using Cfg2Wg = TileCfg2<2, 2, 2, 2>;
@@ -2218,6 +2466,8 @@ size_t gz_conv2d_wgrad_workspace_bytes(int N, int C, int H, int W, int K, int OH
     long long count = (long long)K * C * KH * KW;
     ConvShape s{N, C, H, W, K, OH, OW};
     if (OH == H && OW == W && wgrad_smallch_ok(s, KH, KW, 1, 1)) return (size_t)wgrad_smallch_blocks(s) * (count + K) * 4;
+    size_t fewc = 0;
+    if (KH == 4 && KW == 4 && wgrad_k4s2p1_fewc_ok(s)) fewc = (size_t)wgrad_k4s2p1_fewc_blocks(s) * (count + K) * 4;
     int chunks = (N * OH * OW + BK - 1) / BK;
     // upper bound over the tile choices: smallest tile count is with 128x128 tiles
     long long tiles = (long long)((K + 127) / 128) * ((C * KH * KW + 127) / 128);
@@ -2228,7 +2478,8 @@ size_t gz_conv2d_wgrad_workspace_bytes(int N, int C, int H, int W, int K, int OH
                        : (KH == 3 && KW == 3 && OH == H) ? wgrad2_splits<G3311>(s) : 0;
         if (s2 > splits) splits = s2;
     }
-    return splits > 1 ? (size_t)splits * count * 4 : 0;
+    const size_t generic = splits > 1 ? (size_t)splits * count * 4 : 0;
+    return generic > fewc ? generic : fewc;
 }
 
 int gz_conv2d_wgrad_fuses_bias(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P) {
@@ -2244,6 +2495,9 @@ int gz_conv2d_wgrad(const float* x, const float* y, float* dw, float* dbias, flo
     if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
     if (wgrad_smallch_ok(s, KH, KW, S, P)) return run_wgrad_smallch(x, y, dw, dbias, workspace, ws_bytes, s, stream);
     if (dbias) return GZ_ERR_UNSUPPORTED;       // ask gz_conv2d_wgrad_fuses_bias first
+    if (KH == 4 && KW == 4 && S == 2 && P == 1 && wgrad_k4s2p1_fewc_ok(s) && workspace &&
+        ws_bytes >= (size_t)K * C * 16 * 4)
+        return run_wgrad_k4s2p1_fewc(x, y, nullptr, ACT_NONE, 0.f, dw, workspace, ws_bytes, s, stream);
 #define CALL(G) dispatch_wgrad<G>(x, y, dw, workspace, ws_bytes, s, stream)
     GZ_GEOM_DISPATCH(CALL)
 #undef CALL
@@ -2262,12 +2516,45 @@ int gz_conv2d_wgrad_partial(const float* x, const float* y, float* dw, float* wo
     if (wgrad_smallch_ok(s, KH, KW, S, P)) return run_wgrad_smallch(x, y, dw, nullptr, workspace, ws_bytes, s, stream);
     WgDefer d{1, *stride_out};
     tl_wg_defer = &d;
+    if (KH == 4 && KW == 4 && S == 2 && P == 1 && wgrad_k4s2p1_fewc_ok(s) && workspace &&
+        ws_bytes >= (size_t)K * C * 16 * 4) {
+        const int rc = run_wgrad_k4s2p1_fewc(x, y, nullptr, ACT_NONE, 0.f, dw, workspace, ws_bytes, s, stream);
+        tl_wg_defer = nullptr;
+        *nz_out = d.nz;
+        *stride_out = d.stride;
+        return rc;
+    }
 #define CALL(G) dispatch_wgrad<G>(x, y, dw, workspace, ws_bytes, s, stream)
     const int rc = [&]() -> int { GZ_GEOM_DISPATCH(CALL) }();
 #undef CALL
     tl_wg_defer = nullptr;
     *nz_out = d.nz;
     *stride_out = d.stride;
+    return rc;
+}
+
+int gz_conv2d_wgrad_act_fuses(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, int act) {
+    ConvShape s{N, C, H, W, K, OH, OW};
+    return shape_ok(s, KH, KW, S, P) && KH == 4 && KW == 4 && S == 2 && P == 1 && (act == ACT_RELU || act == ACT_LRELU) &&
+                   wgrad_k4s2p1_fewc_ok(s) ? 1 : 0;
+}
+
+int gz_conv2d_wgrad_act_partial(const float* x, const float* gy, const float* fwd_out, int act, float slope,
+                                float* workspace, size_t ws_bytes, int N, int C, int H, int W, int K, int OH, int OW,
+                                int KH, int KW, int S, int P, int* nz_out, long long* stride_out,
+                                long long* bias_offset_out, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (!nz_out || !stride_out || !bias_offset_out || !x || !gy || !fwd_out) return GZ_ERR_BAD_SHAPE;
+    if (!gz_conv2d_wgrad_act_fuses(N, C, H, W, K, OH, OW, KH, KW, S, P, act)) return GZ_ERR_UNSUPPORTED;
+    ConvShape s{N, C, H, W, K, OH, OW};
+    if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
+    WgDefer d{1, 0};
+    tl_wg_defer = &d;
+    const int rc = run_wgrad_k4s2p1_fewc(x, gy, fwd_out, act, slope, nullptr, workspace, ws_bytes, s, stream);
+    tl_wg_defer = nullptr;
+    *nz_out = d.nz;
+    *stride_out = d.stride;
+    *bias_offset_out = (long long)K * C * 16;
     return rc;
 }
 
@@ -2615,12 +2902,11 @@ static int describe_dgrad(const ConvShape& s, char* b, size_t n) {
     const long long M = (long long)s.N * s.OH * s.OW;
     if (dgrad_direct<G>(nullptr, s)) {
         if (!knobs().smallc_one_pos && s.OW % 4 == 0 && 64 % (s.OW / 4) == 0)
-            return snprintf(b, n, "Dg direct dgrad_smallc4_k4s2p1<C=%d,KS=%d>", s.C,
-                            (M / 4 < knobs().smallc_split_below && s.K >= 16) ? 4 : 1);
+            return snprintf(b, n, "Dg direct dgrad_smallc4_k4s2p1<C=%d,KS=%d>", s.C, smallc_split(M / 4, s.K));
         return snprintf(b, n, "Dg direct dgrad_smallc_k4s2p1<C=%d>", s.C);
     }
     if (G::kh == 5 && G::kw == 5 && G::s == 2 && G::p == 2 && dgrad_direct5_ok(nullptr, nullptr, s))
-        return snprintf(b, n, "Dg direct dgrad_smallc4_k5s2p2<C=%d,KS=%d>", s.C, M / 4 < knobs().smallc_split_below ? 4 : 1);
+        return snprintf(b, n, "Dg direct dgrad_smallc4_k5s2p2<C=%d,KS=%d>", s.C, smallc_split(M / 4, s.K));
     constexpr int TAPS = ((G::kh + G::s - 1) / G::s) * ((G::kw + G::s - 1) / G::s);
     const SplitPlan sp = dgrad_plan<G>(s);
     const int rows = gz_conv2d_dgrad_stats_rows(s.N, s.C, s.H, s.W, s.K, s.OH, s.OW, G::kh, G::kw, G::s, G::p);
@@ -2650,6 +2936,9 @@ static int describe_wgrad(const ConvShape& s, char* b, size_t n) {
     if (wgrad_smallch_ok(s, G::kh, G::kw, G::s, G::p))
         return snprintf(b, n, "Wg direct %s slabs=%d", wgrad_fewk_ok(s) ? "wgrad_k3_fewk<fma>" : "wgrad_smallch_k3<mfma16x16x4>",
                         wgrad_smallch_blocks(s));
+    if (G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1 && wgrad_k4s2p1_fewc_ok(s))
+        return snprintf(b, n, "Wg direct wgrad_k4s2p1_fewc<mfma16x16x4,C=%d,KT=%d> slabs=%d", s.C, s.K / 16,
+                        wgrad_k4s2p1_fewc_blocks(s));
     TileId t = (TileId)gz_conv2d_tile(2, s.N, s.C, s.H, s.W, s.K, s.OH, s.OW, G::kh, G::kw, G::s);
     const int chunks = (s.N * s.OH * s.OW + BK - 1) / BK;
     const int NTOT = s.C * G::kh * G::kw;

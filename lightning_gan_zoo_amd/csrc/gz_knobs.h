@@ -52,7 +52,11 @@ namespace gz {
     X(bool, no_smallc, "GZ_NO_SMALLC", false)                                                                         \
     X(bool, no_smallc5, "GZ_NO_SMALLC5", false)                                                                       \
     X(bool, smallc_one_pos, "GZ_SMALLC_ONE_POS", false)                                                               \
-    X(long long, smallc_split_below, "GZ_SMALLC_SPLIT_BELOW", 36 * 1024)                                              \
+    X(long long, smallc_split_below, "GZ_SMALLC_SPLIT_BELOW", 192 * 1024)                                             \
+    X(long long, smallc_split8_below, "GZ_SMALLC_SPLIT8_BELOW", 36 * 1024)                                            \
+    X(int, smallc_ks, "GZ_SMALLC_KS", 0)                                                                              \
+    X(bool, no_fewc_wg, "GZ_NO_FEWC_WG", false)                                                                       \
+    X(int, fewc_wg_blocks, "GZ_FEWC_WG_BLOCKS", 256)                                                                  \
     X(bool, no_smallch_conv, "GZ_NO_SMALLCH_CONV", false)                                                             \
     X(bool, no_smallch_wg, "GZ_NO_SMALLCH_WG", false)                                                                 \
     X(int, c3_gpw, "GZ_C3_GPW", 4)                                                                                    \

@@ -24,7 +24,21 @@ __device__ __forceinline__ f32x4 reduce_sources(const ReduceSrc* src, int nsrc, 
             const long long st = src[q].stride;
             const int nz = src[q].nz;
             int z = wave;
-            for (; z + 12 < nz; z += 16) {          // four independent 16-byte loads in flight per lane
+            // eight independent 16-byte loads in flight per lane (round 5; four before): with hundreds of slabs a
+            // wavefront's share is a chain of HBM round trips -- 512 slabs were 32 of them, now 16
+            for (; z + 28 < nz; z += 32) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (long long)z * st);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (long long)(z + 4) * st);
+                const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (long long)(z + 8) * st);
+                const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (long long)(z + 12) * st);
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(p + (long long)(z + 16) * st);
+                const f32x4 v5 = *reinterpret_cast<const f32x4*>(p + (long long)(z + 20) * st);
+                const f32x4 v6 = *reinterpret_cast<const f32x4*>(p + (long long)(z + 24) * st);
+                const f32x4 v7 = *reinterpret_cast<const f32x4*>(p + (long long)(z + 28) * st);
+                a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+                a0 += v4; a1 += v5; a2 += v6; a3 += v7;
+            }
+            for (; z + 12 < nz; z += 16) {
                 a0 += *reinterpret_cast<const f32x4*>(p + (long long)z * st);
                 a1 += *reinterpret_cast<const f32x4*>(p + (long long)(z + 4) * st);
                 a2 += *reinterpret_cast<const f32x4*>(p + (long long)(z + 8) * st);

@@ -523,6 +523,40 @@ def _sink_conv_wgrad(w, x, g, geom):
     return True
 
 
+def _sink_conv_wgrad_act(w, b, x, g, y, geom, act, slope):
+    """First-order backward of ``act(conv(x, w) + b)`` for a layer whose input needs no gradient (the critics' first
+    convolution, reference standard_networks.py:62-66), with sinks on: ONE launch (gz_conv2d_wgrad_act_partial) masks
+    ``g`` with the saved output ``y`` on load and leaves weight- and bias-gradient slabs for the flush -- instead of
+    act_bwd + wgrad + slab reduction + channel_sum (+ autograd's accumulation).  ``b`` is the bias Parameter or None.
+    False = not taken."""
+    if not _sinks.enabled or act not in (ACT_RELU, ACT_LRELU) or id(w) in _sinks.deferred:
+        return False
+    for p_ in (w, b):
+        if p_ is None:
+            continue
+        if not isinstance(p_, torch.nn.Parameter) or (p_.numel() & 3):
+            return False
+        if p_.grad is not None and (p_.grad.data_ptr() & 15 or not p_.grad.is_contiguous() or p_.grad.dtype != torch.float32):
+            return False
+    N, C, H, W = x.shape
+    _, K, OH, OW = g.shape
+    shape = (N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride, geom.pad)
+    if not lib.gz_conv2d_wgrad_act_fuses(*shape, act):
+        return False
+    g, y = _req(g), _req(y)
+    nbytes = lib.gz_conv2d_wgrad_workspace_bytes(N, C, H, W, K, OH, OW, geom.kh, geom.kw)
+    ws = _ws(nbytes // 4, x.device)
+    nz, stride, boff = ctypes.c_int(0), ctypes.c_longlong(0), ctypes.c_longlong(0)
+    _timed(2, (N, C, H, W, K, OH, OW), geom, 2.0 * N * OH * OW * K * C * geom.kh * geom.kw, lambda: check(
+        lib.gz_conv2d_wgrad_act_partial(_p(x), _p(g), _p(y), act, float(slope), _p(ws), nbytes, *shape, ctypes.byref(nz),
+                                        ctypes.byref(stride), ctypes.byref(boff), _stream()),
+        "conv2d_wgrad_act_partial"))
+    _sinks.pending.setdefault(id(w), [w, []])[1].append((ws, nz.value, stride.value))
+    if b is not None:
+        _sinks.pending.setdefault(id(b), [b, []])[1].append((ws[boff.value:], nz.value, stride.value))
+    return True
+
+
 def _sink_grad(p, g):
     """A COMPLETE gradient contribution ``g`` of parameter ``p`` (a bias, a Linear weight, a spectral-norm weight_orig):
     queued as a one-slab source and summed with everything else pending by flush_grad_sinks' one launch -- into a fresh
@@ -592,6 +626,9 @@ def flush_grad_sinks(params=None):
         keys = [id(p) for p in params if id(p) in _sinks.pending]
     if not keys:
         return
+    # the gradients with the most slabs first: a 3-channel edge layer's 6144 values come as hundreds of slabs -- a long
+    # chain of dependent loads for a handful of workgroups, which hides behind the bulk only if it starts with it
+    keys.sort(key=lambda k: -sum(nz for (_, nz, _) in _sinks.pending[k][1]))
     max_jobs, max_src = lib.gz_reduce_multi_max_jobs(), lib.gz_reduce_multi_max_sources()
     nb = lib.gz_reduce_multi_table_bytes()
     st = _stream()
@@ -739,6 +776,12 @@ class _ConvF(torch.autograd.Function):
             return (None,) * 7
         x, w, y = ctx.saved_tensors
         geom = ctx.geom
+        if (ctx.act != ACT_NONE and not torch.is_grad_enabled() and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
+                and (not ctx.has_bias or not ctx.needs_input_grad[2] or ctx.bias_ref is not None)):
+            # weights (and bias) only: activation backward, weight gradient and bias gradient in one launch where it exists
+            b = ctx.bias_ref if ctx.has_bias and ctx.needs_input_grad[2] else None
+            if _sink_conv_wgrad_act(w, b, x, gy, y, geom, ctx.act, ctx.slope):
+                return (None,) * 7
         if ctx.act != ACT_NONE:
             gy = _ActBwd.apply(gy, y, ctx.act, ctx.slope)
         if not torch.is_grad_enabled() and _WG_SIDE_FLOPS <= 0:

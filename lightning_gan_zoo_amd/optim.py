@@ -68,6 +68,8 @@ class Adam(torch.optim.Optimizer):
                 self._step_py[id(p)] = k
                 by_step.setdefault(k, []).append((p, srcs))
             for step, items in by_step.items():
+                # most slabs first (see functional.flush_grad_sinks): the edge layers' long slab chains start with the bulk
+                items.sort(key=lambda it: -sum(nz for (_, nz, _) in it[1]))
                 for i in range(0, len(items), max_t):
                     table = (ctypes.c_char * nb)()
                     for p, srcs in items[i:i + max_t]:

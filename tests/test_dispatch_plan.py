@@ -36,9 +36,10 @@ def test_the_heavy_layers_are_on_the_hand_ordered_skeleton():
         assert t[layer + " | F"].startswith("F igemm2<256x128> ConvFwdA2")
         assert t[layer + " | Wg"].startswith("Wg igemm2w<")
     assert t["D.block1 64->128 @32 | Dg"].startswith("Dg igemm2<512x64>")
-    assert t["G.out 128->3 @32->64 (adjoint) | Dg"].startswith("Dg direct dgrad_smallc4_k4s2p1<C=3,KS=1>")
+    assert t["G.out 128->3 @32->64 (adjoint) | Dg"].startswith("Dg direct dgrad_smallc4_k4s2p1<C=3,KS=4>")
     m = golden["dc_gan bs=128 (metric)"]
-    assert m["G.out 128->3 @32->64 (adjoint) | Dg"].startswith("Dg direct dgrad_smallc4_k4s2p1<C=3,KS=4>")
+    assert m["G.out 128->3 @32->64 (adjoint) | Dg"].startswith("Dg direct dgrad_smallc4_k4s2p1<C=3,KS=8>")
+    assert m["D.conv_in 3->64 @64 | Wg"].startswith("Wg direct wgrad_k4s2p1_fewc<mfma16x16x4,C=3,KT=4>")
 
 
 def test_environment_switches_are_ignored_without_gz_experiments():

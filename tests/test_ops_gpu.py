@@ -86,10 +86,13 @@ def test_small_channel_transposed_conv(case):
                TF.conv_transpose2d(gy, w, None, 2, 1)) < TOL
 
 
-@pytest.mark.parametrize("case", [(512, 3, 64, 7), (128, 3, 128, 2), (512, 2, 64, 65), (520, 4, 64, 16), (512, 1, 64, 193)])
+@pytest.mark.parametrize("case", [(512, 3, 64, 7), (128, 3, 128, 2), (512, 2, 64, 65), (520, 4, 64, 16), (512, 1, 64, 193),
+                                  (128, 3, 64, 128), (64, 3, 64, 40), (256, 3, 64, 64), (130, 4, 64, 33), (1100, 3, 64, 16)])
 def test_small_channel_transposed_conv_full_chip(case):
     """The same layer at sizes that give every SIMD >= 2 wavefronts of lane positions (the unsplit channel loop: 256
-    lane positions per workgroup), odd channel counts and a batch that is not a multiple of the workgroup."""
+    lane positions per workgroup), odd channel counts and a batch that is not a multiple of the workgroup; round 5:
+    the benchmarked sizes, where eight (bs <= 128) or four (bs <= 512) wavefronts share the channel loop of 64 lane
+    positions and meet in an LDS tree -- channel counts that are not multiples of the wavefront count included."""
     F = _F()
     N, C, H, K = case
     gy = rnd(N, K, H // 2, H // 2, seed=17)
@@ -99,6 +102,63 @@ def test_small_channel_transposed_conv_full_chip(case):
     ref = torch.tanh(TF.conv_transpose2d(gy, w, b, 2, 1))
     out = F._conv_dgrad_raw(gy.cuda(), w.cuda(), b.cuda(), F.K4S2P1, (H, H), F.ACT_TANH, 0.0)
     assert out.shape == ref.shape and rel(out, ref) < TOL
+
+
+@pytest.mark.parametrize("case", [(16, 3, 64, 64), (20, 4, 64, 128), (16, 1, 64, 16), (33, 2, 64, 32), (128, 3, 64, 128),
+                                  (16, 3, 128, 64), (128, 3, 64, 64)])
+def test_few_channel_k4s2p1_weight_gradient(case):
+    """Weight gradient of the k4 s2 p1 layers with <= 4 image channels (D.conv_in, and G's last layer as its adjoint):
+    the direct 16x16x4-MFMA kernel (k = 4 pixels, one slab per workgroup), reduced by the library and -- the training
+    path -- left as slabs for gz_reduce_multi, against torch."""
+    import ctypes
+    from lightning_gan_zoo_amd._lib import lib
+    F = _F()
+    N, C, H, K = case
+    x = rnd(N, C, H, H, seed=37)
+    gy = rnd(N, K, H // 2, H // 2, seed=38)
+    text = ctypes.create_string_buffer(256)
+    lib.gz_conv2d_plan(2, N, C, H, H, K, H // 2, H // 2, 4, 4, 2, 1, text, 256)
+    direct = K <= 64          # (K = 128, G's last layer as the adjoint, stays on the tile path: no faster in the step)
+    assert text.value.decode().startswith("Wg direct wgrad_k4s2p1_fewc") == direct, text.value
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = torch.nn.grad.conv2d_weight(x, (K, C, 4, 4), gy, stride=2, padding=1)
+    dw = F._conv_wgrad_raw(x.cuda(), gy.cuda(), F.K4S2P1)
+    assert dw.shape == ref.shape and rel(dw, ref) < TOL
+    # the sink route: slabs stay in the workspace, one gz_reduce_multi launch writes the gradient
+    w = torch.nn.Parameter(torch.zeros(K, C, 4, 4, device="cuda"))
+    prev = F.set_grad_sinks(True)
+    try:
+        xin = x.cuda()
+        out = F.conv2d(xin, w, None, F.K4S2P1)
+        out.backward(gy.cuda())
+        F.flush_grad_sinks()
+    finally:
+        F.set_grad_sinks(*prev)
+    assert w.grad is not None and rel(w.grad, ref) < TOL
+    # ... and the layer as the critics use it, LeakyReLU(conv(x) + bias) on an input that needs no gradient: activation
+    # backward, weight gradient and bias gradient in one launch (gz_conv2d_wgrad_act_partial), twice into the same sinks
+    # (a critic applied to a real and a fake batch)
+    # (the reference takes the LeakyReLU decisions of the HIP forward: a pre-activation within rounding of zero may fall on
+    # either side in two implementations, and one flipped element moves a weight gradient by more than 1e-3)
+    w0, b0 = rnd(K, C, 4, 4, seed=39, scale=0.2), rnd(K, seed=40)
+    x2 = rnd(N, C, H, H, seed=41)
+    w, b = torch.nn.Parameter(w0.cuda()), torch.nn.Parameter(b0.cuda())
+    assert bool(lib.gz_conv2d_wgrad_act_fuses(N, C, H, H, K, H // 2, H // 2, 4, 4, 2, 1, F.ACT_LRELU)) == direct
+    dw_ref, db_ref = torch.zeros_like(w0), torch.zeros_like(b0)
+    prev = F.set_grad_sinks(True)
+    try:
+        for xh in (x, x2):
+            out = F.conv2d(xh.cuda(), w, b, F.K4S2P1, F.ACT_LRELU, 0.2)
+            assert rel(out, TF.leaky_relu(TF.conv2d(xh, w0, b0, 2, 1), 0.2)) < TOL
+            out.backward(gy.cuda())
+            g_pre = gy * torch.where(out.detach().cpu() > 0, 1.0, 0.2)
+            dw_ref += torch.nn.grad.conv2d_weight(xh, (K, C, 4, 4), g_pre, stride=2, padding=1)
+            db_ref += g_pre.sum((0, 2, 3))
+        assert not direct or (w.grad is None and b.grad is None)   # nothing went through autograd's accumulation
+        F.flush_grad_sinks()
+    finally:
+        F.set_grad_sinks(*prev)
+    assert rel(w.grad, dw_ref) < TOL and rel(b.grad, db_ref) < TOL
 
 
 @pytest.mark.parametrize("case", [(2, 3, 16, 5), (4, 8, 16, 16), (3, 20, 8, 40), (8, 64, 16, 128), (16, 32, 32, 96),
