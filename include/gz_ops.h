@@ -139,6 +139,12 @@ int gz_conv2d_wgrad_act_partial(const float* x, const float* gy, const float* fw
                                 float* workspace, size_t ws_bytes, int N, int C, int H, int W, int K, int OH, int OW,
                                 int KH, int KW, int S, int P, int* nz_out, long long* stride_out,
                                 long long* bias_offset_out, hipStream_t stream);
+/* ... and the same layer's INPUT gradient (the generator step through the frozen critic): x = conv_transpose(gy *
+ * act'(fwd_out), w) by the direct few-channel kernel with the mask formed on load.  gz_conv2d_dgrad_act_fuses reports
+ * whether the shape takes it (otherwise: gz_act_bwd + gz_conv2d_dgrad); 16-byte aligned tensors, the dgrad weight pack. */
+int gz_conv2d_dgrad_act_fuses(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, int act);
+int gz_conv2d_dgrad_act(const float* gy, const float* fwd_out, int act, float slope, const float* wpack, float* x, int N,
+                        int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream);
 int gz_reduce_multi_max_jobs(void);
 int gz_reduce_multi_max_sources(void);
 size_t gz_reduce_multi_table_bytes(void);

@@ -787,7 +787,11 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void dgrad_smallc4_k4s2p1_k
                                                                    const float* __restrict__ bias,
                                                                    float* __restrict__ x, ConvShape s,
                                                                    FastDiv div_ohw4, FastDiv div_ow4, int act,
-                                                                   float slope) {
+                                                                   float slope, const float* __restrict__ mask = nullptr,
+                                                                   float mask_neg = 0.f) {
+    // mask != nullptr (round 5, the input gradient of `LeakyReLU(conv(.))`): y is the gradient with respect to the
+    // activation's OUTPUT and `mask` the saved forward output, same shape -- y * (mask > 0 ? 1 : mask_neg) is formed on
+    // load (three more 16-byte loads per channel instead of an act_bwd launch: read 2, write 1, read 1 of the tensor)
     constexpr int P = KH == 4 ? 1 : 2, TMAX = (KH + 1) / 2;
     __shared__ float part[KS > 1 ? KS / 2 : 1][KS > 1 ? 16 * C : 1][64];
     const int OW4 = s.OW >> 2, OHW = s.OH * s.OW;
@@ -826,15 +830,18 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void dgrad_smallc4_k4s2p1_k
     // nothing else covers the load latency; G's last layer at bs 128: 56 us with the loads issued in place)
     // (the 256-position form, KS = 1, runs 4-7 wavefronts per SIMD and keeps its loads in place: with the prefetch's 26
     // extra registers it measured 80 -> 110 us at bs 256 and 113 -> 133 us at bs 512)
-    f32x4 nxt[3];
+    const __amdgpu_buffer_rsrc_t rmask = make_rsrc(mask ? mask : y, (uint32_t)s.N * s.K * OHW * 4u);
+    f32x4 nxt[3], mnx[3];
     if constexpr (KS > 1) {
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int dy = 0; dy < 3; ++dy) {
             nxt[dy] = bload4(rsrc, wave < s.K ? voff[dy] : OOB, (uint32_t)wave * (uint32_t)OHW * 4u);
+            if (mask) mnx[dy] = bload4(rmask, wave < s.K ? voff[dy] : OOB, (uint32_t)wave * (uint32_t)OHW * 4u);
+        }
     }
     for (int ko = wave; ko < s.K; ko += KS) {
         float v[3][6];
-        f32x4 cur[3];
+        f32x4 cur[3], mcur[3];
         if constexpr (KS > 1) {
             const bool more = ko + KS < s.K;
             const uint32_t soff = (uint32_t)(more ? ko + KS : ko) * (uint32_t)OHW * 4u;
@@ -842,10 +849,23 @@ __global__ __launch_bounds__(KS > 4 ? 64 * KS : 256) void dgrad_smallc4_k4s2p1_k
             for (int dy = 0; dy < 3; ++dy) {
                 cur[dy] = nxt[dy];
                 nxt[dy] = bload4(rsrc, more ? voff[dy] : OOB, soff);
+                if (mask) {
+                    mcur[dy] = mnx[dy];
+                    mnx[dy] = bload4(rmask, more ? voff[dy] : OOB, soff);
+                }
             }
         } else {
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) cur[dy] = bload4(rsrc, voff[dy], (uint32_t)ko * (uint32_t)OHW * 4u);
+            for (int dy = 0; dy < 3; ++dy) {
+                cur[dy] = bload4(rsrc, voff[dy], (uint32_t)ko * (uint32_t)OHW * 4u);
+                if (mask) mcur[dy] = bload4(rmask, voff[dy], (uint32_t)ko * (uint32_t)OHW * 4u);
+            }
+        }
+        if (mask) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cur[dy][e] = mcur[dy][e] > 0.f ? cur[dy][e] : cur[dy][e] * mask_neg;
         }
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
@@ -980,19 +1000,22 @@ static int run_dgrad_smallc5(const float* y, const float* wp, const float* bias,
     const int ks = smallc_split(M4, s.K);
     if (ks == 8)
         hipLaunchKernelGGL((dgrad_smallc4_k4s2p1_kernel<C, 8, 5>), dim3((unsigned)((M4 + 63) / 64)), dim3(512), 0, st, y, wp,
-                           bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope);
+                           bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope,
+                           (const float*)nullptr, 0.f);
     else if (ks == 4)
         hipLaunchKernelGGL((dgrad_smallc4_k4s2p1_kernel<C, 4, 5>), dim3((unsigned)((M4 + 63) / 64)), dim3(256), 0, st, y, wp,
-                           bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope);
+                           bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope,
+                           (const float*)nullptr, 0.f);
     else
         hipLaunchKernelGGL((dgrad_smallc4_k4s2p1_kernel<C, 1, 5>), dim3((unsigned)((M4 + 255) / 256)), dim3(256), 0, st, y,
-                           wp, bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope);
+                           wp, bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope,
+                           (const float*)nullptr, 0.f);
     return launch_status();
 }
 
 template <int C>
 static int run_dgrad_smallc(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s, int act,
-                            float slope, hipStream_t st) {
+                            float slope, hipStream_t st, const float* mask = nullptr, float mask_neg = 0.f) {
     long long M = (long long)s.N * s.OH * s.OW;
     const bool one_pos = knobs().smallc_one_pos;          // experiment: the round-1 kernel
     // a row of OW/4 lanes must not straddle two wavefronts (the halo columns come from the neighbour LANES)
@@ -1005,15 +1028,19 @@ static int run_dgrad_smallc(const float* y, const float* wp, const float* bias, 
         const int ks = smallc_split(M4, s.K);
         if (ks == 8)
             hipLaunchKernelGGL((dgrad_smallc4_k4s2p1_kernel<C, 8>), dim3((unsigned)((M4 + 63) / 64)), dim3(512), 0, st, y,
-                               wp, bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope);
+                               wp, bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope, mask,
+                               mask_neg);
         else if (ks == 4)
             hipLaunchKernelGGL((dgrad_smallc4_k4s2p1_kernel<C, 4>), dim3((unsigned)((M4 + 63) / 64)), dim3(256), 0, st, y,
-                               wp, bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope);
+                               wp, bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope, mask,
+                               mask_neg);
         else
             hipLaunchKernelGGL((dgrad_smallc4_k4s2p1_kernel<C, 1>), dim3((unsigned)((M4 + 255) / 256)), dim3(256), 0, st,
-                               y, wp, bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope);
+                               y, wp, bias, x, s, make_fastdiv(s.OH * (s.OW / 4)), make_fastdiv(s.OW / 4), act, slope, mask,
+                               mask_neg);
         return launch_status();
     }
+    if (mask) return GZ_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(dgrad_smallc_k4s2p1_kernel<C>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, y, wp, bias,
                        x, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW), act, slope);
     return launch_status();
@@ -2533,10 +2560,37 @@ int gz_conv2d_wgrad_partial(const float* x, const float* y, float* dw, float* wo
     return rc;
 }
 
+static bool dgrad_act_direct(const ConvShape& s, int KH, int KW, int S, int P, int act) {
+    return KH == 4 && KW == 4 && S == 2 && P == 1 && (act == ACT_RELU || act == ACT_LRELU) && !knobs().smallc_one_pos &&
+           !knobs().no_act_fuse && dgrad_direct<G4421>(nullptr, s) && s.OW % 4 == 0 && 64 % (s.OW / 4) == 0;
+}
+
+int gz_conv2d_dgrad_act_fuses(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, int act) {
+    ConvShape s{N, C, H, W, K, OH, OW};
+    return shape_ok(s, KH, KW, S, P) && dgrad_act_direct(s, KH, KW, S, P, act) ? 1 : 0;
+}
+
+int gz_conv2d_dgrad_act(const float* gy, const float* fwd_out, int act, float slope, const float* wpack, float* x, int N,
+                        int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, hipStream_t stream) {
+    gz::clear_stale_error();
+    ConvShape s{N, C, H, W, K, OH, OW};
+    if (!gy || !fwd_out || !wpack || !x || !shape_ok(s, KH, KW, S, P)) return GZ_ERR_BAD_SHAPE;
+    if (too_large((long long)N * C * H * W) || too_large((long long)N * K * OH * OW)) return GZ_ERR_TOO_LARGE;
+    if (!dgrad_act_direct(s, KH, KW, S, P, act) || (((uintptr_t)gy | (uintptr_t)x | (uintptr_t)fwd_out | (uintptr_t)wpack) & 15))
+        return GZ_ERR_UNSUPPORTED;
+    const float neg = act == ACT_RELU ? 0.f : slope;
+    switch (C) {
+        case 1: return run_dgrad_smallc<1>(gy, wpack, nullptr, x, s, ACT_NONE, 0.f, stream, fwd_out, neg);
+        case 2: return run_dgrad_smallc<2>(gy, wpack, nullptr, x, s, ACT_NONE, 0.f, stream, fwd_out, neg);
+        case 3: return run_dgrad_smallc<3>(gy, wpack, nullptr, x, s, ACT_NONE, 0.f, stream, fwd_out, neg);
+        default: return run_dgrad_smallc<4>(gy, wpack, nullptr, x, s, ACT_NONE, 0.f, stream, fwd_out, neg);
+    }
+}
+
 int gz_conv2d_wgrad_act_fuses(int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int S, int P, int act) {
     ConvShape s{N, C, H, W, K, OH, OW};
     return shape_ok(s, KH, KW, S, P) && KH == 4 && KW == 4 && S == 2 && P == 1 && (act == ACT_RELU || act == ACT_LRELU) &&
-                   wgrad_k4s2p1_fewc_ok(s) ? 1 : 0;
+                   !knobs().no_act_fuse && wgrad_k4s2p1_fewc_ok(s) ? 1 : 0;
 }
 
 int gz_conv2d_wgrad_act_partial(const float* x, const float* gy, const float* fwd_out, int act, float slope,

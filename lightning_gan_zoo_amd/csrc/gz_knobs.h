@@ -56,6 +56,7 @@ namespace gz {
     X(long long, smallc_split8_below, "GZ_SMALLC_SPLIT8_BELOW", 36 * 1024)                                            \
     X(int, smallc_ks, "GZ_SMALLC_KS", 0)                                                                              \
     X(bool, no_fewc_wg, "GZ_NO_FEWC_WG", false)                                                                       \
+    X(bool, no_act_fuse, "GZ_NO_ACT_FUSE", false)                                                                     \
     X(int, fewc_wg_blocks, "GZ_FEWC_WG_BLOCKS", 256)                                                                  \
     X(bool, no_smallch_conv, "GZ_NO_SMALLCH_CONV", false)                                                             \
     X(bool, no_smallch_wg, "GZ_NO_SMALLCH_WG", false)                                                                 \

@@ -355,6 +355,25 @@ def _conv_dgrad_raw(g, w, bias, geom, hw, act, slope):
     return x
 
 
+def _conv_dgrad_act_raw(g, y, act, slope, w, geom, hw):
+    """Input gradient of ``act(conv(x, w))`` from the gradient ``g`` w.r.t. the activation's output and the saved output
+    ``y``, the mask formed on load (gz_conv2d_dgrad_act); None when the shape does not take the fused kernel."""
+    N, K, OH, OW = g.shape
+    C = w.shape[1]
+    H, W = hw
+    shape = (N, C, H, W, K, OH, OW, geom.kh, geom.kw, geom.stride, geom.pad)
+    if not lib.gz_conv2d_dgrad_act_fuses(*shape, act):
+        return None
+    g, y = _req(g), _req(y)
+    wp = _packed(w, "d", geom)
+    x = torch.empty((N, C, H, W), device=g.device, dtype=torch.float32)
+    if (g.data_ptr() | y.data_ptr() | x.data_ptr() | wp.data_ptr()) & 15:
+        return None
+    _timed(1, (N, C, H, W, K, OH, OW), geom, 2.0 * N * OH * OW * K * C * geom.kh * geom.kw, lambda: check(
+        lib.gz_conv2d_dgrad_act(_p(g), _p(y), act, float(slope), _p(wp), _p(x), *shape, _stream()), "conv2d_dgrad_act"))
+    return x
+
+
 def _channel_sum_raw(g):
     """g.sum over every dimension but the channel (the bias gradient of a convolution), no autograd."""
     g = _req(g)
@@ -782,6 +801,12 @@ class _ConvF(torch.autograd.Function):
             b = ctx.bias_ref if ctx.has_bias and ctx.needs_input_grad[2] else None
             if _sink_conv_wgrad_act(w, b, x, gy, y, geom, ctx.act, ctx.slope):
                 return (None,) * 7
+        if (ctx.act in (ACT_RELU, ACT_LRELU) and not torch.is_grad_enabled() and ctx.needs_input_grad[0]
+                and not ctx.needs_input_grad[1] and not (ctx.has_bias and ctx.needs_input_grad[2])):
+            # input only (a generator step through the frozen critic's first layer): the mask is formed on load
+            dx = _conv_dgrad_act_raw(gy, y, ctx.act, ctx.slope, w, geom, tuple(x.shape[2:]))
+            if dx is not None:
+                return (dx,) + (None,) * 6
         if ctx.act != ACT_NONE:
             gy = _ActBwd.apply(gy, y, ctx.act, ctx.slope)
         if not torch.is_grad_enabled() and _WG_SIDE_FLOPS <= 0:

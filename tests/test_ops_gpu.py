@@ -86,6 +86,29 @@ def test_small_channel_transposed_conv(case):
                TF.conv_transpose2d(gy, w, None, 2, 1)) < TOL
 
 
+@pytest.mark.parametrize("case", [(4, 3, 64, 16), (128, 3, 64, 64), (256, 3, 64, 64), (1100, 3, 64, 16), (3, 4, 32, 40)])
+@pytest.mark.parametrize("act", ["relu", "lrelu"])
+def test_input_gradient_through_a_fused_activation(case, act):
+    """d/dx of ``act(conv(x, w) + b)`` for the critics' first layer with frozen weights (the generator step): the direct
+    few-channel kernel masks the incoming gradient with the saved output on load (gz_conv2d_dgrad_act) -- every
+    wavefront split of the channel loop (1 / 4 / 8), against act_bwd followed by the plain transposed convolution."""
+    F = _F()
+    N, C, H, K = case
+    A, slope = (F.ACT_RELU, 0.0) if act == "relu" else (F.ACT_LRELU, 0.2)
+    x = rnd(N, C, H, H, seed=47).cuda().requires_grad_()
+    w, b = rnd(K, C, 4, 4, seed=48, scale=0.2).cuda(), rnd(K, seed=49).cuda()
+    gy = rnd(N, K, H // 2, H // 2, seed=50).cuda()
+    from lightning_gan_zoo_amd._lib import lib
+    assert lib.gz_conv2d_dgrad_act_fuses(N, C, H, H, K, H // 2, H // 2, 4, 4, 2, 1, A)
+    y = F.conv2d(x, w, b, F.K4S2P1, A, slope)
+    y.backward(gy)
+    g_pre = F._act_bwd_raw(gy, y.detach(), A, slope)
+    ref = F._conv_dgrad_raw(g_pre, w, None, F.K4S2P1, (H, H), F.ACT_NONE, 0.0)
+    assert x.grad.shape == ref.shape and rel(x.grad, ref) < 1e-5
+    t = TF.conv_transpose2d(g_pre.cpu(), w.cpu(), None, 2, 1)
+    assert rel(x.grad, t) < TOL
+
+
 @pytest.mark.parametrize("case", [(512, 3, 64, 7), (128, 3, 128, 2), (512, 2, 64, 65), (520, 4, 64, 16), (512, 1, 64, 193),
                                   (128, 3, 64, 128), (64, 3, 64, 40), (256, 3, 64, 64), (130, 4, 64, 33), (1100, 3, 64, 16)])
 def test_small_channel_transposed_conv_full_chip(case):
