@@ -263,6 +263,36 @@ __device__ __forceinline__ void pack_dgrad_body(const float* __restrict__ w, flo
         dst[((long long)K * taps + (long long)ko * pad) * ldc + i] = 0.f;
 }
 
+// The k4 s2 p1 case of the same image (every DCGAN layer), one workgroup per ko and ALL four phases (round 5): the body
+// above reads w[ko][c][ky][kx] along c -- a 64-byte stride, one 64-byte segment per lane and load -- once per phase.
+// Here the C x 16 values of the ko are read once, contiguously (16-byte loads), turned in LDS 64 channels at a time,
+// and leave as the sixteen (phase, tap) rows with 16-byte stores.  Same bytes out, bit for bit.
+__device__ __forceinline__ void pack_dgrad_k4_body(const float* __restrict__ w, float* __restrict__ wp, int K, int C,
+                                                   int ldc, int ko, float scale = 1.f) {
+    __shared__ float tile[64][17];
+    const int t = threadIdx.x;
+    const int r = t >> 4, cs = (t & 15) * 4;                  // output row (ky, kx) and channel quad of this thread
+    const int ky = r >> 2, kx = r & 3;
+    const int phase = ((ky + 1) & 1) * 2 + ((kx + 1) & 1), tap = (ky >> 1) * 2 + (kx >> 1);
+    float* dst = wp + (((long long)phase * K + ko) * 4 + tap) * ldc;
+    const float* src = w + (long long)ko * C * 16;
+    for (int c0 = 0; c0 < ldc; c0 += 64) {
+        const int c = c0 + (t >> 2), e = (t & 3) * 4;         // this thread's 4 consecutive (ky, kx) values of channel c
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < C) v = *reinterpret_cast<const f32x4*>(src + (long long)c * 16 + e);
+        __syncthreads();
+        tile[t >> 2][e + 0] = v.x * scale;
+        tile[t >> 2][e + 1] = v.y * scale;
+        tile[t >> 2][e + 2] = v.z * scale;
+        tile[t >> 2][e + 3] = v.w * scale;
+        __syncthreads();
+        if (c0 + cs < ldc) {
+            f32x4 o = {tile[cs][r], tile[cs + 1][r], tile[cs + 2][r], tile[cs + 3][r]};
+            *reinterpret_cast<f32x4*>(dst + c0 + cs) = o;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp,
                                                          int K, int C, int KH, int KW, int S, int P, int TY,
                                                          int TX, int ldc) {
@@ -290,6 +320,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
         case 0: transpose_pad_body(jb.w, jb.wp, jb.K, jb.C * jb.KH * jb.KW, round4(jb.K), bx, by); break;
         case 1: pack_fwd_tap_body(jb.w, jb.wp, jb.K, jb.C, jb.KH * jb.KW, round_bk(jb.C), round4(jb.K), bx, jb.gx); break;
         case 2: pack_dgrad_body(jb.w, jb.wp, jb.K, jb.C, jb.KH, jb.KW, jb.S, jb.P, TY, TX, round4(jb.C), bx, by); break;
+        case 5: pack_dgrad_k4_body(jb.w, jb.wp, jb.K, jb.C, round4(jb.C), bx); break;
         default:
             pack_dgrad_tap_body(jb.w, jb.wp, jb.K, jb.C, jb.KH, jb.KW, jb.S, jb.P, TY, TX, round_bk(jb.K), round4(jb.C), bx,
                                 by, jb.gx);
@@ -328,6 +359,7 @@ __global__ __launch_bounds__(256) void pack_table_kernel(PackTable t) {
             pack_dgrad_tap_body(jb.w, jb.wp, jb.K, jb.C, jb.KH, jb.KW, jb.S, jb.P, TY, TX, round_bk(jb.K), round4(jb.C), bx,
                                 by, jb.gx, scale);
             break;
+        case 5: pack_dgrad_k4_body(jb.w, jb.wp, jb.K, jb.C, round4(jb.C), bx, scale); break;
         default: {      // 4: wp = w * scale, same layout
             const long long total = (long long)jb.K * jb.C * jb.KH * jb.KW;
             for (long long i = (long long)bx * 256 + threadIdx.x; i < total; i += (long long)jb.gx * 256)
@@ -2387,6 +2419,10 @@ int gz_conv2d_pack_job(void* job_out, const float* w, float* wp, int is_dgrad, i
         jb.kind = 3;
         jb.gx = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
         jb.gy = S * S;
+    } else if (KH == 4 && KW == 4 && S == 2 && P == 1 && !knobs().no_pack_k4 && (((uintptr_t)w | (uintptr_t)wp) & 15) == 0) {
+        jb.kind = 5;          // the whole ko in one workgroup, contiguous reads (pack_dgrad_k4_body)
+        jb.gx = K;
+        jb.gy = 1;
     } else {
         jb.kind = 2;
         jb.gx = K;

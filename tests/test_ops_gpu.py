@@ -1153,8 +1153,10 @@ def test_group_repack_equals_single_packs():
     per-image pack launches write: all four layouts (forward / transposed, reduction in (c, tap) or tap-major order)."""
     F = _F()
     F.set_pack_cache(True)       # (a GraphedTrainer test that ran earlier in the process leaves the cache off)
-    geoms = [F.K4S2P1, F.Geom(5, 5, 2, 2), F.Geom(3, 3, 1, 1), F.Geom(5, 5, 2, 2)]
-    shapes = [(24, 12, 4, 4), (40, 32, 5, 5), (16, 20, 3, 3), (6, 3, 5, 5)]
+    geoms = [F.K4S2P1, F.Geom(5, 5, 2, 2), F.Geom(3, 3, 1, 1), F.Geom(5, 5, 2, 2), F.K4S2P1, F.K4S2P1]
+    # (the k4 s2 p1 transposed image has a group-launch body of its own, 64 channels per LDS pass: 70 -> two passes and a
+    # padded tail, 3 -> one partial quad)
+    shapes = [(24, 12, 4, 4), (40, 32, 5, 5), (16, 20, 3, 3), (6, 3, 5, 5), (130, 70, 4, 4), (64, 3, 4, 4)]
     ws = [torch.nn.Parameter(rnd(*s, seed=300 + i).cuda()) for i, s in enumerate(shapes)]
     F.register_pack_group(ws)
     first = [(F._packed(w, "f", g), F._packed(w, "d", g)) for w, g in zip(ws, geoms)]       # single launches
