@@ -179,6 +179,7 @@ class Trainer:
         self.epoch_batch_idx = 0          # batch index inside the epoch: selects the stepping batches
         self.epoch = 0
         self.accumulate_grad_batches = accumulate_grad_batches
+        self._ones = {}
         # weight gradients straight into p.grad (functional.set_grad_sinks): on for the duration of each step on the
         # GPU path -- ONE slab-reduction launch per backward pass (per gradient bucket under data parallelism) instead
         # of one per layer plus autograd's `grad += new` launches
@@ -206,7 +207,14 @@ class Trainer:
         taken = None
         try:
             loss = m.training_step(batch, self.batch_idx, idx)
-            (loss if factor == 1 else loss / factor).backward()
+            if factor == 1 and loss.dim() == 0 and loss.is_cuda:
+                # d loss / d loss from a cached one: autograd otherwise fills a fresh scalar per backward (a launch each)
+                one = self._ones.get((loss.device, loss.dtype))
+                if one is None:
+                    one = self._ones[(loss.device, loss.dtype)] = torch.ones((), device=loss.device, dtype=loss.dtype)
+                loss.backward(gradient=one)
+            else:
+                (loss if factor == 1 else loss / factor).backward()
             if self.grad_sync is not None:
                 # still inside the sink region: GradSync sums the slabs bucket by bucket, runs the weight-gradient
                 # launches it postponed (deferred tail) and issues what the backward hooks have not issued yet
