@@ -144,8 +144,8 @@ class Generator(nn.Module):
         return view
 
     def prefetch_view(self, batch_size):
-        """Draw and invert the NEXT forward's view matrices now (harness.Trainer calls this at the end of a step, with
-        the whole backward pass still queued on the GPU): the ~0.3 ms of small host operations otherwise sit at the top
+        """Draw and invert the NEXT forward's view matrices now (harness.Trainer calls this right after a step's
+        training_step, with that forward still queued on the GPU): the ~0.5 ms of small host operations otherwise sit at the top
         of the next forward, where the queue holds only the first few small kernels and runs dry (0.13 ms idle per
         forward in the kernel trace, three forwards per optimizer cycle).  numpy's stream is consumed in the same order
         -- one draw per forward -- and the draw is provisional: if anything touches numpy's generator before the next

@@ -207,6 +207,14 @@ class Trainer:
         taken = None
         try:
             loss = m.training_step(batch, self.batch_idx, idx)
+            gen = getattr(m, "generator", None)
+            if F is not None and hasattr(gen, "prefetch_view") and torch.is_tensor(batch[0]):
+                # HoloGAN: the NEXT forward's view matrices (0.4-0.5 ms of numpy on the host) now, with this step's whole
+                # forward queued on the GPU.  (First placed at the END of the step; the kernel trace shows 0.2 ms idle at
+                # every step boundary there -- under the profiler only: unprofiled the host is 7 ms per cycle ahead and
+                # both placements measure 17.50 ms, tools/boundary_probe.py / tools/ab_expt.sh.  Kept here, where it
+                # cannot land in front of an empty queue.)
+                gen.prefetch_view(len(batch[0]))
             if factor == 1 and loss.dim() == 0 and loss.is_cuda:
                 # d loss / d loss from a cached one: autograd otherwise fills a fresh scalar per backward (a launch each)
                 one = self._ones.get((loss.device, loss.dtype))
@@ -237,9 +245,6 @@ class Trainer:
             else:
                 opt.step()
             opt.zero_grad(set_to_none=True)
-        gen = getattr(m, "generator", None)
-        if self._F is not None and hasattr(gen, "prefetch_view") and torch.is_tensor(batch[0]):
-            gen.prefetch_view(len(batch[0]))       # HoloGAN: the next forward's view matrices, while the GPU is busy
         self.batch_idx += 1
         self.epoch_batch_idx += 1
         return loss.detach(), idx
