@@ -535,8 +535,8 @@ static int run_fwd2(const float* x, const float* wp, const float* bias, float* y
 
 // any other geometry whose reduction is tap-major (5x5 s2 p2, 3x3 s1 p1, 1x1 ...): gather loader, 4-byte LDS-DMA
 template <class G, class Cfg>
-static int run_fwdtap2(const float* x, const float* wp, const float* bias, float* y, const ConvShape& s, int act,
-                       float slope, hipStream_t st, int splits, float* slab, float* stats) {
+static int run_fwdtap2_impl(const float* x, const float* wp, const float* bias, float* y, const ConvShape& s, int act,
+                            float slope, hipStream_t st, int splits, float* slab, float* stats) {
     using AL = ConvTapA2<Cfg::BM, G::kh, G::kw, G::s, G::p>;
     using BL = MContigB2<Cfg::BN>;
     typename AL::Params pa{x, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW)};
@@ -554,6 +554,19 @@ static int run_fwdtap2(const float* x, const float* wp, const float* bias, float
         }
     }
     return launch_igemm2<Cfg, AL, BL, EpiNCHWB>(pa, pb, pe, M, s.K, Kt, 1, splits, st, slab);
+}
+
+// k4 s2 p1 has loaders of its own (ConvFwdA2 / ConvDgA2) and the planners never pair it with the gather loaders
+// (fwdtap2_plan / dgradtap2_plan return "not applicable" for it): not instantiating them for that geometry takes eight
+// never-launched kernels out of the library (round 5, tools/kernel_reach.sh).
+template <class G>
+constexpr bool has_own_igemm2_loaders() { return G::kh == 4 && G::kw == 4 && G::s == 2 && G::p == 1; }
+
+template <class G, class Cfg>
+static int run_fwdtap2(const float* x, const float* wp, const float* bias, float* y, const ConvShape& s, int act,
+                       float slope, hipStream_t st, int splits, float* slab, float* stats) {
+    if constexpr (has_own_igemm2_loaders<G>()) return GZ_ERR_UNSUPPORTED;
+    else return run_fwdtap2_impl<G, Cfg>(x, wp, bias, y, s, act, slope, st, splits, slab, stats);
 }
 
 template <class Cfg>
@@ -1151,8 +1164,8 @@ static int run_dgrad2(const float* y, const float* wp, const float* bias, float*
 // taps): gather loader with 4-byte LDS-DMA; the reduction is cut into pieces of ~48 chunks so that the phases'
 // workgroups balance (unsplit, the 9-tap phase's workgroups would run 2.25x longer than the 4-tap phase's)
 template <class G, class Cfg>
-static int run_dgradtap2(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s, int act,
-                         float slope, hipStream_t st, int splits, float* slab) {
+static int run_dgradtap2_impl(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s, int act,
+                              float slope, hipStream_t st, int splits, float* slab) {
     using AL = ConvDgTapA2<Cfg::BM, G::kh, G::kw, G::s, G::p>;
     using BL = MContigB2<Cfg::BN>;
     using Epi = EpiPhaseB<G::s>;
@@ -1178,6 +1191,13 @@ static int run_dgradtap2(const float* y, const float* wp, const float* bias, flo
         }
     }
     return launch_igemm2<Cfg, AL, BL, Epi>(pa, pb, pe, M, s.C, Kt, G::s * G::s, splits, st, slab, pc);
+}
+
+template <class G, class Cfg>
+static int run_dgradtap2(const float* y, const float* wp, const float* bias, float* x, const ConvShape& s, int act,
+                         float slope, hipStream_t st, int splits, float* slab) {
+    if constexpr (has_own_igemm2_loaders<G>()) return GZ_ERR_UNSUPPORTED;     // (see run_fwdtap2)
+    else return run_dgradtap2_impl<G, Cfg>(y, wp, bias, x, s, act, slope, st, splits, slab);
 }
 
 template <class G>

@@ -42,6 +42,12 @@ CONV_CASES = [
     (8, 64, 16, 128),     # 128-wide N
     (16, 32, 32, 96),     # larger M, ragged N tile (96)
     (64, 16, 32, 256),    # >= 256 tiles of 128x128
+    # round 5 (tools/kernel_reach.sh: no test reached the generic weight-gradient loaders -- every case above has feature
+    # rows of 4, 8, 16 or 32 pixels, which the row-aligned loaders take): feature rows that neither divide nor are
+    # multiples of 16
+    (3, 6, 12, 10),       # rows of 6 (s2) / 12 (s1) pixels
+    (2, 5, 20, 7),        # rows of 10 / 20
+    (2, 4, 40, 72),       # rows of 20 / 40, 72 output channels
 ]
 
 
