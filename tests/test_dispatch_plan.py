@@ -56,3 +56,24 @@ def test_environment_switches_are_ignored_without_gz_experiments():
     assert plain.returncode == 0 and forced.returncode == 0, plain.stderr + forced.stderr
     assert "igemm2<256x128>" in plain.stdout, plain.stdout
     assert "igemm2" not in forced.stdout and "igemm<" in forced.stdout, forced.stdout
+
+
+def test_the_critics_first_layer_takes_the_fused_backward_at_every_baseline_batch():
+    """Round 5: `LeakyReLU(conv(x) + b)` of the critics' first layer (reference standard_networks.py:62-66) has a one-launch
+    first-order backward in the D step (gz_conv2d_wgrad_act_partial) and forms the activation mask on load in the G step
+    (gz_conv2d_dgrad_act).  Pure host predicates: they must say yes for every BASELINE batch size (and the stacked
+    2 x batch pass), for ReLU / LeakyReLU only, and no for the shapes the direct kernels do not take."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from lightning_gan_zoo_amd import functional as F
+    from lightning_gan_zoo_amd._lib import lib
+    for n in (64, 128, 256, 512, 1024):
+        shape = (n, 3, 64, 64, 64, 32, 32, 4, 4, 2, 1)
+        assert lib.gz_conv2d_wgrad_act_fuses(*shape, F.ACT_LRELU) == 1, n
+        assert lib.gz_conv2d_wgrad_act_fuses(*shape, F.ACT_RELU) == 1, n
+        assert lib.gz_conv2d_dgrad_act_fuses(*shape, F.ACT_LRELU) == 1, n
+        assert lib.gz_conv2d_wgrad_act_fuses(*shape, F.ACT_TANH) == 0 and lib.gz_conv2d_dgrad_act_fuses(*shape, F.ACT_NONE) == 0
+    assert lib.gz_conv2d_wgrad_act_fuses(4, 3, 64, 64, 64, 32, 32, 4, 4, 2, 1, F.ACT_LRELU) == 0      # too few row segments
+    assert lib.gz_conv2d_wgrad_act_fuses(128, 3, 64, 64, 128, 32, 32, 4, 4, 2, 1, F.ACT_LRELU) == 0   # 128 channels: tile path
+    assert lib.gz_conv2d_wgrad_act_fuses(128, 64, 32, 32, 128, 16, 16, 4, 4, 2, 1, F.ACT_LRELU) == 0  # not an image layer
+    assert lib.gz_conv2d_dgrad_act_fuses(128, 64, 32, 32, 128, 16, 16, 4, 4, 2, 1, F.ACT_LRELU) == 0
+    assert lib.gz_conv2d_dgrad_act_fuses(128, 3, 64, 64, 64, 32, 32, 5, 5, 2, 2, F.ACT_LRELU) == 0    # HoloGAN's k5: unfused
