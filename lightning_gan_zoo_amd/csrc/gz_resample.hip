@@ -20,6 +20,22 @@ struct Corner8 {
     float w[8];
 };
 
+// LDS placement of voxel e = (a * S + b) * S + c of a volume staged as [S^3][4 floats] (round 5).  A 16-byte element's
+// bank group is e & 7 -- the low bits of the INNERMOST coordinate alone -- so a wavefront whose gathered voxels differ
+// mostly in the outer coordinates (a view rotated by ~90 degrees maps an output row onto a source column) hits one bank
+// group 16 times over.  XOR-ing those three bits with the low bits of a ^ b spreads any axis-aligned run over all
+// eight groups; sh = log2(S) for power-of-two S >= 8, 0 = plain placement.
+__device__ __forceinline__ int lds_slot(int e, int sh) {
+    return sh ? e ^ (((e >> (2 * sh)) ^ (e >> sh)) & 7) : e;
+}
+
+static int swizzle_shift(int S) {
+    if (knobs().no_resample_swizzle || S < 8 || (S & (S - 1))) return 0;
+    int sh = 0;
+    while ((1 << sh) < S) ++sh;
+    return sh;
+}
+
 // minv: row-major 4x4 (already inverted on the host side exactly as the reference does)
 __device__ __forceinline__ Corner8 corners(const float* __restrict__ m, int x, int y, int z, int S) {
     const float fx = (float)x, fy = (float)y, fz = (float)z;
@@ -88,7 +104,8 @@ constexpr int FW_LC = 4;
 
 __global__ __launch_bounds__(RS_THREADS) void resample_fwd_staged_kernel(const float* __restrict__ vox,
                                                                          const float* __restrict__ minv,
-                                                                         float* __restrict__ out, int N, int C, int S) {
+                                                                         float* __restrict__ out, int N, int C, int S,
+                                                                         int sh) {
     // [S^3][FW_LC], channels interleaved (round 4): a corner's FW_LC channel values are ONE 16-byte LDS read instead of
     // FW_LC scattered 4-byte ones -- the gathers' bank conflicts, not HBM, set this kernel's pace (111 us for 134 MB)
     static_assert(FW_LC == 4, "one f32x4 per corner");
@@ -101,10 +118,10 @@ __global__ __launch_bounds__(RS_THREADS) void resample_fwd_staged_kernel(const f
     for (int i = threadIdx.x * 4; i < FW_LC * S3; i += RS_THREADS * 4) {
         const int j = i / S3, u = i - j * S3;            // (S^3 is a multiple of 4: a float4 stays inside one channel)
         const f32x4 v = j < lc ? *reinterpret_cast<const f32x4*>(src + i) : f32x4{0.f, 0.f, 0.f, 0.f};
-        vl[(u + 0) * FW_LC + j] = v[0];
-        vl[(u + 1) * FW_LC + j] = v[1];
-        vl[(u + 2) * FW_LC + j] = v[2];
-        vl[(u + 3) * FW_LC + j] = v[3];
+        vl[lds_slot(u + 0, sh) * FW_LC + j] = v[0];
+        vl[lds_slot(u + 1, sh) * FW_LC + j] = v[1];
+        vl[lds_slot(u + 2, sh) * FW_LC + j] = v[2];
+        vl[lds_slot(u + 3, sh) * FW_LC + j] = v[3];
     }
     __syncthreads();
     const float* m = minv + n * 16;
@@ -112,9 +129,9 @@ __global__ __launch_bounds__(RS_THREADS) void resample_fwd_staged_kernel(const f
     for (int r = threadIdx.x; r < S3; r += RS_THREADS) {
         const int z = r / (S * S), y = (r / S) % S, x = r % S;
         Corner8 cn = corners(m, x, y, z, S);
-        f32x4 acc = vq[cn.off[0]] * cn.w[0];
+        f32x4 acc = vq[lds_slot(cn.off[0], sh)] * cn.w[0];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) acc = acc + vq[cn.off[k]] * cn.w[k];       // same order as resample_fwd_kernel
+        for (int k = 1; k < 8; ++k) acc = acc + vq[lds_slot(cn.off[k], sh)] * cn.w[k];   // same order as resample_fwd_kernel
 #pragma unroll
         for (int j = 0; j < FW_LC; ++j)
             if (j < lc) out[(((long long)n * C * S + (long long)(c0 + j) * S + (S - 1 - y)) * S + z) * S + x] = acc[j];
@@ -326,11 +343,14 @@ __global__ __launch_bounds__(RS_THREADS) void resample_bwd_staged_kernel(const f
                                                                          const int* __restrict__ hoff,
                                                                          const float* __restrict__ hw,
                                                                          const int* __restrict__ overflow,
-                                                                         float* __restrict__ gvox, int N, int C, int S) {
+                                                                         float* __restrict__ gvox, int N, int C, int S,
+                                                                         int sh) {
     static_assert(LC == 4, "one f32x4 per hit");
     extern __shared__ __attribute__((aligned(16))) float gl[];      // [S^3][LC], channels interleaved (see the forward)
     if (*overflow) return;                 // the launcher re-runs this gradient with the gather kernel
     const int S3 = S * S * S;
+    // (Tried, round 5: an XCD-aware block order that sends all sixteen channel groups of a sample to one XCD so that the
+    // sample's 278 KB of hit lists stay in that L2 -- 100 -> 105 us: the lists already come out of the last-level cache.)
     const int n = blockIdx.x;
     const int c0 = blockIdx.y * LC;
     const int lc = min(LC, C - c0);
@@ -338,28 +358,63 @@ __global__ __launch_bounds__(RS_THREADS) void resample_bwd_staged_kernel(const f
     for (int i = threadIdx.x * 4; i < LC * S3; i += RS_THREADS * 4) {
         const int j = i / S3, u = i - j * S3;
         const f32x4 v = j < lc ? *reinterpret_cast<const f32x4*>(src + i) : f32x4{0.f, 0.f, 0.f, 0.f};
-        gl[(u + 0) * LC + j] = v[0];
-        gl[(u + 1) * LC + j] = v[1];
-        gl[(u + 2) * LC + j] = v[2];
-        gl[(u + 3) * LC + j] = v[3];
+        gl[lds_slot(u + 0, sh) * LC + j] = v[0];
+        gl[lds_slot(u + 1, sh) * LC + j] = v[1];
+        gl[lds_slot(u + 2, sh) * LC + j] = v[2];
+        gl[lds_slot(u + 3, sh) * LC + j] = v[3];
     }
     __syncthreads();
     const long long NS3 = (long long)N * S3;
     const f32x4* gq = reinterpret_cast<const f32x4*>(gl);
-    for (int u = threadIdx.x; u < S3; u += RS_THREADS) {
-        const long long slot = (long long)n * S3 + u;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const int cnt = hoff[BH * NS3 + slot];
-        for (int k = 0; k < cnt; ++k) {
-            const int off = hoff[k * NS3 + slot];
-            const float w = hw[k * NS3 + slot];
-            const f32x4 g4 = gq[off];
+    // Two source voxels per lane and pass, their hit lists read in batches of HB with all 4 * HB list loads in flight
+    // (round 5; one dependent pair of loads per hit before -- a lane-dependent trip count kept the compiler from hoisting
+    // them: ~12 serial round trips per voxel, 16 voxels per lane): 99 -> 88 us; four voxels per pass: 86 us.  Same
+    // summation order per voxel.  Planes past a voxel's count are unwritten memory and never enter a sum.
+    constexpr int HB = 8, UV = 2;
+    static_assert(BH % HB == 0, "whole batches");
+    for (int u0 = threadIdx.x; u0 < S3; u0 += UV * RS_THREADS) {
+        long long slot[UV];
+        int cnt[UV];
+        f32x4 acc[UV];
 #pragma unroll
-            for (int j = 0; j < LC; ++j) acc[j] = fmaf(w, g4[j], acc[j]);
+        for (int v = 0; v < UV; ++v) {
+            const int u = u0 + v * RS_THREADS;
+            slot[v] = (long long)n * S3 + (u < S3 ? u : u0);
+            cnt[v] = u < S3 ? hoff[BH * NS3 + slot[v]] : 0;
+            acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int k0 = 0; __any(k0 < max(cnt[0], cnt[1])); k0 += HB) {
+            static_assert(UV == 2, "the loop bound spells out the two counts");
+            int offs[UV][HB];
+            float ws[UV][HB];
+#pragma unroll
+            for (int v = 0; v < UV; ++v)
+#pragma unroll
+                for (int k = 0; k < HB; ++k) {
+                    offs[v][k] = hoff[(long long)(k0 + k) * NS3 + slot[v]];
+                    ws[v][k] = hw[(long long)(k0 + k) * NS3 + slot[v]];
+                }
+#pragma unroll
+            for (int v = 0; v < UV; ++v)
+#pragma unroll
+                for (int k = 0; k < HB; ++k) {
+                    const bool live = k0 + k < cnt[v];
+                    const f32x4 g4 = gq[lds_slot(live ? offs[v][k] : 0, sh)];
+                    if (live) {
+#pragma unroll
+                        for (int j = 0; j < LC; ++j) acc[v][j] = fmaf(ws[v][k], g4[j], acc[v][j]);
+                    }
+                }
         }
 #pragma unroll
-        for (int j = 0; j < LC; ++j)
-            if (j < lc) gvox[((long long)n * C + c0 + j) * S3 + u] = acc[j];
+        for (int v = 0; v < UV; ++v) {
+            const int u = u0 + v * RS_THREADS;
+            if (u < S3) {
+#pragma unroll
+                for (int j = 0; j < LC; ++j)
+                    if (j < lc) gvox[((long long)n * C + c0 + j) * S3 + u] = acc[v][j];
+            }
+        }
     }
 }
 
@@ -378,7 +433,7 @@ int gz_rigid_resample_fwd(const float* vox, const float* minv, float* out2d, lon
     const bool direct = knobs().resample_fwd_direct;      // experiment: the round-1 kernel
     if (!idx_out && !direct && S3 % 4 == 0 && lds <= 64 * 1024 && (((uintptr_t)vox) & 15) == 0) {
         hipLaunchKernelGGL(resample_fwd_staged_kernel, dim3(N, (C + FW_LC - 1) / FW_LC), dim3(RS_THREADS), lds, stream,
-                           vox, minv, out2d, N, C, S);
+                           vox, minv, out2d, N, C, S, swizzle_shift(S));
         return launch_status();
     }
     long long vox_n = (long long)N * S * S * S;
@@ -409,7 +464,7 @@ int gz_rigid_resample_bwd(const float* gout2d, const float* minv, float* gvox, f
         hipLaunchKernelGGL(resample_hits_kernel, dim3((S3 + RS_THREADS - 1) / RS_THREADS, N), dim3(RS_THREADS), 0, stream,
                            minv, hoff, hw, flag, N, S);
         hipLaunchKernelGGL(resample_bwd_staged_kernel, dim3(N, (C + LC - 1) / LC), dim3(RS_THREADS), lds_staged, stream,
-                           gout2d, hoff, hw, flag, gvox, N, C, S);
+                           gout2d, hoff, hw, flag, gvox, N, C, S, swizzle_shift(S));
         // more than BH hits somewhere (a view that zooms out): the staged kernel did nothing; no host sync --
         // the gather kernel reads the same flag and runs only then
         dim3 grid((S3 + RS_THREADS - 1) / RS_THREADS, N, (C + BG_CH - 1) / BG_CH);
