@@ -419,6 +419,11 @@ int gz_colsum(const float* x, float* out, int R, int L, hipStream_t stream);
 size_t gz_coldot_workspace_bytes(int R, int L);
 int gz_coldot(const float* g, const float* x, float* out, float* workspace, size_t ws_bytes, int R, int L,
               hipStream_t stream);
+/* gz_coldot without its slab sum (round 5): *nz_out row slices of L partial sums each are left in `workspace` (L floats
+ * apart) for gz_reduce_multi / gz_adam_step_from_slabs; *nz_out == 1 means `out` is complete.  The critics' last layer
+ * (Conv2d(8 f_d, 1, 4, 2, 0), reference standard_networks.py:27-30): its weight gradient joins the sinks unreduced. */
+int gz_coldot_partial(const float* g, const float* x, float* out, float* workspace, size_t ws_bytes, int R, int L,
+                      int* nz_out, hipStream_t stream);
 /* dst[i] = src[i] for `words` 4-byte words; src may be PINNED HOST memory (device-mapped): the staging of the per-step
  * host draws -- `noise = distn.sample(...).to(device)`, core/lightning_module.py:107-108, core/utils/utils.py:41 */
 int gz_copy_words(const void* src, void* dst, long long words, hipStream_t stream);

@@ -59,7 +59,7 @@ namespace gz {
     X(bool, no_act_fuse, "GZ_NO_ACT_FUSE", false)                                                                     \
     X(bool, no_pack_k4, "GZ_NO_PACK_K4", false)                                                                       \
     X(bool, no_resample_swizzle, "GZ_NO_RESAMPLE_SWIZZLE", false)                                                     \
-    X(int, fewc_wg_blocks, "GZ_FEWC_WG_BLOCKS", 256)                                                                  \
+    X(int, fewc_wg_blocks, "GZ_FEWC_WG_BLOCKS", 512)                                                                  \
     X(bool, no_smallch_conv, "GZ_NO_SMALLCH_CONV", false)                                                             \
     X(bool, no_smallch_wg, "GZ_NO_SMALLCH_WG", false)                                                                 \
     X(int, c3_gpw, "GZ_C3_GPW", 4)                                                                                    \

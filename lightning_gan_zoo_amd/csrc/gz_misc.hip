@@ -351,6 +351,20 @@ int gz_coldot(const float* g, const float* x, float* out, float* workspace, size
     return launch_status();
 }
 
+int gz_coldot_partial(const float* g, const float* x, float* out, float* workspace, size_t ws_bytes, int R, int L,
+                      int* nz_out, hipStream_t stream) {
+    gz::clear_stale_error();
+    if (R <= 0 || L <= 0 || (L & 3) || !nz_out) return GZ_ERR_BAD_SHAPE;
+    int slices = R >= 64 ? 32 : 1;
+    if (slices > 1 && ws_bytes < (size_t)slices * L * 4) return GZ_ERR_WORKSPACE;
+    int rps = (R + slices - 1) / slices;
+    int L4 = L / 4;
+    hipLaunchKernelGGL(coldot_kernel, dim3((L4 + MT - 1) / MT, slices), dim3(MT), 0, stream, g, x,
+                       slices > 1 ? workspace : out, R, L4, rps);
+    *nz_out = slices;
+    return launch_status();
+}
+
 int gz_copy_words(const void* src, void* dst, long long words, hipStream_t stream) {
     gz::clear_stale_error();
     if (words <= 0 || !src || !dst) return GZ_ERR_BAD_SHAPE;

@@ -1058,6 +1058,29 @@ def _coldot_raw(g, x):
     return out
 
 
+def _sink_coldot(param, g, x):
+    """``param``'s gradient sum_r g[r] * x[r, :] into its sink as UNREDUCED row slices (gz_coldot_partial): the slab sum
+    that would follow is done by the launch that sums everything else.  False = not taken."""
+    if not _sinks.enabled or not isinstance(param, torch.nn.Parameter) or (param.numel() & 3):
+        return False
+    if param.grad is not None and (param.grad.data_ptr() & 15 or not param.grad.is_contiguous()
+                                   or param.grad.dtype != torch.float32):
+        return False
+    R, L = x.shape
+    if L != param.numel():
+        return False
+    nbytes = lib.gz_coldot_workspace_bytes(R, L)
+    ws = _ws(max(nbytes // 4, 1), x.device)
+    out = torch.empty(L, device=x.device, dtype=torch.float32)
+    nz = ctypes.c_int(0)
+    check(lib.gz_coldot_partial(_p(g), _p(x), _p(out), _p(ws), nbytes, R, L, ctypes.byref(nz), _stream()), "coldot_partial")
+    src = (ws, nz.value, L) if nz.value > 1 else (out, 1, L)
+    if src[0].data_ptr() & 15:
+        _sink_fail("coldot slices")
+    _sinks.pending.setdefault(id(param), [param, []])[1].append(src)
+    return True
+
+
 class _DotF(torch.autograd.Function):
     """y[r] = <x[r,:], w>"""
 
@@ -1075,9 +1098,10 @@ class _DotF(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             if ctx.param is not None and not torch.is_grad_enabled() and _sinks.enabled:
-                dw = _coldot_raw(_req(g), x)
-                if _sink_grad(ctx.param, dw.view_as(ctx.param)):
-                    dw = None
+                if not _sink_coldot(ctx.param, _req(g), x):
+                    dw = _coldot_raw(_req(g), x)
+                    if _sink_grad(ctx.param, dw.view_as(ctx.param)):
+                        dw = None
             else:
                 dw = _DotWg.apply(x, g)
         return dx, dw, None
@@ -1100,9 +1124,10 @@ class _DotDg(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             if ctx.param is not None and not torch.is_grad_enabled() and _sinks.enabled:
-                dw = _coldot_raw(_req(g), _req(v))                # == _DotWg(v, g)
-                if _sink_grad(ctx.param, dw.view_as(ctx.param)):
-                    dw = None
+                if not _sink_coldot(ctx.param, _req(g), _req(v)):     # == _DotWg(v, g)
+                    dw = _coldot_raw(_req(g), _req(v))
+                    if _sink_grad(ctx.param, dw.view_as(ctx.param)):
+                        dw = None
             else:
                 dw = _DotWg.apply(v, g)
         return dg, dw, None
