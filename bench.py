@@ -50,7 +50,11 @@ NATIVE_IMG_SIZE = {"gan_stability_r1": 128}
 SUB_CONFIGS = (("dc_gan_bs128", "dc_gan", 128, 64), ("dc_gan_bs512", "dc_gan", 512, 64),
                ("wgan_gp_bs256", "wgan_gp", 256, 64), ("hologan_bs64", "hologan", 64, 64),
                ("hologan_ext128_bs64", "hologan", 64, 128), ("wgan_bs512", "wgan", 512, 64))
-MULTI_GPU_SUB_CONFIGS = ("dc_gan_bs128", "dc_gan_bs512")     # what a --gpus N run times on all ranks
+# what a --gpus N run times on all ranks: the metric's batch, BASELINE config 4 (dc_gan bs 512 / GPU) and config 5
+# (hologan 128x128 bs 64 / GPU: EXT-128, throughput only -- the reference cannot run at 128)
+MULTI_GPU_SUB_CONFIGS = ("dc_gan_bs128", "dc_gan_bs512", "hologan_ext128_bs64")
+# the data-parallel code path on ONE GPU (single-rank RCCL), timed next to the plain trainer in every default run
+GRADSYNC_W1_CONFIGS = ("dc_gan_bs128", "dc_gan_bs512", "wgan_gp_bs256", "hologan_ext128_bs64")
 DEFAULT_BATCH = {"dc_gan": 128, "wgan": 512, "wgan_gp": 256, "hologan": 64, "gan_stability_r1": 64}
 PEAK_FP32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
 TIMER_EVERY = 4     # per-launch HIP events on every 4th cycle of the timed region (they cost ~5 % when always on)
@@ -449,13 +453,16 @@ class single_rank_rccl:
 
 
 def gradsync_w1_records(F, args, device, use_timer, out, head_key):
-    """dc_gan bs 128 and bs 512 under ddp.GradSync over RCCL at world size 1 (GZ_DDP_ALWAYS_REDUCE: the collective is
-    really issued).  The numbers price the data-parallel machinery itself; an N > 1 run adds the wire time."""
+    """dc_gan bs 128 / bs 512, wgan_gp bs 256 (config 3) and hologan EXT-128 bs 64 (config 5's per-GPU workload) under
+    ddp.GradSync over RCCL at world size 1 (GZ_DDP_ALWAYS_REDUCE: the collective is really issued).  The numbers price
+    the data-parallel machinery itself; an N > 1 run adds the wire time."""
     recs = {}
+    cfgs = {k: (e, b, i) for k, e, b, i in SUB_CONFIGS}
     with single_rank_rccl(device):
-        for key, bs in (("dc_gan_bs128", 128), ("dc_gan_bs512", 512)):
-            rec = measure(F, "dc_gan", bs, 64, device, 0, 1, args.steps, args.warmup, args.reps, use_timer,
-                          force_sync=True)
+        for key in GRADSYNC_W1_CONFIGS:
+            expt, bs, img = cfgs[key]
+            steps = args.steps if expt == "dc_gan" else min(args.steps, args.sub_steps)
+            rec = measure(F, expt, bs, img, device, 0, 1, steps, args.warmup, args.reps, use_timer, force_sync=True)
             plain = out if key == head_key else out["sub_configs"].get(key)
             if plain is not None:
                 rec["vs_plain"] = round(rec["ms_per_step"] / plain["ms_per_step"], 4)

@@ -37,7 +37,9 @@ class BasicBlock(nn.Module):
         """w: this call's spectral-normalised weight when the caller already has it (Discriminator.forward runs the
         power iteration of all three blocks in one set of launches)."""
         c = self.conv2d
+        F.ready(c.bias)
         if w is None:
+            F.ready(c.weight_orig)
             w = F.spectral_normalize(c.weight_orig, c.weight_u, c.weight_v, self.training)
         y = F.conv2d(x, w, c.bias, K5S2P2)
         return F.instance_norm_act(y, None, None, self.instance_norm.eps, F.ACT_LRELU, self.lrelu.negative_slope)
@@ -79,6 +81,7 @@ class Discriminator(nn.Module):
     # discriminator step can apply D ONCE to [real; fake] (`groups` = 2: two consecutive power iterations, one sigma per
     # half -- what the reference's two calls see).  False: the per-call weight copy of rounds 2-4a.
     fused_sn_blocks = True
+    gates_parameters = True      # every layer announces its parameters with F.ready before reading them (ddp.GradSync)
 
     @property
     def supports_stacked_batches(self):
@@ -87,11 +90,13 @@ class Discriminator(nn.Module):
     def forward(self, x, groups=1):
         batch_size = x.size(0)
         slope = self.lrelu.negative_slope
+        F.ready(self.conv2d.weight, self.conv2d.bias)
         h = F.conv2d(x, self.conv2d.weight, self.conv2d.bias, K5S2P2, F.ACT_LRELU, slope)
         # torch.nn.utils.spectral_norm's pre-forward hook of each block (reference :15,32) depends only on the block's
         # own weight and buffers: the three power iterations share their launches
         convs = [blk.conv2d for blk in self.blocks]
         layers = [(c.weight_orig, c.weight_u, c.weight_v) for c in convs]
+        F.ready(*[p for c in convs for p in (c.weight_orig, c.bias)])       # (the power iterations read all three)
         if self.training and x.is_cuda and self.supports_stacked_batches:
             for blk, (sigma, us, vs) in zip(self.blocks, F.spectral_power_iterations(layers, calls=groups)):
                 c = blk.conv2d
@@ -105,6 +110,7 @@ class Discriminator(nn.Module):
             for blk, w in zip(self.blocks, ws):
                 h = blk(h, w)
         h = h.reshape(batch_size, -1)
+        F.ready(*[p for lin in (self.linear1, self.linear2, self.linear3) for p in (lin.weight, lin.bias)])
         logit = F.linear_act(h, self.linear1.weight, self.linear1.bias)
         enc = F.linear_act(h, self.linear2.weight, self.linear2.bias, F.ACT_LRELU, slope)
         z_prediction = F.linear_act(enc, self.linear3.weight, self.linear3.bias, F.ACT_TANH)

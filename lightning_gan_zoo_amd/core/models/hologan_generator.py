@@ -35,6 +35,7 @@ class ZMapping(nn.Module):
     def forward(self, x):
         """[N, 2C]: the AdaIN scale (first half) and shift (second half), consumed packed by adain_act_packed
         (the reference slices them, hologan_generator.py:17-18)."""
+        F.ready(self.linear1.weight, self.linear1.bias)
         return F.linear_act(x, self.linear1.weight, self.linear1.bias, F.ACT_RELU)
 
 
@@ -56,6 +57,7 @@ class BasicBlock(nn.Module):
         """style: this block's zMapping(z) when the caller already has it (Generator.forward maps z through all five
         ZMapping layers in one launch)."""
         ct = self.convTranspose
+        F.ready(ct.weight, ct.bias)
         # (the AdaIN below normalises every (sample, channel) plane: the bias cannot reach the loss, its gradient is 0)
         if self.transpose_dim == 2:
             h = F.conv_transpose2d(h, ct.weight, ct.bias, F.K4S2P1, bias_cancels=True)
@@ -92,6 +94,8 @@ def view_inverse_matrices(view, size=16, new_size=16):
 
 
 class Generator(nn.Module):
+    gates_parameters = True      # every layer announces its parameters with F.ready before reading them (ddp.GradSync)
+
     def __init__(self, in_planes, out_planes, z_planes, view_args, img_size, view_planes=6, gpu=True,
                  ext128=False):
         super().__init__()
@@ -125,6 +129,34 @@ class Generator(nn.Module):
         self.tanh = nn.Tanh()
         self.staged_minv = None     # harness.GraphedTrainer: the step's inverse view matrices, already on the device
         self._prefetched = None     # harness.Trainer: (matrices on the device, numpy state before, after, batch size)
+
+    # -- data parallelism (ddp.GradSync; reference run_network.py:66, conf/expt/hologan.yaml:16-17: D, G, G) ----------
+    def _zmaps(self):
+        return (self.zMapping, self.block1.zMapping, self.block2.zMapping, self.block3.zMapping, self.block4.zMapping)
+
+    def grad_arrival_order(self):
+        """The parameters in the order their gradients complete during backward.  Not the reverse definition order: the
+        five ZMapping layers are evaluated by ONE launch at the top of forward(), so their gradients come out of one
+        launch at the very end of backward, whichever block owns them."""
+        order = []
+        for m in (self.final_layer, self.block4.convTranspose, self.block3.convTranspose, self.convTranspose2d1,
+                  self.block2.convTranspose, self.block1.convTranspose):
+            order += [m.weight, m.bias]
+        order.append(self.x)
+        for m in self._zmaps():
+            order += [m.linear1.weight, m.linear1.bias]
+        return order
+
+    def deferred_tail_parameters(self):
+        """Weight gradients whose LAUNCH is postponed to the end of backward and whose bucket travels last (ddp.py).
+        The schedule runs two generator steps back to back, so the next user of these gradients is this network's own
+        next forward: the constant, the ZMapping layers, the two 3-D blocks and the 1x1 projection (13 of 31 MB,
+        needed first) travel underneath these launches -- block3 / block4 are ~60 % of the generator's FLOP -- and
+        block3 / block4's own 17.8 MB underneath the early layers of that forward."""
+        tail = [self.block4.convTranspose.weight, self.block3.convTranspose.weight]
+        if isinstance(self.final_layer, nn.ConvTranspose2d):       # EXT-128: bias-free sink path (functional._ConvDg)
+            tail.insert(0, self.final_layer.weight)
+        return tail
 
     def sample_view(self, batch_size):
         """Transformation parameters from numpy's global generator, reference :80-114 (call order kept)."""
@@ -174,8 +206,10 @@ class Generator(nn.Module):
         dev = self.x.device
 
         # the five ZMapping layers (reference :33, :57, :141) read the same z: one launch, [N, 2C] each
-        maps = (self.zMapping, self.block1.zMapping, self.block2.zMapping, self.block3.zMapping, self.block4.zMapping)
+        maps = self._zmaps()
+        F.ready(*[p for m in maps for p in (m.linear1.weight, m.linear1.bias)])
         s0, s1, s2, s3, s4 = F.linear_act_multi(z, [(m.linear1.weight, m.linear1.bias) for m in maps], F.ACT_RELU)
+        F.ready(self.x)
         h = F.adain_const_act(self.x, s0, 1e-8, F.ACT_RELU)     # = AdaIN(self.x.repeat(n, ...)), reference :141
         h = self.block1(h, z, s1)
         h = self.block2(h, z, s2)
@@ -194,10 +228,12 @@ class Generator(nn.Module):
             minv = draw_on_host(lambda: view_inverse_matrices(view_in).reshape(n, 16).contiguous(), dev)
         h = F.rigid_resample(h, minv)                                 # [N, 16*C, 16, 16]
         p = self.convTranspose2d1
+        F.ready(p.weight, p.bias)
         h = F.conv_transpose2d(h, p.weight, p.bias, K1S1P0, F.ACT_RELU)
         h = self.block3(h, z, s3)
         h = self.block4(h, z, s4)
         f = self.final_layer
+        F.ready(f.weight, f.bias)
         if isinstance(f, nn.ConvTranspose2d):                          # EXT-128
             return F.conv_transpose2d(h, f.weight, f.bias, F.K4S2P1, F.ACT_TANH)
         return F.conv2d(h, f.weight, f.bias, K3S1P1, F.ACT_TANH)

@@ -50,9 +50,15 @@ DEFER_TAIL = os.environ.get("GZ_DDP_DEFER_TAIL", "1") != "0"
 
 
 class _FlatGrads:
-    def __init__(self, params, bucket_bytes=BUCKET_BYTES, tail=()):
+    def __init__(self, params, bucket_bytes=BUCKET_BYTES, tail=(), arrival=None):
+        """``params``: the network's parameters in definition order; ``arrival``: the same parameters in the order their
+        gradients COMPLETE during backward when that is not simply the reverse (a network says so with
+        ``grad_arrival_order()``: HoloGAN's five ZMapping layers are evaluated by one launch at the top of the forward,
+        so their gradients land last whichever block they belong to)."""
         tail_ids = {id(p) for p in tail}
-        back = [p for p in params][::-1]              # backward order: the last layer's gradient lands first
+        back = [p for p in params][::-1] if arrival is None else list(arrival)
+        if arrival is not None and sorted(map(id, back)) != sorted(id(p) for p in params):
+            raise ValueError("grad_arrival_order() must be a permutation of the network's parameters")
         self.params = [p for p in back if id(p) not in tail_ids] + [p for p in back if id(p) in tail_ids]
         self.n_main = sum(1 for p in back if id(p) not in tail_ids)      # params[n_main:] = the deferred tail
         # every view starts on a 16-byte boundary (the sink kernels read and write float4; a 1-element bias -- HoloGAN's
@@ -122,7 +128,13 @@ class _Pending:
 def pick_tail(net, bucket_bytes=BUCKET_BYTES, min_bytes=MIN_BUCKET_BYTES):
     """The deferred tail of a network: the convolution weights of its LAST layers (definition order = forward order for
     the standard networks) while they fit min(bucket cap, a quarter of the network's gradient bytes); at least 1 MB,
-    else no tail (a tiny last message hides nothing and costs a collective)."""
+    else no tail (a tiny last message hides nothing and costs a collective).  A network that knows better declares
+    ``deferred_tail_parameters()`` (HoloGAN's generator: its schedule runs two generator steps back to back, so the
+    tail is sized to what the NEXT generator forward can hide)."""
+    own = getattr(net, "deferred_tail_parameters", None)
+    if own is not None:
+        tail = [p for p in own() if p.dim() >= 4 and not (p.numel() & 3)]
+        return tail if sum(p.numel() for p in tail) * 4 >= min_bytes else []
     params = list(net.parameters())
     total = sum(p.numel() for p in params) * 4
     budget = min(bucket_bytes, total // 4)
@@ -168,7 +180,9 @@ class GradSync:
             defer_tail = DEFER_TAIL and on_gpu
         tails = [pick_tail(n, bucket_bytes, tail_min_bytes) if (defer_tail and lazy) else []
                  for n, lazy in zip(self.nets, self.lazy)]
-        self.flats = [_FlatGrads(list(n.parameters()), bucket_bytes, t) for n, t in zip(self.nets, tails)]
+        arrivals = [getattr(n, "grad_arrival_order", None) for n in self.nets]
+        self.flats = [_FlatGrads(list(n.parameters()), bucket_bytes, t, None if a is None else a())
+                      for n, t, a in zip(self.nets, tails, arrivals)]
         self.tails = tails
         self.pending = [None, None]   # _Pending per network
         self.active = None            # network whose backward is running (and exchanging)
@@ -313,7 +327,12 @@ class GradSync:
             self._broadcast_all_buffers()
         if getattr(self.module, "mutates_discriminator_before_forward", False):
             self.finalize(0)     # WGAN clamps D's weights at the top of training_step
-        self.finalize(optimizer_idx)     # a pending step of the SAME network must land before its next backward
+        # A pending step of the SAME network must land before its next backward.  A network with per-layer gates lands
+        # it by itself, bucket by bucket, during the forward that precedes that backward (a forward that leaves a
+        # bucket un-finalized raises, _make_post_hook) -- HoloGAN's D, G, G schedule hands a generator pass straight to
+        # the next generator step, whose early layers then run underneath the previous pass's tail bucket.
+        if not self.lazy[optimizer_idx]:
+            self.finalize(optimizer_idx)
         fg = self.flats[optimizer_idx]
         fg.rebind()
         self.active = optimizer_idx if exchange else None
@@ -364,6 +383,25 @@ class GradSync:
         self.order[optimizer_idx] = []
         if not self.overlap:
             self.finalize(optimizer_idx)
+
+    def abort_pass(self, optimizer_idx):
+        """A training_step / backward of network ``optimizer_idx`` raised half-way (harness.Trainer's except branch):
+        wait for the all-reduces this rank has already issued from the backward hooks (a collective that is never waited
+        for keeps its buffer busy and leaves the ranks with different numbers of matched calls), drop them, clear the
+        running pass's bookkeeping and the postponed launches, and zero what the pass had accumulated in the flat
+        buffer.  Earlier passes that are still pending (``self.pending``) are untouched."""
+        for work in self.works[optimizer_idx].values():
+            if work is not None:
+                work.wait()
+        self.works[optimizer_idx] = {}
+        self.order[optimizer_idx] = []
+        self.reported = set()
+        self.active = None
+        if self._F is not None:
+            self._F.discard_grad_sinks()
+            self._F.set_deferred_wgrads(())
+        if self.pending[optimizer_idx] is None:       # (else the flat buffer still holds the pending pass's gradients)
+            self.flats[optimizer_idx].flat.zero_()
 
     # ---- landing a pass ------------------------------------------------------------------------------------------
     def finalize(self, idx, upto=None):

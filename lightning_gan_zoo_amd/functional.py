@@ -2113,8 +2113,8 @@ class _SNConvINAct(torch.autograd.Function):
             p = ctx.param
             # weight_orig is a leaf: the convolution's weight gradient and the sigma term join its sink as two sources
             sunk = isinstance(p, torch.nn.Parameter) and not (W.numel() & 3) and _sink_conv_wgrad(p, x, g_raw, geom)
-            if sunk:
-                _sinks.pending[id(p)][1].append((term, 1, W.numel()))
+            if sunk:     # (setdefault: a weight whose launch GradSync postponed has no entry yet)
+                _sinks.pending.setdefault(id(p), [p, []])[1].append((term, 1, W.numel()))
             if not sunk:
                 dW = _conv_wgrad_raw(x, g_raw, geom)
                 dW.add_(term)

@@ -235,6 +235,8 @@ class Trainer:
         except BaseException:
             if F is not None:             # nothing half-built is reduced, nothing leaks into the next step's gradients
                 F.discard_grad_sinks()
+            if self.grad_sync is not None:
+                self.grad_sync.abort_pass(idx)
             raise
         finally:
             if F is not None:

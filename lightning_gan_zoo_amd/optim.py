@@ -47,8 +47,6 @@ class Adam(torch.optim.Optimizer):
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         max_t, nb = lib.gz_adam_src_max_tensors(), lib.gz_adam_src_table_bytes()
         for group in self.param_groups:
-            if group.get("_tick") is not None:
-                raise RuntimeError("capturable fused Adam does not take sink sources")
             beta1, beta2 = group["betas"]
             todo = [(p, sources[id(p)][1]) for p in group["params"] if id(p) in sources]
             if not todo:
@@ -89,7 +87,10 @@ class Adam(torch.optim.Optimizer):
         """Move the step counter to the device so that ``step()`` can be captured in a HIP graph and replayed
         (harness.GraphedTrainer): one float[3] per param group {step, 1 - beta1^step, sqrt(1 - beta2^step)} advanced
         by gz_adam_tick; the per-parameter ``state['step']`` entries become views of its first element (what
-        torch.optim.Adam(capturable=True) keeps as 0-dim device tensors)."""
+        torch.optim.Adam(capturable=True) keeps as 0-dim device tensors).  From here on the optimizer steps whole param
+        groups from ``p.grad`` only: callers that look at ``accepts_param_subset`` / ``accepts_sink_sources``
+        (ddp.GradSync, harness.Trainer) take their generic paths."""
+        self.accepts_param_subset = self.accepts_sink_sources = False
         for group in self.param_groups:
             params = [p for p in group["params"]]
             if not params:
@@ -138,6 +139,11 @@ class Adam(torch.optim.Optimizer):
         ``sink_sources`` (functional.take_grad_sinks): parameters whose gradient exists only as unreduced slabs -- the
         kernel sums them itself (gz_adam_step_from_slabs; same bits as reduce-then-step)."""
         loss = closure() if closure is not None else None
+        if (params is not None or sink_sources) and not self.accepts_sink_sources:
+            # a capturable group shares ONE device step counter, ticked once per step(): a per-bucket step would advance
+            # it several times per optimizer step, and the slab path reads the step count on the host (ADVICE r5)
+            raise RuntimeError("capturable fused Adam steps whole param groups from p.grad only (no params= subset, "
+                               "no sink_sources=)")
         if sink_sources:
             self._step_from_slabs(sink_sources, grad_scale)
         if getattr(self, "_pack_group", None) is None:      # the conv weights this optimizer rewrites re-pack together

@@ -94,9 +94,14 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     assert out["config"]["global_batch"] == 256 and out["scaling"] == "weak" and "rehearsal" in out
     # ... and the north star's bs=512/GPU is timed on ALL ranks in the same run (a SCALE run yields both curves)
     big = out["sub_configs"]["dc_gan_bs512"]
-    assert set(out["sub_configs"]) == {"dc_gan_bs512"} and big["n_gpus"] == 2 and len(big["per_rank_ms_per_step"]) == 2
+    # ... and so is BASELINE config 5, the 8-GPU HoloGAN workload (128x128 bs 64 / GPU; round 6)
+    holo = out["sub_configs"]["hologan_ext128_bs64"]
+    assert set(out["sub_configs"]) == {"dc_gan_bs512", "hologan_ext128_bs64"}
+    assert big["n_gpus"] == 2 and len(big["per_rank_ms_per_step"]) == 2
     assert big["value"] > 0 and "bs=512/GPU" in big["workload"]
-    for rec in (out, big):
+    assert holo["n_gpus"] == 2 and holo["value"] > 0 and "hologan synthetic 128x128 bs=64/GPU" in holo["workload"]
+    assert holo["grad_exchange"]["per_layer_gates"] == [True, True]
+    for rec in (out, big, holo):
         ex = rec["grad_exchange"]
         assert ex["buckets_from_hooks"] > 0 and ex["buckets_after_backward"] == 0
         assert ex["buckets_deferred_tail"] > 0          # the generator's last layers: launched + exchanged last
