@@ -37,7 +37,10 @@ import os
 import torch
 import torch.distributed as dist
 
-BUCKET_BYTES = int(os.environ.get("GZ_DDP_BUCKET_MB", "16")) << 20
+# Bucket cap.  Every message costs the compute stream two cross-stream hand-overs of ~20 us each (issue + wait) whatever its
+# size, and every exchange of this workload hides behind milliseconds of compute, so messages are few and large: 32 MB
+# (round 6; 16 MB before) makes HoloGAN's critic one message (21.5 MB at 64x64, 34 MB at 128x128).
+BUCKET_BYTES = int(os.environ.get("GZ_DDP_BUCKET_MB", "32")) << 20
 MIN_BUCKET_BYTES = 1 << 20       # a bucket is not closed below this size just because a large parameter follows
 # CUs the convolution planner leaves to RCCL's channel kernels while the exchange overlaps backward (gz_set_cu_budget).
 # Default 0 = plans sized for the whole chip: the single-GPU rehearsal (profiles/r04_contention.json, tools/
@@ -89,9 +92,14 @@ class _FlatGrads:
             end = self.offsets[i] + p.numel()
             last = i + 1 == len(self.params)
             nxt = self.params[i + 1].numel() if not last else 0
-            section_end = self.n_main if i < self.n_main else len(self.params)
+            in_tail = i >= self.n_main
+            section_end = len(self.params) if in_tail else self.n_main
             rest = sum(sizes[i + 1:section_end])
-            over = (end - start + nxt) * 4 > bucket_bytes and (end - start) * 4 >= floor and rest > bucket_bytes // 2
+            # the deferred tail is waited for at the gates of ITS layers only, which all sit late in the next forward:
+            # cutting it lands nothing earlier and costs a second pair of cross-stream hand-overs -- one message up to
+            # twice the cap (HoloGAN's block3 + block4: 17.8 MB)
+            cap = 2 * bucket_bytes if in_tail else bucket_bytes
+            over = (end - start + nxt) * 4 > cap and (end - start) * 4 >= floor and rest > bucket_bytes // 2
             if last or over or i + 1 == self.n_main:
                 self.buckets.append((start, end, first, i + 1))
                 start, first = end, i + 1

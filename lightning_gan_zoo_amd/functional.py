@@ -835,6 +835,7 @@ class _ConvF(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if want_b:
                 dw, db = _conv_wgrad_raw(x, gy, geom, with_bias=True)
+                dw = _sink_or_return(w, dw)       # (complete gradient: one-slab source, no AccumulateGrad `add_`)
             elif not _sink_conv_wgrad(w, x, gy, geom):
                 dw = _conv_wgrad_raw(x, gy, geom)
         elif want_b:
@@ -1574,6 +1575,7 @@ class _Conv3DDg(torch.autograd.Function):
     def forward(ctx, g, w, bias, bias_cancels=False):
         g, w = _req(g, "g"), _req(w, "w")
         ctx.save_for_backward(g, w)
+        ctx.w_ref = w
         ctx.has_bias = bias is not None
         ctx.bias_cancels = bias_cancels
         ctx.bias_ref = bias if isinstance(bias, torch.nn.Parameter) else None
@@ -1583,8 +1585,12 @@ class _Conv3DDg(torch.autograd.Function):
     def backward(ctx, v):
         g, w = ctx.saved_tensors
         v = _req(v)
-        dg = _Conv3DF.apply(v, w) if ctx.needs_input_grad[0] else None
-        dw = _Conv3DWg.apply(v, g, w.shape[2]) if ctx.needs_input_grad[1] else None
+        if torch.is_grad_enabled():
+            dg = _Conv3DF.apply(v, w) if ctx.needs_input_grad[0] else None
+            dw = _Conv3DWg.apply(v, g, w.shape[2]) if ctx.needs_input_grad[1] else None
+        else:                                # no graph is being recorded: raw launches, the weight gradient into its sink
+            dg = _conv3d_fwd_raw(v, w, None, ACT_NONE, 0.0) if ctx.needs_input_grad[0] else None
+            dw = _sink_or_return(ctx.w_ref, _conv3d_wgrad_raw(v, g, w.shape[2])) if ctx.needs_input_grad[1] else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if ctx.bias_cancels and not torch.is_grad_enabled():
@@ -1647,6 +1653,7 @@ class _AdaINAct(torch.autograd.Function):
                                      _stream()), "rownorm_act_fwd(adain)")
         ctx.save_for_backward(x, coef)
         ctx.cfg = (N, C, inner, act, slope)
+        ctx.x_ref = x
         return out
 
     @staticmethod
@@ -1689,6 +1696,7 @@ class _AdaINActPacked(torch.autograd.Function):
                                      inner, eps, 2, 1, act, slope, _stream()), "rownorm_act_fwd(adain, packed)")
         ctx.save_for_backward(x, coef)
         ctx.cfg = (N, C, inner, act, slope)
+        ctx.x_ref = x
         return out
 
     @staticmethod
@@ -1729,6 +1737,7 @@ class _AdaINConst(torch.autograd.Function):
               "adain_const_fwd")
         ctx.save_for_backward(x, coef)
         ctx.cfg = (N, C, inner, act, slope)
+        ctx.x_ref = x
         return out
 
     @staticmethod
@@ -1741,7 +1750,7 @@ class _AdaINConst(torch.autograd.Function):
         dsb = torch.empty((N, 2 * C), device=x.device, dtype=torch.float32)
         check(lib.gz_adain_const_bwd(_p(gout), _p(x), _p(coef), _p(dx), _p(dsb), N, C, inner, act, slope, _stream()),
               "adain_const_bwd")
-        return dx, dsb, None, None, None
+        return (_sink_or_return(ctx.x_ref, dx) if ctx.needs_input_grad[0] else None), dsb, None, None, None
 
 
 def adain_const_act(x, sb, eps=1e-8, act=ACT_RELU, slope=0.0):
@@ -1808,6 +1817,7 @@ class _LinearActMulti(torch.autograd.Function):
         check(lib.gz_linear_multi_fwd(table, _p(x), N, K, act, slope, _stream()), "linear_multi_fwd")
         ctx.save_for_backward(x, *ws, *outs)
         ctx.act, ctx.slope, ctx.has_bias = act, slope, [b is not None for b in bs]
+        ctx.params = tuple(wb)               # the Parameters themselves: their gradients join the sinks
         return outs
 
     @staticmethod
@@ -1832,6 +1842,10 @@ class _LinearActMulti(torch.autograd.Function):
                 gm = g if ctx.act == ACT_NONE else g * _act_derivative(o, ctx.act, ctx.slope)
                 part = gemm(gm.contiguous(), w)
                 dx = part if dx is None else dx + part
+        # complete gradients: one-slab sources of the sink flush (under data parallelism p.grad is a view of the flat
+        # exchange buffer and autograd would spend an `add_` launch per parameter: 10 per generator step)
+        grads = [None if not ctx.needs_input_grad[3 + j] else _sink_or_return(p_, g_)
+                 for j, (p_, g_) in enumerate(zip(ctx.params, grads))]
         return (dx, None, None, *grads)
 
 
