@@ -7,6 +7,7 @@ Run in the build container only (the reference does not exist on the GPU box):
     python tests/golden/make_golden.py            # all fixtures
     python tests/golden/make_golden.py dc_gan     # one experiment
     python tests/golden/make_golden.py pinned     # the *_full_pinned.npz fixtures (reference mask decisions)
+    python tests/golden/make_golden.py pinned_tiny   # the *_tiny_pinned.npz fixtures (same, features 8 / bs 4, full tensors)
 
 Each fixture holds the latent / alpha inputs (``in/...``; the synthetic reals are regenerated
 from their seeds and pinned by a checksum), everything tests/scenario.py records (``out/...``)
@@ -119,23 +120,27 @@ PINNED_KW = dict(pairs=1, skip_opt=True, probe=False)
 PINNED_SIZE = "full64"        # == "full" for the standard networks; HoloGAN at the reference's default in_planes 64, bs 8
 
 
-def make_pinned(expt):
-    """``<expt>_full_pinned.npz``: the features-64 / bs-8 scenario on the plain (un-stabilised) closed-form
+def make_pinned(expt, size="full"):
+    """``<expt>_full_pinned.npz`` (``<expt>_tiny_pinned.npz``: the same at features 8 / bs 4, round 6 -- the tiny nets'
+    gradients move by ~1e-2 per ReLU decision, so only a fixture WITH the reference's decisions can hold them to 1e-3):
+    the features-64 / bs-8 scenario on the plain (un-stabilised) closed-form
     parameters, one D step and one G step from those parameters (no optimizer step in between), together with every
     ReLU / LeakyReLU decision the reference took (``mask/NNN`` packed bits in call order, ``mask_shape/NNN``;
     observed with a global forward hook -- tests/mask_pinning.py -- the reference is not modified).  Oracle and
     product are re-run with exactly these decisions and compared at the plain 1e-3, every gradient included."""
     from mask_pinning import MaskTape, record_module_masks
-    inputs = scenario.make_inputs(expt, PINNED_SIZE)
+    scen = "tiny" if size == "tiny" else PINNED_SIZE
+    inputs = scenario.make_inputs(expt, scen)
     tape = MaskTape()
     with record_module_masks(tape):
-        out = run_reference(expt, PINNED_SIZE, False, torch.float32, False, inputs, **PINNED_KW)
+        # (tiny: full tensors, like the *_tiny fixtures; full: norm / sum / 16 samples per tensor)
+        out = run_reference(expt, scen, False, torch.float32, size == "tiny", inputs, **PINNED_KW)
     blob = {"in/" + k: v.numpy() for k, v in inputs.items() if not k.startswith("real_")}
     blob["in/real_checksum"] = np.float64(sum(float(v.double().sum()) for k, v in sorted(inputs.items())
                                               if k.startswith("real_")))
     blob.update({"out/" + k: np.asarray(v) for k, v in out.items()})
     blob.update(tape.to_arrays())
-    path = os.path.join(HERE, f"{expt}_full_pinned.npz")
+    path = os.path.join(HERE, f"{expt}_{size}_pinned.npz")
     np.savez_compressed(path, **blob)
     bits = sum(m.numel() for m in tape.masks)
     print(f"{path}: {len(tape.masks)} mask decisions, {bits / 8e6:.2f} MB of bits, file "
@@ -158,9 +163,9 @@ def sensitivity(o32, o64):
 
 def main(argv):
     torch.set_num_threads(8)
-    if argv and argv[0] == "pinned":
+    if argv and argv[0] in ("pinned", "pinned_tiny"):
         for expt in argv[1:] or PINNED_EXPTS:
-            make_pinned(expt)
+            make_pinned(expt, "tiny" if argv[0] == "pinned_tiny" else "full")
         return
     expts = argv or list(scenario.STD_EXPTS)
     for expt in expts:

@@ -145,6 +145,25 @@ def record_product_masks(tape):
             setattr(F, name, fn)
 
 
+# decisions per forward pass: (generator, discriminator).  Reference standard_networks.py:34-50,78-89 -- one ReLU per
+# generator block, LeakyReLU after conv_in and after each of the three blocks; hologan_generator.py:116-143 -- five
+# ZMapping ReLUs, five AdaIN ReLUs, the projection's ReLU; hologan_discriminator.py:56-70 -- conv2d, three blocks, linear2
+DECISIONS_PER_FORWARD = {"dc_gan": (4, 4), "wgan": (4, 4), "wgan_gp": (4, 4), "hologan": (11, 5)}
+
+
+def stack_discriminator_decisions(tape, expt):
+    """A tape in the reference's call order (D step: G(z), D(real), D(fake)[, D(x_hat)]; then whatever follows) with the
+    D step's two discriminator calls merged layer by layer along the batch: what ONE pass over cat(real, fake) -- the
+    product's default discriminator step -- must decide."""
+    n_g, n_d = DECISIONS_PER_FORWARD[expt]
+    m = tape.masks
+    real, fake = m[n_g:n_g + n_d], m[n_g + n_d:n_g + 2 * n_d]
+    assert all(a.shape == b.shape for a, b in zip(real, fake))
+    out = MaskTape()
+    out.masks = list(m[:n_g]) + [torch.cat([a, b]) for a, b in zip(real, fake)] + list(m[n_g + 2 * n_d:])
+    return out
+
+
 class _PinnedLeaky(torch.nn.Module):
     def __init__(self, tape, slope):
         super().__init__()

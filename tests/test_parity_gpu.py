@@ -39,11 +39,18 @@ def test_regression_guard_product_vs_unpinned_reference_fixture(expt, size):
     out = scenario.run_scenario(step, inputs, "cuda", full=full, set_alpha=set_alpha,
                                 shadow=build_oracle_step(expt, size))
     scale = float(np.abs(golden["probe/logits"]).max())
-    # (tiny nets, features 8 / bs 4: one ReLU decision on a pre-activation that is zero up to rounding moves a generator
-    # gradient by up to ~1e-2 -- 4 samples x 8 channels average little out -- and every change of a summation order, e.g.
-    # round 5's short-reduction kernel for G.block1, re-rolls which entries those are; the features-64 fixtures keep 5e-3)
+    if size == "tiny":
+        # features 8 / bs 4: ONE ReLU decision on a pre-activation that is zero up to rounding moves a generator gradient
+        # by ~1e-2 (4 samples x 8 channels average little out), and every change of a summation order re-rolls which
+        # entries those are -- round 5 answered by loosening this guard's gradient floor to 1e-2.  Round 6: the tiny
+        # nets' gradients are held to the plain 1e-3 where that is well defined, on the reference's own decisions
+        # (*_tiny_pinned.npz: test_product_with_reference_mask_decisions... and test_default_path_gpu.py), and this
+        # un-pinned guard keeps what does not depend on a decision: forward quantities, buffers, first losses (1e-3),
+        # the optimizer plumbing below.
+        drop = lambda d: {k: v for k, v in d.items() if not k.startswith("grad")}      # noqa: E731
+        out, golden = drop(out), drop(golden)
     worst = compare(out, golden, TOL, f"hip {expt}/{size}", atol_scale=scale, cond=cond,
-                    final_abs=2 * 2 * LR[expt], grad_floor=1e-2 if size == "tiny" else 5e-3, report=True)
+                    final_abs=2 * 2 * LR[expt], grad_floor=5e-3, report=True)
     print(f"{expt}/{size}: worst {worst[3]} err {worst[1]:.2e} (bar {worst[2]:.2e})")
     # second pair: HIP loss vs the CPU oracle evaluated on the SAME (HIP-trained) parameters
     for tag in ("d", "g"):
@@ -94,21 +101,26 @@ def test_product_matches_stable_mask_fixture(expt):
     = 1.6e-3 -- the reference's own fp32-vs-fp64 pair shows exactly that (cond 5e-4 .. 7e-3 on the discriminator's
     second-pair gradients, <= 1e-4 elsewhere).  Hence max(1e-3, 10 cond) per quantity, as everywhere else.
 
-    Second-pair GENERATOR gradients (``grad1_g/*``), hologan only: 5e-2; the discriminator's second-pair gradients
-    keep the ordinary bar.  The discriminator's input gradient is a sum of nearly cancelling
-    contributions (|d loss / d image| = 0.07 against 15 inside the blocks), so ONE LeakyReLU decision of the G step
-    taken the other way moves the generator's gradients by up to 3.8e-2 (final_layer) -- measured in round 2 by
-    running this product with two split-K plans of the same ConvTranspose3d, i.e. a 1e-9 relative perturbation of
-    the volume: one plan lands on the reference's side of that 3e-7 margin, the other does not, every forward
-    quantity and every first-pair gradient agreeing to 1e-6 in both.  Which side an fp32 implementation lands on is
-    not a property the reference defines; the 1e-3 statement about BOTH steps' gradients is
-    test_hologan_step_gradients_with_pinned_masks, where the oracle takes the product's decisions."""
+    Second-pair GENERATOR gradients (``grad1_g/*``), hologan only: not compared here (round 6; rounds 2-5 carried a 5e-2
+    floor).  The discriminator's input gradient is a sum of nearly cancelling contributions (|d loss / d image| = 0.07
+    against 15 inside the blocks), so ONE LeakyReLU decision of the G step taken the other way moves the generator's
+    gradients by up to 3.8e-2 (final_layer) -- measured in round 2 by running this product with two split-K plans of the
+    same ConvTranspose3d, i.e. a 1e-9 relative perturbation of the volume: one plan lands on the reference's side of that
+    3e-7 margin, the other does not, every forward quantity and every first-pair gradient agreeing to 1e-6 in both.
+    Which side an fp32 implementation lands on is not a property the reference defines; the 1e-3 statements about the
+    generator step's gradients are the reference-decision tests (``hologan_full_pinned.npz``, both call orders)."""
     inputs, golden, cond = load_golden(expt, "full", stable=True)
     step = build_product_step(expt, "full", stable=True)
     out = scenario.run_scenario(step, inputs, "cuda", full=False, set_alpha=set_alpha, stable=True)
     scale = float(np.abs(golden["probe/logits"]).max())
-    worst = compare(out, golden, TOL, f"hip {expt}/full/stable", atol_scale=scale, cond=cond, report=True,
-                    pair1_grad_floor=5e-2 if expt == "hologan" else 0.0)
+    if expt == "hologan":
+        # round 6: the 5e-2 floor on these is gone.  One LeakyReLU decision of the G step (|pre-activation| 3e-7 in the
+        # reference) moves them by 3.8e-2 whichever implementation takes it; a bar that wide guards nothing, and the
+        # 1e-3 statement on the generator step's gradients exists on the reference's own decisions
+        # (test_hologan_with_reference_mask_decisions_every_gradient_at_1e3, test_default_path_gpu.py)
+        drop = lambda d: {k: v for k, v in d.items() if not k.startswith("grad1_g/")}      # noqa: E731
+        out, golden = drop(out), drop(golden)
+    worst = compare(out, golden, TOL, f"hip {expt}/full/stable", atol_scale=scale, cond=cond, report=True)
     print(f"{expt}/full/stable: worst {worst[3]} err {worst[1]:.2e} (bar {worst[2]:.2e})")
 
 
@@ -420,8 +432,9 @@ def test_full_size_batch_consistency():
     print("bs512 vs 8 x bs64:", {k: f"{v:.1e}" for k, v in worst.items()})
 
 
+@pytest.mark.parametrize("fixture", ["tiny", "full"])
 @pytest.mark.parametrize("expt", ["dc_gan", "wgan", "wgan_gp"])
-def test_product_with_reference_mask_decisions_every_gradient_at_1e3(expt):
+def test_product_with_reference_mask_decisions_every_gradient_at_1e3(expt, fixture):
     """The un-stabilised features-64 scenario with the ReLU / LeakyReLU decisions of the UNMODIFIED reference pinned
     (``*_full_pinned.npz``: ~7 M packed mask bits recorded by tests/golden/make_golden.py): the product takes exactly
     those decisions (tests/mask_pinning.py: fused op with ACT_NONE + where(mask, y, slope y) on the device), so no
@@ -437,14 +450,14 @@ def test_product_with_reference_mask_decisions_every_gradient_at_1e3(expt):
     pre-activations that are zero up to rounding."""
     from mask_pinning import pinned_module_masks, pinned_product_masks
     from test_oracle_golden import PINNED_KW, load_pinned, pinned_scale
-    inputs, golden, tape = load_pinned(expt)
-    scale = pinned_scale(expt)
+    inputs, golden, tape = load_pinned(expt, fixture)      # tiny: *_tiny_pinned.npz (features 8 / bs 4, round 6)
+    scale = pinned_scale(expt, fixture)
     torch.set_num_threads(min(16, torch.get_num_threads()))
     with pinned_module_masks(tape.rewind()):
-        cpu = scenario.run_scenario(build_oracle_step(expt, "full"), inputs, "cpu", full=True, set_alpha=set_alpha,
+        cpu = scenario.run_scenario(build_oracle_step(expt, fixture), inputs, "cpu", full=True, set_alpha=set_alpha,
                                     **PINNED_KW)
     assert tape.cursor == len(tape.masks)
-    product = build_product_step(expt, "full")
+    product = build_product_step(expt, fixture)
     product.real_first = False    # the reference's decisions are taped in ITS call order (G(z), D(real), D(fake))
     product.stack_d_passes = False
     with pinned_product_masks(tape.rewind()):
@@ -457,7 +470,7 @@ def test_product_with_reference_mask_decisions_every_gradient_at_1e3(expt):
     # a sanity bound on the diagnostic, not the parity bar (those follow): the entries the product alone would decide
     # differently are pre-activations within the 1e-3 tolerance of zero -- observed <= 7.8e-5 in round 3, 1.2e-4 once
     # the BatchNorm statistics of split launches come from the finish pass (other summation order), activations O(1)
-    assert flips <= 1e-4 * total and all(m[3] <= 3e-4 for m in tape.mismatches), tape.mismatches
+    assert flips <= max(4, 1e-4 * total) and all(m[3] <= 3e-4 for m in tape.mismatches), tape.mismatches
     assert set(hip) == set(cpu) == set(golden)
     worst = []
     for k, ref in cpu.items():
@@ -479,11 +492,14 @@ def test_product_with_reference_mask_decisions_every_gradient_at_1e3(expt):
     # and against the reference's own numbers (summaries)
     summ = {k: (v if np.asarray(v).ndim == 0 or not k.startswith(("grad", "final/")) else
                 scenario.summarize(torch.from_numpy(np.asarray(v)))) for k, v in hip.items()}
-    w = compare(summ, golden, TOL, f"hip {expt}/full/pinned vs reference", atol_scale=scale)
+    if fixture == "tiny":
+        summ = hip                  # the tiny fixture stores full tensors
+    w = compare(summ, golden, TOL, f"hip {expt}/{fixture}/pinned vs reference", atol_scale=scale)
     print(f"{expt}: product vs reference fixture, worst {w[3]} {w[1]:.1e}")
 
 
-def test_hologan_with_reference_mask_decisions_every_gradient_at_1e3():
+@pytest.mark.parametrize("fixture", ["tiny", "full"])
+def test_hologan_with_reference_mask_decisions_every_gradient_at_1e3(fixture):
     """HoloGAN's counterpart of the test above -- ``hologan_full_pinned.npz`` holds the ReLU / LeakyReLU
     decisions of the UNMODIFIED reference (in_planes 64, z 128, bs 8, plain closed-form parameters, non-right-angle
     views; one D step and one G step; 21 M decisions).  The product takes exactly those decisions: every fused op runs
@@ -494,10 +510,12 @@ def test_hologan_with_reference_mask_decisions_every_gradient_at_1e3():
     at 1e-5: test_oracle_takes_the_reference_mask_decisions_hologan), and against the reference's own recorded numbers.
     No conditioning slack, no second-pair floor."""
     from mask_pinning import pinned_oracle_masks, pinned_product_masks
-    from test_oracle_golden import PINNED_KW, PINNED_SIZE, drop_exact_zero_gradients, load_pinned, pinned_scale
+    from test_oracle_golden import (PINNED_KW, drop_exact_zero_gradients, load_pinned, pinned_scale,
+                                    pinned_scenario_size)
     expt = "hologan"
-    inputs, golden, tape = load_pinned(expt)
-    scale = pinned_scale(expt)
+    PINNED_SIZE = pinned_scenario_size(expt, fixture)      # tiny: hologan_tiny_pinned.npz (in_planes 8, bs 4; round 6)
+    inputs, golden, tape = load_pinned(expt, fixture)
+    scale = pinned_scale(expt, fixture)
     torch.set_num_threads(min(16, torch.get_num_threads()))
     oracle = build_oracle_step(expt, PINNED_SIZE)
     with pinned_oracle_masks(oracle, tape.rewind()):
@@ -517,7 +535,7 @@ def test_hologan_with_reference_mask_decisions_every_gradient_at_1e3():
     flips = sum(m[1] for m in tape.mismatches)
     print(f"hologan: the product alone would decide {flips} of {total} mask entries differently "
           f"(largest |pre-activation| among them {max([m[3] for m in tape.mismatches], default=0.0):.1e})")
-    assert flips <= 1e-4 * total and all(m[3] <= 3e-4 for m in tape.mismatches), tape.mismatches
+    assert flips <= max(4, 1e-4 * total) and all(m[3] <= 3e-4 for m in tape.mismatches), tape.mismatches
     cpu, hip, golden = (drop_exact_zero_gradients(d) for d in (cpu, hip, golden))
     assert set(hip) == set(cpu) == set(golden)
     worst = []
@@ -539,7 +557,9 @@ def test_hologan_with_reference_mask_decisions_every_gradient_at_1e3():
     assert worst[0][0] <= TOL, worst[:4]
     summ = {k: (v if np.asarray(v).ndim == 0 or not k.startswith(("grad", "final/")) else
                 scenario.summarize(torch.from_numpy(np.asarray(v)))) for k, v in hip.items()}
-    w = compare(summ, golden, TOL, "hip hologan/full/pinned vs reference", atol_scale=scale)
+    if fixture == "tiny":
+        summ = hip                  # the tiny fixture stores full tensors
+    w = compare(summ, golden, TOL, f"hip hologan/{fixture}/pinned vs reference", atol_scale=scale)
     print(f"hologan: product vs reference fixture, worst {w[3]} {w[1]:.1e}")
 
 
