@@ -33,7 +33,8 @@ using Cfg128x256 = TileCfg2<1, 4, 2, 2>;      // weight gradient with 128 output
 using Cfg256x64 = TileCfg2<2, 2, 1, 3>;
 
 enum TileId { T128x128 = 0, T128x64 = 1, T128x32 = 2, T64x64 = 3, T256x256 = 4, T256x128 = 5, T512x64 = 6, T128x256 = 7,
-              T256x64 = 8 };
+              T256x64 = 8,
+              T256x128P = 9 };   // (a label only: ConvDg5A2's 256 pixels x (2 column phases x 64 channels), gz_conv2d_tile)
 static bool is_tile2(TileId t) { return t >= T256x256; }
 
 // Which launches take the igemm2 skeleton: its workgroup is a whole CU's worth of matrix pipes (one wavefront per
@@ -1255,6 +1256,73 @@ static SplitPlan dgradtap2_plan(const ConvShape& s) {
     return SplitPlan{T256x128, splits < 1 ? 1 : splits};
 }
 
+// ---- 5x5 s2 p2 transposed convolution on row-shared LDS rows, both column phases per workgroup (gz_igemm2.h: ConvDg5A2,
+// DgPairB2, EpiPhasePairB; round 6).  Grid phases y = py (two); columns = (px, channel): N = 2 C.  The reduction of row
+// phase py has 9 K/16 (py = 0) / 6 K/16 (py = 1) chunks; a launch with too few tiles cuts it into pieces of equal length
+// (slabs + the finish pass), each row phase getting as many pieces as its length asks for.
+struct Dg5Plan {
+    bool ok;
+    int splits;          // of the LONGER phase (py = 0); launch_igemm2 derives chunks_per_split from it
+    int nz0, nz1;        // slabs per row phase (1, 1 = unsplit)
+};
+template <class G>
+static bool dgrad5_shape_ok(const ConvShape& s) {
+    return G::kh == 5 && G::kw == 5 && G::s == 2 && G::p == 2 && !knobs().no_igemm2 && !knobs().no_dg5 && s.H == 2 * s.OH &&
+           s.W == 2 * s.OW && s.OW % 4 == 0 && 256 % s.OW == 0 && s.K % 16 == 0 && s.K >= 32 && s.C % 64 == 0 &&
+           dgrad_tap_major(s.K, 5, 5, 2) && (long long)s.N * s.OH * s.OW >= 256;
+}
+template <class G>
+static Dg5Plan dgrad5_plan(const ConvShape& s) {
+    Dg5Plan p{false, 1, 1, 1};
+    if (!dgrad5_shape_ok<G>(s)) return p;
+    const long long M = (long long)s.N * s.OH * s.OW;
+    const long long tiles = ((M + 255) / 256) * (s.C / 64);
+    const int c0 = 9 * s.K / 16, c1 = 6 * s.K / 16;
+    // too little work (< ~0.5 GFLOP) for 256-pixel tiles on a whole chip: the small-tile kernels keep it
+    if (tiles * (c0 + c1) < 1LL * cus() * knobs().dg5_min_units) return p;
+    const long long want = (long long)knobs().dg5_wgs * cus() / 256;
+    if (tiles * 2 >= want * 3 / 4) {                               // unsplit: >= 1.5 workgroups per CU
+        p.ok = true;
+        return p;
+    }
+    // Launches that have to cut their reduction stay on the gather loader by default.  Measured (tools/tap_bench.py 64,
+    // tools/ab_dg5.sh, round 6): the two row phases cost 3 : 2, their pieces pack badly into 512 workgroup slots, and
+    // the finish pass reads 5-20 slabs of 2 C columns -- 92-95 TFLOP/s against the gather loader's 99 on EXT-128's
+    // D.block2 / 3, 55-60 against 67-84 on the 6.7-GFLOP layers of the 64 x 64 critic.  GZ_DG5_SPLIT=1 (experiments).
+    if (!knobs().dg5_split) return p;
+    p.ok = true;
+    long long cps = (tiles * (c0 + c1) + want - 1) / want;         // chunks per workgroup for ~want workgroups
+    if (cps < knobs().dg5_min_chunks) cps = knobs().dg5_min_chunks;
+    if (cps >= c0) return p;
+    p.splits = (int)((c0 + cps - 1) / cps);
+    const int per = (c0 + p.splits - 1) / p.splits;               // (= launch_igemm2's chunks_per_split)
+    p.nz0 = (c0 + per - 1) / per;
+    p.nz1 = (c1 + per - 1) / per;
+    if (p.nz0 <= 1) { p.splits = p.nz0 = p.nz1 = 1; }
+    return p;
+}
+template <class G>
+static size_t dgrad5_ws_bytes(const ConvShape& s) {
+    const Dg5Plan p = dgrad5_plan<G>(s);
+    if (!p.ok || p.nz0 <= 1) return 0;
+    return (size_t)(p.nz0 + p.nz1) * (size_t)s.N * s.OH * s.OW * (size_t)(2 * s.C) * 4;
+}
+static int run_dgrad5pair(const float* y, const float* wp, float* x, const ConvShape& s, hipStream_t st, const Dg5Plan& plan,
+                          float* slab) {
+    using Cfg = Cfg256x128;
+    using AL = ConvDg5A2<Cfg::BM>;
+    using BL = DgPairB2;
+    using Epi = EpiPhasePairB;
+    const int AH = s.OH, AW = s.OW;
+    typename AL::Params pa{y, s, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW)};
+    typename BL::Params pb{wp, s.K, s.C, round4(s.C)};
+    const int M = s.N * AH * AW;
+    typename Epi::Params pe{x, M, s.C, s.H, s.W, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW), nullptr, ACT_NONE, 0.f,
+                            nullptr, 0};
+    int pc[8] = {9 * s.K / 16, 6 * s.K / 16, 0, 0, 0, 0, 0, 0};
+    return launch_igemm2<Cfg, AL, BL, Epi>(pa, pb, pe, M, 2 * s.C, 9 * s.K, 2, plan.splits, st, plan.nz0 > 1 ? slab : nullptr, pc);
+}
+
 template <class G>
 static bool dgrad2_ok(const ConvShape& s) {
     // ConvDgA2: 16-byte pieces of whole pixel quads; a tile's first pixel starts an image row (256 % AW == 0)
@@ -1302,7 +1370,10 @@ static size_t dgrad_ws_bytes(const ConvShape& s) {
     constexpr int TAPS = ((G::kh + G::s - 1) / G::s) * ((G::kw + G::s - 1) / G::s);
     if (s.H % G::s || s.W % G::s || dgrad_direct<G>(nullptr, s)) return 0;
     const int kk = dgrad_tap_major(s.K, G::kh, G::kw, G::s) ? round_bk(s.K) : s.K;
-    return split_bytes(dgrad_plan<G>(s), (long long)s.N * (s.H / G::s) * (s.W / G::s), s.C, kk * TAPS, G::s * G::s);
+    const size_t b = split_bytes(dgrad_plan<G>(s), (long long)s.N * (s.H / G::s) * (s.W / G::s), s.C, kk * TAPS, G::s * G::s);
+    // (ConvDg5A2 needs aligned tensors, known only at the launch: the workspace serves either path)
+    const size_t b5 = dgrad5_ws_bytes<G>(s);
+    return b > b5 ? b : b5;
 }
 
 template <class G>
@@ -1328,6 +1399,13 @@ static int dispatch_dgrad(const float* y, const float* wp, const float* bias, fl
         }
     }
     long long M = (long long)s.N * (s.H / G::s) * (s.W / G::s);
+    if constexpr (G::kh == 5 && G::kw == 5 && G::s == 2 && G::p == 2) {
+        if (!bias && act == ACT_NONE && (((uintptr_t)y | (uintptr_t)x | (uintptr_t)wp) & 15) == 0) {
+            const Dg5Plan p5 = dgrad5_plan<G>(s);
+            if (p5.ok && (p5.nz0 <= 1 || (ws && ws_bytes >= dgrad5_ws_bytes<G>(s))))
+                return run_dgrad5pair(y, wp, x, s, st, p5, ws);
+        }
+    }
     SplitPlan sp = dgrad_plan<G>(s);
     if (sp.splits > 1 && (!ws || ws_bytes < dgrad_ws_bytes<G>(s))) sp = SplitPlan{pick_tile(M, s.C, G::s * G::s), 1};
     float* slab = sp.splits > 1 ? ws : nullptr;
@@ -2915,6 +2993,10 @@ int gz_conv2d_tile(int op, int N, int C, int H, int W, int K, int OH, int OW, in
                 if (is_tile2(sp.tile)) return sp.tile;
             }
         }
+        if (KH == 5 && KW == 5 && S == 2) {
+            ConvShape s{N, C, H, W, K, OH, OW};
+            if (dgrad5_plan<G5522>(s).ok) return T256x128P;
+        }
         if ((KH == 5 && KW == 5 && S == 2) || (KH == 3 && KW == 3 && S == 1) || (KH == 1 && KW == 1 && S == 1)) {
             ConvShape s{N, C, H, W, K, OH, OW};
             const SplitPlan pt = KH == 5 ? dgradtap2_plan<G5522>(s) : KH == 3 ? dgradtap2_plan<G3311>(s) : dgradtap2_plan<G1110>(s);
@@ -2964,6 +3046,7 @@ static const char* tile_text(TileId t) {
         case T256x128: return "256x128";
         case T512x64: return "512x64";
         case T256x64: return "256x64";
+        case T256x128P: return "256x(2x64)";
         default: return "128x256";
     }
 }
@@ -3017,6 +3100,12 @@ static int describe_dgrad(const ConvShape& s, char* b, size_t n) {
     }
     if (G::kh == 5 && G::kw == 5 && G::s == 2 && G::p == 2 && dgrad_direct5_ok(nullptr, nullptr, s))
         return snprintf(b, n, "Dg direct dgrad_smallc4_k5s2p2<C=%d,KS=%d>", s.C, smallc_split(M / 4, s.K));
+    if constexpr (G::kh == 5 && G::kw == 5 && G::s == 2 && G::p == 2) {
+        const Dg5Plan p5 = dgrad5_plan<G>(s);
+        if (p5.ok)
+            return snprintf(b, n, "Dg igemm2<256x128=(px,64)> ConvDg5A2(row-shared, LDS-DMA 16B, px pair) slabs=%d+%d "
+                                  "(no bias / activation, aligned tensors; else the gather loader)", p5.nz0, p5.nz1);
+    }
     constexpr int TAPS = ((G::kh + G::s - 1) / G::s) * ((G::kw + G::s - 1) / G::s);
     const SplitPlan sp = dgrad_plan<G>(s);
     const int rows = gz_conv2d_dgrad_stats_rows(s.N, s.C, s.H, s.W, s.K, s.OH, s.OW, G::kh, G::kw, G::s, G::p);

@@ -306,6 +306,127 @@ struct ConvDgTapA2 {
     }
 };
 
+// ---- round 6: the 5x5 s2 p2 TRANSPOSED convolution, row-shared (HoloGAN's critic, input gradients) -------------------
+// ConvDgTapA2 above gathers a chunk per (tap, 16 channels): the 9 / 6 / 6 / 4 taps of the four output phases each fetch
+// the SAME gradient rows again, 4 bytes per lane and instruction, and every phase stores every other float of a row
+// (EXT-128 D.block1: 6.8x its algorithmic bytes).  But along m = (n, a, b) the operand IS contiguous in memory --
+//   dx[2a + py][2b + px] = sum_{ty < ny, tx < nx}  dy[a + 1 - ty][b + 1 - tx] . w[py + 2 ty][px + 2 tx],  ny = 3 - py, nx = 3 - px
+// -- so the row-shared form of ConvDgA2 applies: an LDS row = 256 consecutive pixels of ONE (feature channel, ty),
+// fetched once by a 16-byte LDS-DMA piece, the horizontal taps applied as shifts on the fragment read (zero column for
+// the lanes at an image row's edge).  What is new against k4 s2 p1:
+//   * the workgroup computes BOTH column phases px = 0 / 1 of its row phase py (y = py: two grid phases, not four).
+//     Their part-A taps are the same two shifts (+1, 0), so they share the A fragments outright and the B image is the
+//     ordinary 128-column one with columns = (px, channel): accumulator block j is px, and the epilogue stores the two
+//     as one 8-byte pair (EpiPhasePairB);
+//   * DUAL MODE: px = 0 has a third tap (shift -1).  The reduction is  part A: chunks of 8 LDS rows x 2 shifts on all
+//     128 columns (the row-shared k-step: half-wave = shift), then  part B: chunks of 16 LDS rows x the one shift on
+//     the px = 0 columns only (plain k-step: half-wave = next row; MFMAs on accumulator block 0 only).  Chunk counts
+//     per py: 9 K/16 and 6 K/16 -- exactly the 9 + 6 | 6 + 4 taps of the phases it replaces;
+//   * the weights are read from the EXISTING tap-major pack (pack_dgrad_tap: [phase (py, px)][tap = ty * nx + tx][ko][C])
+//     by a B loader that picks the right rows (DgPairB2): no second packed image, no pack-cache changes.
+// Needs AH = OH, AW = OW a multiple of 4 dividing 256, K % 16 == 0, C % 64 == 0, 16-byte aligned tensors, no bias /
+// activation (an input gradient).  Reference: core/models/hologan_discriminator.py:7-23 (Conv2d k5 s2 p2).
+template <int BM>
+struct ConvDg5A2 {
+    static_assert(BM == 256, "one 256-pixel piece per LDS row");
+    using Params = typename ConvDgALoaderTap<BM, 5, 5, 2, 2>::Params;
+    static constexpr int LD = BM + 4, ROWS = BK, PIECES = 4;
+    static constexpr int ZERO_COL = BM;
+    static constexpr bool ROWSHARE = true, DUALMODE = true;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff0, voff1, voff2;      // [ty]: this lane's pixel quad in row a + 1 - ty (out of range: outside the image / ty >= ny)
+    int wave, K, OHW, chunksA;         // (three scalars, not an array: a ty-indexed array ends up in scratch)
+    __device__ __forceinline__ void init(const Params& p, int tile, int py, int tid) {
+        const ConvShape& s = p.s;
+        rsrc = make_rsrc(p.y, (uint32_t)s.N * s.K * s.OH * s.OW * 4u);
+        const int lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        K = s.K; OHW = s.OH * s.OW;
+        const int ny = 3 - py;
+        chunksA = ny * K / 8;
+        const uint32_t m = (uint32_t)tile * BM + lane * 4;
+        const bool m_ok = m < (uint32_t)s.N * p.AH * p.AW;
+        const uint32_t n = fdiv(m, p.div_ahw);
+        const uint32_t pix = m - n * (uint32_t)(p.AH * p.AW);
+        const uint32_t a = fdiv(pix, p.div_aw);
+        const uint32_t b = pix - a * (uint32_t)p.AW;
+        auto row = [&](int ty) {
+            const int oy = (int)a + 1 - ty;
+            const bool ok = m_ok && ty < ny && (unsigned)oy < (unsigned)s.OH;
+            return ok ? (n * (uint32_t)(s.K * OHW) + (uint32_t)(oy * s.OW) + b) * 4u : OOB;
+        };
+        voff0 = row(0); voff1 = row(1); voff2 = row(2);
+    }
+    __device__ __forceinline__ int frag_shift(int half) const { return half ? 0 : 1; }      // part A: tx = half-wave
+    __device__ __forceinline__ void issue_piece(int kc, float* stage, int p, bool live) {
+        // part A: 8 rows per chunk (this wavefront: rows 2w, 2w + 1; its pieces 2, 3 are fillers -- every chunk must
+        // issue the same number of loads, the counted s_waitcnt vmcnt depends on it); part B: 16 rows (4w .. 4w + 3)
+        const bool partA = kc < chunksA;
+        if (partA && p >= 2) {
+            bload_lds16(rsrc, stage + (8 + wave * 2 + (p - 2)) * LD, OOB, SOFF_OOB);
+            return;
+        }
+        const int row = partA ? wave * 2 + p : wave * 4 + p;
+        const int r = partA ? kc * 8 + row : (kc - chunksA) * 16 + row;          // (ty, ko), ty-major: r = ty * K + ko
+        const int ty = (r >= K) + (r >= 2 * K);
+        const int ko = r - ty * K;
+        // (masks, not a select chain: the compiler turns `ty == 0 ? voff0 : ...` into a ty-indexed table in scratch)
+        const uint32_t m0 = 0u - (uint32_t)(ty == 0), m1 = 0u - (uint32_t)(ty == 1), m2 = 0u - (uint32_t)(ty == 2);
+        const uint32_t v = (voff0 & m0) | (voff1 & m1) | (voff2 & m2);
+        bload_lds16(rsrc, stage + row * LD, v, live ? (uint32_t)ko * (uint32_t)OHW * 4u : SOFF_OOB);
+    }
+};
+
+// B operand of ConvDg5A2: the [16 k][128 = (wn, px, 32 channels)] image of a chunk, gathered row-wise out of the tap-major
+// dgrad pack of a 5x5 s2 p2 weight (gz_conv.hip pack_dgrad_tap_body: phase (py, px) at phase * 9 * K * ldc floats, row
+// (ty * nx + tx) * K + ko, nx = 3 - px).  A piece = two k rows x 128 columns (lane = (k row, 4 columns)):
+//   part A, chunk row r = (ty, ko):  k rows (r, tx = 0), (r, tx = 1) of BOTH phases' images -- the lane's phase and
+//           tap offsets are per-lane constants, ty enters through a per-lane stride (nx differs between the phases);
+//   part B, rows (ty, ko), (ty, ko + 1) at tx = 2 of phase (py, 0); the px = 1 columns are never multiplied (zeros).
+struct DgPairB2 {
+    struct Params {
+        const float* wp;
+        int K, C, ldc;                  // feature channels (multiple of 16), image-side channels, row pitch of the pack
+    };
+    static constexpr int LD = 128, ROWS = BK, PIECES = 2;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t vA, vA_step, vB, ldb;
+    int wave, K, chunksA;
+    __device__ __forceinline__ void init(const Params& p, int tile, int py, int tid) {
+        const uint32_t phase_floats = 9u * (uint32_t)p.K * (uint32_t)p.ldc;
+        rsrc = make_rsrc(p.wp, 4u * phase_floats * 4u);
+        const int lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        K = p.K;
+        chunksA = (3 - py) * p.K / 8;
+        const int t = lane >> 5, q = (lane & 31) * 4;             // k row inside the piece, first of 4 image columns
+        const int px = (q & 63) >> 5;
+        const int ch = tile * 64 + (q >> 6) * 32 + (q & 31);
+        const bool ok = ch < p.C;
+        ldb = (uint32_t)p.ldc * 4u;
+        const uint32_t phase = (uint32_t)(py * 2 + px) * phase_floats;
+        vA = ok ? (phase + (uint32_t)t * (uint32_t)(p.K * p.ldc) + (uint32_t)ch) * 4u : OOB;
+        vA_step = ok ? (uint32_t)(3 - px) * (uint32_t)(p.K * p.ldc) * 4u : 0u;
+        vB = (ok && px == 0) ? ((uint32_t)(py * 2) * phase_floats + (uint32_t)t * (uint32_t)p.ldc + (uint32_t)ch) * 4u : OOB;
+    }
+    __device__ __forceinline__ void issue_piece(int kc, float* stage, int p, bool live) {
+        const int piece = wave * PIECES + p;
+        uint32_t v, so;
+        if (kc < chunksA) {
+            const int r = kc * 8 + piece;
+            const int ty = (r >= K) + (r >= 2 * K);
+            v = vA + (uint32_t)ty * vA_step;
+            so = (uint32_t)(r - ty * K) * ldb;
+        } else {
+            const int r = (kc - chunksA) * 16 + piece * 2;
+            const int ty = (r >= K) + (r >= 2 * K);
+            v = vB;
+            so = (uint32_t)((ty * 3 + 2) * K + (r - ty * K)) * ldb;
+        }
+        bload_lds16(rsrc, stage + piece * 256, v, live ? so : SOFF_OOB);
+    }
+};
+
 // 1x1 stride-1 layers are plain GEMMs over an NCHW tensor: A[k = channel][m = (n, pixel)], 256 consecutive rows of a
 // channel are 1 KB of contiguous memory whenever H*W is a multiple of 4 (a lane's 16-byte quad never straddles two
 // samples).  One 16-byte LDS-DMA piece per LDS row instead of the gather's four 4-byte ones (HoloGAN's 1024 -> 1024
@@ -541,6 +662,12 @@ __device__ __forceinline__ void mfma_row(f32x16 (&c)[1], float a, const float (&
                  : "+a"(c[0])
                  : "v"(a), "v"(b[0]));
 }
+__device__ __forceinline__ void mfma_one(f32x16& c, float a, float b) {      // dual mode, part B: accumulator block 0 only
+    asm volatile(GZ2_NOP
+                 "v_mfma_f32_32x32x2_f32 %0, %2, %1, %0"
+                 : "+a"(c)
+                 : "v"(a), "v"(b));
+}
 // D[m][n] order (lanes along n): row-major outputs (weight gradient slabs)
 __device__ __forceinline__ void mfma_row_mn(f32x16 (&c)[4], float a, const float (&b)[4]) {
     asm volatile(GZ2_NOP
@@ -600,6 +727,8 @@ __global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel
     static_assert(KG == 1 || (KG == 2 && TN <= 2), "two wave groups: the parked accumulators must fit the LDS");
     constexpr bool RS = is_rowshare<AL>::value;
     constexpr bool FR = is_fwdrows<AL>::value;
+    constexpr bool DM = is_dualmode<AL>::value;      // (ConvDg5A2) chunks >= al.chunksA are plain chunks on accumulator block 0
+    static_assert(!DM || (RS && KG == 1 && TN == 2), "dual mode: row-shared loader, px pair in the two accumulator blocks");
     constexpr int A_EXTRA = igemm2_a_extra<AL>();
     constexpr int A_ELEMS = AL::ROWS * LDA + A_EXTRA, B_ELEMS = BL::ROWS * LDB;
     constexpr int STAGE = A_ELEMS + B_ELEMS;
@@ -691,6 +820,14 @@ __global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel
             ring[st * STAGE + B_ELEMS + (q >> 2) * LDA + AL::ZERO_COL + (q & 3)] = 0.f;
         }
     }
+    uint32_t a_addrB[TM];          // dual mode, part B: half-wave = next LDS row, ONE shift (-1) for both
+    if constexpr (DM) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int b = (tile_m * Cfg::BM + wm * TM * 32 + i * 32 + l32) % pa.AW;
+            a_addrB[i] = lds0 + (uint32_t)(B_ELEMS + half * LDA + (b == 0 ? AL::ZERO_COL : wm * TM * 32 + i * 32 + l32 - 1)) * 4u;
+        }
+    }
     uint32_t a_odd[TM];            // forward-row images: the odd k-steps' addresses (a_addr: the even ones)
     if constexpr (FR) {
 #pragma unroll
@@ -720,6 +857,15 @@ __global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel
         else bl.issue_piece(kc, sb, p - NPA, live);
     };
     // k-step S of the stage whose byte offset is `so`: raw fragments
+    auto fetch_b = [&](auto Sc, uint32_t so, float (&af)[TM], float (&bf)[TN]) {      // dual mode, part B
+        constexpr int S = decltype(Sc)::value;
+        constexpr int AO = 2 * LDA * S * 4, BO = 2 * S * LDB * 4;
+        af[0] = lds_rd<AO>(a_addrB[0] + so);
+        af[1] = lds_rd<AO>(a_addrB[1] + so);
+        af[2] = lds_rd<AO>(a_addrB[2] + so);
+        af[3] = lds_rd<AO>(a_addrB[3] + so);
+        bf[0] = lds_rd<BO>(b_addr + so);
+    };
     auto fetch = [&](auto Sc, uint32_t so, float (&af)[TM], float (&bf)[TN]) {
         constexpr int S = decltype(Sc)::value;
         constexpr int AO = (RS ? LDA : 2 * LDA) * S * 4, BO = 2 * S * LDB * 4;
@@ -770,18 +916,41 @@ __global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel
 #ifdef GZ2_STEP_STAMPS
         unsigned long long step_cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, step_t = __builtin_amdgcn_s_memtime();
 #endif
-        fetch(std::integral_constant<int, 0>{}, 0u, af[0], bf[0]);
+        int chunksA = 0x7fffffff;              // dual mode: first plain chunk
+        if constexpr (DM) {
+            chunksA = al.chunksA;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[q][j] = 0.f;
+            if (kc0 >= chunksA) fetch_b(std::integral_constant<int, 0>{}, 0u, af[0], bf[0]);
+            else fetch(std::integral_constant<int, 0>{}, 0u, af[0], bf[0]);
+        } else {
+            fetch(std::integral_constant<int, 0>{}, 0u, af[0], bf[0]);
+        }
         lgkm_done(af[0], bf[0]);
         mask(af[0]);
         int stage = 0;
-        for (int kc = kc0; kc < kend; ++kc) {
+        // (dual mode: the row-shared chunks and the plain chunks are TWO loops, one after the other -- a per-chunk branch
+        // between the two k-step forms inside one loop made the register allocator spill accumulators in every iteration)
+        auto run_chunks = [&](int k_from, int k_to, auto MBc) {
+        for (int kc = k_from; kc < k_to; ++kc) {
             int s1 = stage + 1; if (s1 >= STAGES2) s1 -= STAGES2;
             int s2 = s1 + 1; if (s2 >= STAGES2) s2 -= STAGES2;
             const uint32_t so = (uint32_t)(stage * STAGE * 4), sno = (uint32_t)(s1 * STAGE * 4);
             const bool more = kc + 2 < kc1;
             auto kstep = [&](auto Sc) {
                 constexpr int S = decltype(Sc)::value;
+                constexpr bool MB = decltype(MBc)::value;        // dual mode, part B: plain chunk, accumulator block 0 only
                 constexpr int c = S & 1, n = c ^ 1;
+                auto mfma_row = [&](f32x16 (&cc)[TN], float a, const float (&b)[TN]) {
+                    if constexpr (MB) gz::mfma_one(cc[0], a, b[0]);
+                    else gz::mfma_row(cc, a, b);
+                };
+                auto fetch_same = [&](auto S2c, uint32_t o, float (&fa)[TM], float (&fb)[TN]) {
+                    if constexpr (MB) fetch_b(S2c, o, fa, fb);
+                    else fetch(S2c, o, fa, fb);
+                };
                 // chunk kc+2's pieces go out in the FIRST k-steps, PPS per step, one behind each MFMA row (the stage
                 // they overwrite was last read in chunk kc-1, behind its barrier), so that by the last k-step exactly
                 // NP are in flight
@@ -792,7 +961,7 @@ __global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel
                     if constexpr (r >= 0 && r < PPS && q < NP) issue_piece(kc + 2, s2, q, more);
                 };
                 if constexpr (S + 1 < STEPS) {
-                    fetch(std::integral_constant<int, S + 1>{}, so, af[n], bf[n]);
+                    fetch_same(std::integral_constant<int, S + 1>{}, so, af[n], bf[n]);
                     mfma_row(acc[0], af[c][0], bf[c]);
                     pieces(std::integral_constant<int, 0>{});
                     mfma_row(acc[1], af[c][1], bf[c]);
@@ -817,7 +986,12 @@ __global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel
 #ifndef GZ2_EXP_NOBARRIER
                     __builtin_amdgcn_s_barrier();
 #endif
-                    fetch(std::integral_constant<int, 0>{}, sno, af[n], bf[n]);
+                    if constexpr (DM) {      // the next chunk's first fragments, in ITS mode
+                        if (kc + 1 >= chunksA) fetch_b(std::integral_constant<int, 0>{}, sno, af[n], bf[n]);
+                        else fetch(std::integral_constant<int, 0>{}, sno, af[n], bf[n]);
+                    } else {
+                        fetch(std::integral_constant<int, 0>{}, sno, af[n], bf[n]);
+                    }
                     mfma_row(acc[2], af[c][2], bf[c]);
                     mfma_row(acc[3], af[c][3], bf[c]);
                 }
@@ -840,6 +1014,13 @@ __global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel
             kstep(std::integral_constant<int, 6>{});
             kstep(std::integral_constant<int, 7>{});
             stage = s1;
+        }
+        };
+        if constexpr (DM) {
+            run_chunks(kc0, min(kend, chunksA), std::false_type{});
+            run_chunks(max(kc0, chunksA), kend, std::true_type{});
+        } else {
+            run_chunks(kc0, kend, std::false_type{});
         }
         // drain the LDS-DMA queue; MFMA results must have retired before the epilogue's v_accvgpr_read (the hazard
         // recognizer does not look inside the asm statements)
@@ -1433,7 +1614,7 @@ template <class T>
 struct is_tapgather<T, std::void_t<decltype(T::TAPGATHER)>> : std::true_type {};
 template <class Cfg, class AL>
 constexpr bool igemm2_kg2_built() {
-    return Cfg::TN <= 2 && Cfg::WM * Cfg::WN == 4 && Cfg::WN == 2 &&
+    return Cfg::TN <= 2 && Cfg::WM * Cfg::WN == 4 && Cfg::WN == 2 && !is_dualmode<AL>::value &&
            (is_rowshare<AL>::value || is_fwdrows<AL>::value || is_tapgather<AL>::value);
 }
 inline bool igemm2_use_kg2(long long workgroups, int chunks_per_workgroup) {

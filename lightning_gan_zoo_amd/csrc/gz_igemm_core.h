@@ -76,6 +76,12 @@ template <class T, class = void>
 struct is_rowshare : std::false_type {};
 template <class T>
 struct is_rowshare<T, std::void_t<decltype(T::ROWSHARE)>> : std::true_type {};
+// (round 6) a row-shared loader whose reduction has a SECOND part of plain chunks (ConvDg5A2: the third horizontal tap of
+// the 5x5 s2 p2 transposed convolution's even columns), see igemm2_kernel
+template <class T, class = void>
+struct is_dualmode : std::false_type {};
+template <class T>
+struct is_dualmode<T, std::void_t<decltype(T::DUALMODE)>> : std::true_type {};
 
 template <class Cfg, class AL, class BL, class Epi>
 __global__ __launch_bounds__(NT, GZ_IGEMM_WAVES_PER_SIMD) void igemm_kernel(typename AL::Params pa, typename BL::Params pb,

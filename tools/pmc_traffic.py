@@ -41,6 +41,8 @@ def label_of(name):
         op = "Wg"
     else:
         return None
+    if loader == "ConvDg5A2":          # (round 6) 256 pixels x (2 column phases x 64 channels): bench.py's label
+        return "igemm<Dg,256x(2x64)>"
     return "igemm<%s,%dx%d>" % (op, wm * tm * 32, wn * tn * 32)
 
 
