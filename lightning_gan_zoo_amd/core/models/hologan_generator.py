@@ -95,6 +95,7 @@ def view_inverse_matrices(view, size=16, new_size=16):
 
 class Generator(nn.Module):
     gates_parameters = True      # every layer announces its parameters with F.ready before reading them (ddp.GradSync)
+    _warned_numpy_touched = False
 
     def __init__(self, in_planes, out_planes, z_planes, view_args, img_size, view_planes=6, gpu=True,
                  ext128=False):
@@ -199,7 +200,20 @@ class Generator(nn.Module):
             return minv
         if untouched:                    # another batch size (an epoch's last batch), or an explicit view: undo the
             np.random.set_state(before)  # provisional draw
-        return None                      # (generator touched by someone else: their state stands)
+            return None
+        # Someone used numpy's global generator between the provisional draw and this forward.  A RESEED (tests, a
+        # resumed run) makes the provisional draw irrelevant: the view is drawn below from the new state, as the
+        # reference would.  A DRAW cannot be told from a reseed here and cannot be undone: numpy's stream then reads
+        # (view, other, view) where the reference reads (other, view) -- loudly, once, instead of silently (ADVICE r5;
+        # nothing in this package draws there during training: eval.py's KID subsets follow a generator forward).
+        if not Generator._warned_numpy_touched:
+            Generator._warned_numpy_touched = True
+            import warnings
+            warnings.warn("HoloGAN: numpy's global generator was used between a training step and the next generator "
+                          "forward; the view prefetched for that forward is dropped and drawn again.  After a reseed that "
+                          "is exactly the reference's stream; after another draw it is not (call "
+                          "generator.prefetch_view = lambda n: None to draw views inside forward() only).", stacklevel=3)
+        return None
 
     def forward(self, z, view_in=None):
         n = z.shape[0]

@@ -179,3 +179,25 @@ def evaluate(module, dump, feature_fn, real_act, n_subsets=100):
     fid = frechet_distance(real_mu, real_sigma, fake_mu, fake_sigma)
     kid = polynomial_mmd_averages(np.asarray(real_act), fake_act, n_subsets=n_subsets)
     return {"fid": fid, "kid": float(kid[0].mean()), "kid_std": float(kid[0].std())}
+
+
+def fid_from_weight_file(module, real_images_u8, weights=None, n_samples=5000, batch_size=16, n_subsets=100):
+    """FID / KID end to end (reference core/callback_inception_metrics.py:183-246): the fixed latent set, the eval-mode
+    generator sweep, InceptionV3 pool features on the HIP kernels with the reference's weight FILE, Frechet distance and
+    KID.  ``weights``: path of pytorch-fid's ``pt_inception-2015-12-05-6726825d.pth`` (default: the ``GZ_FID_WEIGHTS``
+    environment variable; the reference downloads it, metrics/inception.py:13 -- there is no network here); the file's
+    sha256 prefix is verified.  ``real_images_u8``: uint8 [n, H, W, 3] real images, or None to compare the generated
+    set with itself (a self-check: FID 0)."""
+    import os
+    from .inception import InceptionFeatures, load_fid_weights
+    weights = weights or os.environ.get("GZ_FID_WEIGHTS")
+    if not weights:
+        raise RuntimeError("lightning_gan_zoo_amd.eval: FID needs the published Inception weight file; pass weights=<path> "
+                           "or set GZ_FID_WEIGHTS (pt_inception-2015-12-05-6726825d.pth)")
+    features = InceptionFeatures(load_fid_weights(weights, module.device), batch_size)
+    dump = SampleDump(module, n_samples, batch_size)
+    if real_images_u8 is None:
+        real_act = np.concatenate([np.asarray(features(img)) for img in dump.images(module)], axis=0)
+    else:
+        real_act = features(real_images_u8)
+    return evaluate(module, dump, features, real_act, n_subsets=n_subsets)
