@@ -6,7 +6,7 @@
  *   core/lightning_module.py:104-128,158-207     (DCGAN / WGAN / WGANGP training_step)
  *   core/utils/utils.py:39-58                    (gradient_penalty)
  * Each entry point below replaces the aten operator(s) named in its comment; the Python side
- * (lightning_gan_zoo_amd/functional.py) binds them with ctypes and wraps them in
+ * (lightning_gan_zoo_amd/functional/) binds them with ctypes and wraps them in
  * torch.autograd.Function objects (see INTEGRATION.md for the binding a maintainer would add).
  *
  * Conventions

@@ -493,7 +493,7 @@ __global__ __launch_bounds__(PW_THREADS) void norm_bwd_rowsums_kernel(const floa
 // BatchNorm: combine row sums over n -> k[0*C] = mean(dz), k[1*C] = mean(dz*xh); dgamma, dbeta.
 // One wavefront per channel.
 // (statistics groups: k per (group, channel); the affine gradients sum over the groups.  accumulate != 0: dgamma /
-// dbeta already hold earlier contributions -- the gradient sink of functional.py -- and are added to)
+// dbeta already hold earlier contributions -- the gradient sink of functional/_base.py -- and are added to)
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const f32x2* __restrict__ sums, float* __restrict__ k,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                              int N, int C, int inner, int groups, int accumulate) {

@@ -24,7 +24,7 @@ def _free_port():
 
 
 def test_post_accumulate_hook_fires_once_for_none_gradients():
-    """What functional's gradient sinks + ddp.GradSync rely on (functional.py, "WHEN a sunk parameter's gradient is
+    """What functional's gradient sinks + ddp.GradSync rely on (functional/_base.py, "WHEN a sunk parameter's gradient is
     complete"): a parameter's post-accumulate-grad hook runs ONCE per backward pass, after every node that uses the
     parameter has run -- also when those nodes return None for it (the sink took the gradient), and also when part of
     the uses were created by a double backward."""
