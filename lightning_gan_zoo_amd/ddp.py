@@ -160,7 +160,7 @@ def pick_tail(net, bucket_bytes=BUCKET_BYTES, min_bytes=MIN_BUCKET_BYTES):
 class GradSync:
     """Plugs into harness.Trainer: ``before_step``, ``after_backward``, ``flush``."""
 
-    def __init__(self, module, process_group=None, overlap=True, bucket_bytes=BUCKET_BYTES, broadcast_buffers=False,
+    def __init__(self, module, process_group=None, overlap=True, bucket_bytes=BUCKET_BYTES, broadcast_buffers=None,
                  defer_tail=None, tail_min_bytes=MIN_BUCKET_BYTES):
         self.module = module
         # torch DDP (the reference's accelerator="ddp", run_network.py:66) broadcasts rank 0's buffers -- the BatchNorm
@@ -171,7 +171,13 @@ class GradSync:
         # per-rank buffers during training, rank 0's at every checkpoint (sync_buffers) -- one collective per
         # checkpoint instead of one per step; ``broadcast_buffers=True`` reproduces DDP's per-step broadcast (one
         # coalesced broadcast per dtype at the top of each training_step).  tests/test_ddp_gloo.py states both.
+        # Round 6, the default ``None`` = "what training READS": the buffers that feed the training arithmetic -- the
+        # spectral-norm power-iteration vectors ``weight_u`` / ``weight_v`` (HoloGAN's critic, a few KB) -- take rank
+        # 0's value at the top of every training_step exactly as under DDP, so that every rank normalises with the same
+        # sigma the reference's ranks see; the BatchNorm running statistics, which training-mode BatchNorm never
+        # reads, stay per rank until a checkpoint / evaluation (sync_buffers).
         self.broadcast_buffers = broadcast_buffers
+        self._trained_buffers = [b for n, b in module.named_buffers() if n.endswith(("weight_u", "weight_v"))]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.overlap = overlap
@@ -316,10 +322,11 @@ class GradSync:
             self.trace.append(("issue", idx, b))
 
     @torch.no_grad()
-    def _broadcast_all_buffers(self, src=0):
-        """DDP's ``_sync_buffers`` at the top of a forward: every buffer of the module takes rank ``src``'s value."""
+    def _broadcast_all_buffers(self, src=0, only=None):
+        """DDP's ``_sync_buffers`` at the top of a forward: every buffer of the module (or the buffers ``only``) takes
+        rank ``src``'s value."""
         by_dtype = {}
-        for b in self.module.buffers():
+        for b in (self.module.buffers() if only is None else only):
             by_dtype.setdefault(b.dtype, []).append(b)
         for bufs in by_dtype.values():
             flat = torch.cat([b.reshape(-1) for b in bufs])
@@ -331,8 +338,11 @@ class GradSync:
                 off += n
 
     def before_step(self, optimizer_idx, exchange=True):
-        if self.broadcast_buffers and self.world > 1:
-            self._broadcast_all_buffers()
+        if self.world > 1:
+            if self.broadcast_buffers:
+                self._broadcast_all_buffers()
+            elif self.broadcast_buffers is None and self._trained_buffers:
+                self._broadcast_all_buffers(only=self._trained_buffers)
         if getattr(self.module, "mutates_discriminator_before_forward", False):
             self.finalize(0)     # WGAN clamps D's weights at the top of training_step
         # A pending step of the SAME network must land before its next backward.  A network with per-layer gates lands

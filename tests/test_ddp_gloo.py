@@ -100,6 +100,11 @@ def _worker(rank, world, port, overlap, ret, bucket_bytes=16 << 20, expt="dc_gan
             idx = order[k % len(order)]
             toggle_optimizer(b, idx)
             per_step_inputs(b, k)
+            # torch DDP broadcasts rank 0's buffers at the top of every forward (broadcast_buffers=True, its default);
+            # GradSync's default does so for the buffers training reads: the spectral-norm vectors (HoloGAN)
+            for name, buf in b.named_buffers():
+                if name.endswith(("weight_u", "weight_v")):
+                    dist.broadcast(buf, src=0)
             b.training_step(batches[k], k, idx).backward()
             net = b.discriminator if idx == 0 else b.generator
             for p in net.parameters():
