@@ -1256,71 +1256,63 @@ static SplitPlan dgradtap2_plan(const ConvShape& s) {
     return SplitPlan{T256x128, splits < 1 ? 1 : splits};
 }
 
-// ---- 5x5 s2 p2 transposed convolution on row-shared LDS rows, both column phases per workgroup (gz_igemm2.h: ConvDg5A2,
-// DgPairB2, EpiPhasePairB; round 6).  Grid phases y = py (two); columns = (px, channel): N = 2 C.  The reduction of row
-// phase py has 9 K/16 (py = 0) / 6 K/16 (py = 1) chunks; a launch with too few tiles cuts it into pieces of equal length
-// (slabs + the finish pass), each row phase getting as many pieces as its length asks for.
+// ---- 5x5 s2 p2 transposed convolution on row-shared LDS rows, all four output phases per workgroup (gz_igemm2.h:
+// ConvDg5A2, DgQuadB2, EpiPhaseQuadB; round 6).  Tile = 256 pixels x 32 channels x (py, px); columns N = 4 C, one grid
+// phase; 3 K/8 chunks of 12 k-steps, every workgroup identical.  Unsplit when every CU gets a workgroup, else the
+// reduction is cut for ~512 workgroups (slabs + the finish pass).  Launches with little work per CU stay on the gather
+// loader: measured (tools/tap_bench.py 64 / 128, TFLOP/s, this kernel vs the gather loader): EXT-128's critic at bs 64
+// D.block1 125 vs 123, D.block2 111 vs 99, D.block3 102 vs 99, at bs 128 128 / 128 / 117; the 6.7-GFLOP layers of the
+// 64 x 64 critic 65-72 vs 67-84.
 struct Dg5Plan {
     bool ok;
-    int splits;          // of the LONGER phase (py = 0); launch_igemm2 derives chunks_per_split from it
-    int nz0, nz1;        // slabs per row phase (1, 1 = unsplit)
+    int splits, nz;
 };
 template <class G>
 static bool dgrad5_shape_ok(const ConvShape& s) {
     return G::kh == 5 && G::kw == 5 && G::s == 2 && G::p == 2 && !knobs().no_igemm2 && !knobs().no_dg5 && s.H == 2 * s.OH &&
-           s.W == 2 * s.OW && s.OW % 4 == 0 && 256 % s.OW == 0 && s.K % 16 == 0 && s.K >= 32 && s.C % 64 == 0 &&
+           s.W == 2 * s.OW && s.OW % 4 == 0 && 256 % s.OW == 0 && s.K % 16 == 0 && s.K >= 32 && s.C % 32 == 0 &&
            dgrad_tap_major(s.K, 5, 5, 2) && (long long)s.N * s.OH * s.OW >= 256;
 }
 template <class G>
 static Dg5Plan dgrad5_plan(const ConvShape& s) {
-    Dg5Plan p{false, 1, 1, 1};
+    Dg5Plan p{false, 1, 1};
     if (!dgrad5_shape_ok<G>(s)) return p;
     const long long M = (long long)s.N * s.OH * s.OW;
-    const long long tiles = ((M + 255) / 256) * (s.C / 64);
-    const int c0 = 9 * s.K / 16, c1 = 6 * s.K / 16;
-    // too little work (< ~0.5 GFLOP) for 256-pixel tiles on a whole chip: the small-tile kernels keep it
-    if (tiles * (c0 + c1) < 1LL * cus() * knobs().dg5_min_units) return p;
-    const long long want = (long long)knobs().dg5_wgs * cus() / 256;
-    if (tiles * 2 >= want * 3 / 4) {                               // unsplit: >= 1.5 workgroups per CU
-        p.ok = true;
-        return p;
-    }
-    // Launches that have to cut their reduction stay on the gather loader by default.  Measured (tools/tap_bench.py 64,
-    // tools/ab_dg5.sh, round 6): the two row phases cost 3 : 2, their pieces pack badly into 512 workgroup slots, and
-    // the finish pass reads 5-20 slabs of 2 C columns -- 92-95 TFLOP/s against the gather loader's 99 on EXT-128's
-    // D.block2 / 3, 55-60 against 67-84 on the 6.7-GFLOP layers of the 64 x 64 critic.  GZ_DG5_SPLIT=1 (experiments).
-    if (!knobs().dg5_split) return p;
+    const long long tiles = ((M + 255) / 256) * (s.C / 32);
+    const int chunks = 3 * s.K / 8;          // chunks of 8 LDS rows, 12 k-steps each
+    if (tiles * chunks < 1LL * cus() * knobs().dg5_min_units) return p;
     p.ok = true;
-    long long cps = (tiles * (c0 + c1) + want - 1) / want;         // chunks per workgroup for ~want workgroups
+    if (tiles >= cus()) return p;                                  // unsplit: every CU has a workgroup
+    const long long want = (long long)knobs().dg5_wgs * cus() / 256;
+    long long cps = (tiles * chunks + want - 1) / want;
     if (cps < knobs().dg5_min_chunks) cps = knobs().dg5_min_chunks;
-    if (cps >= c0) return p;
-    p.splits = (int)((c0 + cps - 1) / cps);
-    const int per = (c0 + p.splits - 1) / p.splits;               // (= launch_igemm2's chunks_per_split)
-    p.nz0 = (c0 + per - 1) / per;
-    p.nz1 = (c1 + per - 1) / per;
-    if (p.nz0 <= 1) { p.splits = p.nz0 = p.nz1 = 1; }
+    if (cps >= chunks) return p;
+    p.splits = (int)((chunks + cps - 1) / cps);
+    const int per = (chunks + p.splits - 1) / p.splits;           // (= launch_igemm2's chunks_per_split)
+    p.nz = (chunks + per - 1) / per;
+    if (p.nz <= 1) p.splits = p.nz = 1;
     return p;
 }
 template <class G>
 static size_t dgrad5_ws_bytes(const ConvShape& s) {
     const Dg5Plan p = dgrad5_plan<G>(s);
-    if (!p.ok || p.nz0 <= 1) return 0;
-    return (size_t)(p.nz0 + p.nz1) * (size_t)s.N * s.OH * s.OW * (size_t)(2 * s.C) * 4;
+    if (!p.ok || p.nz <= 1) return 0;
+    return (size_t)p.nz * (size_t)s.N * s.OH * s.OW * (size_t)(4 * s.C) * 4;
 }
-static int run_dgrad5pair(const float* y, const float* wp, float* x, const ConvShape& s, hipStream_t st, const Dg5Plan& plan,
-                          float* slab) {
-    using Cfg = Cfg256x128;
+using CfgQuad = TileCfg2<4, 1, 4, 2, 2>;       // four wavefronts of 64 pixels x (4 phases x 32 channels)
+static int run_dgrad5(const float* y, const float* wp, float* x, const ConvShape& s, hipStream_t st, const Dg5Plan& plan,
+                      float* slab) {
+    using Cfg = CfgQuad;
     using AL = ConvDg5A2<Cfg::BM>;
-    using BL = DgPairB2;
-    using Epi = EpiPhasePairB;
+    using BL = DgQuadB2;
+    using Epi = EpiPhaseQuadB;
     const int AH = s.OH, AW = s.OW;
     typename AL::Params pa{y, s, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW)};
     typename BL::Params pb{wp, s.K, s.C, round4(s.C)};
     const int M = s.N * AH * AW;
     typename Epi::Params pe{x, M, s.C, s.H, s.W, AH, AW, make_fastdiv(AH * AW), make_fastdiv(AW), nullptr, ACT_NONE, 0.f,
                             nullptr, 0};
-    int pc[8] = {9 * s.K / 16, 6 * s.K / 16, 0, 0, 0, 0, 0, 0};
-    return launch_igemm2<Cfg, AL, BL, Epi>(pa, pb, pe, M, 2 * s.C, 9 * s.K, 2, plan.splits, st, plan.nz0 > 1 ? slab : nullptr, pc);
+    return launch_igemm2<Cfg, AL, BL, Epi>(pa, pb, pe, M, 4 * s.C, 6 * s.K, 1, plan.splits, st, plan.nz > 1 ? slab : nullptr);
 }
 
 template <class G>
@@ -1402,8 +1394,8 @@ static int dispatch_dgrad(const float* y, const float* wp, const float* bias, fl
     if constexpr (G::kh == 5 && G::kw == 5 && G::s == 2 && G::p == 2) {
         if (!bias && act == ACT_NONE && (((uintptr_t)y | (uintptr_t)x | (uintptr_t)wp) & 15) == 0) {
             const Dg5Plan p5 = dgrad5_plan<G>(s);
-            if (p5.ok && (p5.nz0 <= 1 || (ws && ws_bytes >= dgrad5_ws_bytes<G>(s))))
-                return run_dgrad5pair(y, wp, x, s, st, p5, ws);
+            if (p5.ok && (p5.nz <= 1 || (ws && ws_bytes >= dgrad5_ws_bytes<G>(s))))
+                return run_dgrad5(y, wp, x, s, st, p5, ws);
         }
     }
     SplitPlan sp = dgrad_plan<G>(s);
@@ -3046,7 +3038,7 @@ static const char* tile_text(TileId t) {
         case T256x128: return "256x128";
         case T512x64: return "512x64";
         case T256x64: return "256x64";
-        case T256x128P: return "256x(2x64)";
+        case T256x128P: return "256x(4x32)";
         default: return "128x256";
     }
 }
@@ -3103,8 +3095,8 @@ static int describe_dgrad(const ConvShape& s, char* b, size_t n) {
     if constexpr (G::kh == 5 && G::kw == 5 && G::s == 2 && G::p == 2) {
         const Dg5Plan p5 = dgrad5_plan<G>(s);
         if (p5.ok)
-            return snprintf(b, n, "Dg igemm2<256x128=(px,64)> ConvDg5A2(row-shared, LDS-DMA 16B, px pair) slabs=%d+%d "
-                                  "(no bias / activation, aligned tensors; else the gather loader)", p5.nz0, p5.nz1);
+            return snprintf(b, n, "Dg igemm2<256x(4 phases x 32)> ConvDg5A2(row-shared, LDS-DMA 16B, 12 k-steps) slabs=%d "
+                                  "(no bias / activation, aligned tensors; else the gather loader)", p5.nz);
     }
     constexpr int TAPS = ((G::kh + G::s - 1) / G::s) * ((G::kw + G::s - 1) / G::s);
     const SplitPlan sp = dgrad_plan<G>(s);

@@ -30,9 +30,9 @@ namespace gz {
 constexpr int STAGES2 = 3;
 constexpr uint32_t SOFF_OOB = 0x80000000u;      // scalar offset that puts every lane of a buffer access out of range
 
-template <int WM_, int WN_, int TN_, int OCC_>
+template <int WM_, int WN_, int TN_, int OCC_, int TM_ = 4>
 struct TileCfg2 {
-    static constexpr int WM = WM_, WN = WN_, TM = 4, TN = TN_, OCC = OCC_;      // OCC: workgroups per CU (= waves / SIMD)
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, OCC = OCC_;    // OCC: workgroups per CU (= waves / SIMD)
     static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 wavefronts per workgroup, one per SIMD");
 };
@@ -309,41 +309,52 @@ struct ConvDgTapA2 {
 // ---- round 6: the 5x5 s2 p2 TRANSPOSED convolution, row-shared (HoloGAN's critic, input gradients) -------------------
 // ConvDgTapA2 above gathers a chunk per (tap, 16 channels): the 9 / 6 / 6 / 4 taps of the four output phases each fetch
 // the SAME gradient rows again, 4 bytes per lane and instruction, and every phase stores every other float of a row
-// (EXT-128 D.block1: 6.8x its algorithmic bytes).  But along m = (n, a, b) the operand IS contiguous in memory --
+// (EXT-128 D.block1: 6.6x its algorithmic bytes).  But along m = (n, a, b) the operand IS contiguous in memory --
 //   dx[2a + py][2b + px] = sum_{ty < ny, tx < nx}  dy[a + 1 - ty][b + 1 - tx] . w[py + 2 ty][px + 2 tx],  ny = 3 - py, nx = 3 - px
 // -- so the row-shared form of ConvDgA2 applies: an LDS row = 256 consecutive pixels of ONE (feature channel, ty),
-// fetched once by a 16-byte LDS-DMA piece, the horizontal taps applied as shifts on the fragment read (zero column for
+// fetched ONCE by a 16-byte LDS-DMA piece, the horizontal taps applied as shifts on the fragment read (zero column for
 // the lanes at an image row's edge).  What is new against k4 s2 p1:
-//   * the workgroup computes BOTH column phases px = 0 / 1 of its row phase py (y = py: two grid phases, not four).
-//     Their part-A taps are the same two shifts (+1, 0), so they share the A fragments outright and the B image is the
-//     ordinary 128-column one with columns = (px, channel): accumulator block j is px, and the epilogue stores the two
-//     as one 8-byte pair (EpiPhasePairB);
-//   * DUAL MODE: px = 0 has a third tap (shift -1).  The reduction is  part A: chunks of 8 LDS rows x 2 shifts on all
-//     128 columns (the row-shared k-step: half-wave = shift), then  part B: chunks of 16 LDS rows x the one shift on
-//     the px = 0 columns only (plain k-step: half-wave = next row; MFMAs on accumulator block 0 only).  Chunk counts
-//     per py: 9 K/16 and 6 K/16 -- exactly the 9 + 6 | 6 + 4 taps of the phases it replaces;
+//   * ALL FOUR output phases in one workgroup: tile = 256 pixels x 32 channels x (py, px), four wavefronts of 64 pixels
+//     (TM = 2), accumulator block j = 2 py + px.  Row a + 1 - ty serves py = 0 as its tap ty and, for ty < 2, py = 1 as ITS
+//     tap ty, and the column phases share the shifts (+1, 0): the A fragments are shared outright, the B image is the
+//     ordinary 128-column one with columns = (phase, channel), and the epilogue stores a lane's four values as two
+//     8-byte pairs (EpiPhaseQuadB: whole 64-byte lines leave the CU);
+//   * TWELVE k-steps per chunk of 8 LDS rows: 8 row-shared ones (half-wave = shift +1 / 0) and then 4 PLAIN ones (half-wave
+//     = next row, shift -1: px = 0's third tap) on the SAME staged rows -- every dy row is staged once;
+//   * two chunk MODES, one loop each (a mode switch inside one loop made the register allocator spill accumulators):
+//     rows ty < 2 feed all four phases (8 x 8 + 4 x 4 = 80 MFMAs per wavefront and chunk), rows ty = 2 the py = 0 phases
+//     (40).  3 K/8 chunks, 25 K MFMAs per wavefront = exactly the 25 taps, and every workgroup is identical (two earlier
+//     forms of the round were not: DESIGN 3.1);
 //   * the weights are read from the EXISTING tap-major pack (pack_dgrad_tap: [phase (py, px)][tap = ty * nx + tx][ko][C])
-//     by a B loader that picks the right rows (DgPairB2): no second packed image, no pack-cache changes.
-// Needs AH = OH, AW = OW a multiple of 4 dividing 256, K % 16 == 0, C % 64 == 0, 16-byte aligned tensors, no bias /
+//     by a B loader that picks the rows (DgQuadB2): no second packed image, no pack-cache changes.
+// Needs AH = OH, AW = OW a multiple of 4 dividing 256, K % 16 == 0, C % 32 == 0, 16-byte aligned tensors, no bias /
 // activation (an input gradient).  Reference: core/models/hologan_discriminator.py:7-23 (Conv2d k5 s2 p2).
 template <int BM>
 struct ConvDg5A2 {
     static_assert(BM == 256, "one 256-pixel piece per LDS row");
     using Params = typename ConvDgALoaderTap<BM, 5, 5, 2, 2>::Params;
-    static constexpr int LD = BM + 4, ROWS = BK, PIECES = 4;
+    static constexpr int LD = BM + 4, ROWS = 8, PIECES = 2;
     static constexpr int ZERO_COL = BM;
     static constexpr bool ROWSHARE = true, DUALMODE = true;
+    static constexpr int MODES = 2, KSTEPS = 12;
+    static constexpr bool step_plain(int m, int S) { return S >= 8; }
+    static constexpr unsigned step_mask(int m, int S) {       // accumulator blocks (output phases) the k-step's taps feed
+        return m == 0 ? (S < 8 ? 15u : 5u) : (S < 8 ? 3u : 1u);
+    }
+    static constexpr int step_arow(int m, int S) { return S < 8 ? S : 2 * (S - 8); }
+    static constexpr int step_brow(int m, int S) { return S < 8 ? 2 * S : 16 + 2 * (S - 8); }
     __amdgpu_buffer_rsrc_t rsrc;
-    uint32_t voff0, voff1, voff2;      // [ty]: this lane's pixel quad in row a + 1 - ty (out of range: outside the image / ty >= ny)
-    int wave, K, OHW, chunksA;         // (three scalars, not an array: a ty-indexed array ends up in scratch)
-    __device__ __forceinline__ void init(const Params& p, int tile, int py, int tid) {
+    uint32_t voff0, voff1, voff2;      // [ty]: this lane's pixel quad in row a + 1 - ty (out of range: outside the image)
+    int wave, K, OHW;                  // (three scalars, not an array: a ty-indexed array ends up in scratch)
+    int bound[1];                      // first chunk of mode 1 (rows ty = 2)
+    __device__ __forceinline__ int mode_of(int kc) const { return kc >= bound[0]; }
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
         const ConvShape& s = p.s;
         rsrc = make_rsrc(p.y, (uint32_t)s.N * s.K * s.OH * s.OW * 4u);
         const int lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         K = s.K; OHW = s.OH * s.OW;
-        const int ny = 3 - py;
-        chunksA = ny * K / 8;
+        bound[0] = 2 * K / 8;
         const uint32_t m = (uint32_t)tile * BM + lane * 4;
         const bool m_ok = m < (uint32_t)s.N * p.AH * p.AW;
         const uint32_t n = fdiv(m, p.div_ahw);
@@ -352,22 +363,15 @@ struct ConvDg5A2 {
         const uint32_t b = pix - a * (uint32_t)p.AW;
         auto row = [&](int ty) {
             const int oy = (int)a + 1 - ty;
-            const bool ok = m_ok && ty < ny && (unsigned)oy < (unsigned)s.OH;
+            const bool ok = m_ok && (unsigned)oy < (unsigned)s.OH;
             return ok ? (n * (uint32_t)(s.K * OHW) + (uint32_t)(oy * s.OW) + b) * 4u : OOB;
         };
         voff0 = row(0); voff1 = row(1); voff2 = row(2);
     }
-    __device__ __forceinline__ int frag_shift(int half) const { return half ? 0 : 1; }      // part A: tx = half-wave
+    __device__ __forceinline__ int frag_shift(int half) const { return half ? 0 : 1; }      // row-shared k-steps: tx = half-wave
     __device__ __forceinline__ void issue_piece(int kc, float* stage, int p, bool live) {
-        // part A: 8 rows per chunk (this wavefront: rows 2w, 2w + 1; its pieces 2, 3 are fillers -- every chunk must
-        // issue the same number of loads, the counted s_waitcnt vmcnt depends on it); part B: 16 rows (4w .. 4w + 3)
-        const bool partA = kc < chunksA;
-        if (partA && p >= 2) {
-            bload_lds16(rsrc, stage + (8 + wave * 2 + (p - 2)) * LD, OOB, SOFF_OOB);
-            return;
-        }
-        const int row = partA ? wave * 2 + p : wave * 4 + p;
-        const int r = partA ? kc * 8 + row : (kc - chunksA) * 16 + row;          // (ty, ko), ty-major: r = ty * K + ko
+        const int row = wave * 2 + p;
+        const int r = kc * 8 + row;          // (ty, ko), ty-major: r = ty * K + ko
         const int ty = (r >= K) + (r >= 2 * K);
         const int ko = r - ty * K;
         // (masks, not a select chain: the compiler turns `ty == 0 ? voff0 : ...` into a ty-indexed table in scratch)
@@ -377,51 +381,52 @@ struct ConvDg5A2 {
     }
 };
 
-// B operand of ConvDg5A2: the [16 k][128 = (wn, px, 32 channels)] image of a chunk, gathered row-wise out of the tap-major
-// dgrad pack of a 5x5 s2 p2 weight (gz_conv.hip pack_dgrad_tap_body: phase (py, px) at phase * 9 * K * ldc floats, row
-// (ty * nx + tx) * K + ko, nx = 3 - px).  A piece = two k rows x 128 columns (lane = (k row, 4 columns)):
-//   part A, chunk row r = (ty, ko):  k rows (r, tx = 0), (r, tx = 1) of BOTH phases' images -- the lane's phase and
-//           tap offsets are per-lane constants, ty enters through a per-lane stride (nx differs between the phases);
-//   part B, rows (ty, ko), (ty, ko + 1) at tx = 2 of phase (py, 0); the px = 1 columns are never multiplied (zeros).
-struct DgPairB2 {
+// B operand of ConvDg5A2: image [24 k rows][128 columns = (phase j = 2 py + px, 32 channels)] per chunk of 8 LDS rows
+// r = (ty, ko), gathered row-wise out of the tap-major dgrad pack of a 5x5 s2 p2 weight (gz_conv.hip pack_dgrad_tap_body:
+// phase (py, px) at phase * 9 * K * ldc floats, row (ty * nx + tx) * K + ko, nx = 3 - px): rows 0-15 = (r, tx in {0, 1}) of
+// every phase that has tap row ty (py = 1 has none at ty = 2: zeros, never multiplied), rows 16-23 = (r, tx = 2) of the
+// px = 0 phases.  A piece = two image rows x 128 columns (lane = (image row, 4 columns)); the lane's phase and tap offsets
+// are per-lane constants, ty enters through a per-lane stride (nx differs between the column phases).
+struct DgQuadB2 {
     struct Params {
         const float* wp;
         int K, C, ldc;                  // feature channels (multiple of 16), image-side channels, row pitch of the pack
     };
-    static constexpr int LD = 128, ROWS = BK, PIECES = 2;
+    static constexpr int LD = 128, ROWS = 24, PIECES = 3;
     __amdgpu_buffer_rsrc_t rsrc;
-    uint32_t vA, vA_step, vB, ldb;
-    int wave, K, chunksA;
-    __device__ __forceinline__ void init(const Params& p, int tile, int py, int tid) {
+    uint32_t vA, vA_step, vA2, vB, vB2, ldb;
+    int wave, K, b0;
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
         const uint32_t phase_floats = 9u * (uint32_t)p.K * (uint32_t)p.ldc;
         rsrc = make_rsrc(p.wp, 4u * phase_floats * 4u);
         const int lane = tid & 63;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         K = p.K;
-        chunksA = (3 - py) * p.K / 8;
-        const int t = lane >> 5, q = (lane & 31) * 4;             // k row inside the piece, first of 4 image columns
-        const int px = (q & 63) >> 5;
-        const int ch = tile * 64 + (q >> 6) * 32 + (q & 31);
+        b0 = 2 * K / 8;
+        const int t = lane >> 5, q = (lane & 31) * 4;             // image row inside the piece, first of 4 image columns
+        const int j = q >> 5, py = j >> 1, px = j & 1;
+        const int ch = tile * 32 + (q & 31);
         const bool ok = ch < p.C;
         ldb = (uint32_t)p.ldc * 4u;
-        const uint32_t phase = (uint32_t)(py * 2 + px) * phase_floats;
-        vA = ok ? (phase + (uint32_t)t * (uint32_t)(p.K * p.ldc) + (uint32_t)ch) * 4u : OOB;
-        vA_step = ok ? (uint32_t)(3 - px) * (uint32_t)(p.K * p.ldc) * 4u : 0u;
-        vB = (ok && px == 0) ? ((uint32_t)(py * 2) * phase_floats + (uint32_t)t * (uint32_t)p.ldc + (uint32_t)ch) * 4u : OOB;
+        const uint32_t phase = (uint32_t)j * phase_floats;
+        const uint32_t kld = (uint32_t)(p.K * p.ldc);
+        vA = ok ? (phase + (uint32_t)t * kld + (uint32_t)ch) * 4u : OOB;                 // + ty * vA_step, + ko * ldb
+        vA_step = ok ? (uint32_t)(3 - px) * kld * 4u : 0u;
+        vA2 = (ok && py == 0) ? vA + 2u * vA_step : OOB;                                    // ty = 2
+        vB = (ok && px == 0) ? (phase + (uint32_t)t * (uint32_t)p.ldc + (uint32_t)ch) * 4u : OOB;   // + ((3 ty + 2) K + ko) * ldb
+        vB2 = j == 0 ? vB : OOB;                                                             // ty = 2: phase (0, 0) alone
     }
     __device__ __forceinline__ void issue_piece(int kc, float* stage, int p, bool live) {
-        const int piece = wave * PIECES + p;
+        const int piece = wave * PIECES + p;                      // 0..11: image rows 2 piece, 2 piece + 1
+        const int r0 = kc * 8;                                    // the chunk's first LDS row (all of one ty: K % 8 == 0)
+        const int ty = (r0 >= K) + (r0 >= 2 * K);
         uint32_t v, so;
-        if (kc < chunksA) {
-            const int r = kc * 8 + piece;
-            const int ty = (r >= K) + (r >= 2 * K);
-            v = vA + (uint32_t)ty * vA_step;
-            so = (uint32_t)(r - ty * K) * ldb;
-        } else {
-            const int r = (kc - chunksA) * 16 + piece * 2;
-            const int ty = (r >= K) + (r >= 2 * K);
-            v = vB;
-            so = (uint32_t)((ty * 3 + 2) * K + (r - ty * K)) * ldb;
+        if (piece < 8) {                     // (LDS row r0 + piece, tx = lane's image row)
+            v = kc < b0 ? vA + (uint32_t)ty * vA_step : vA2;
+            so = (uint32_t)(r0 + piece - ty * K) * ldb;
+        } else {                             // (LDS rows r0 + 2 (piece - 8) + lane's image row, tx = 2)
+            v = kc < b0 ? vB : vB2;
+            so = (uint32_t)((ty * 3 + 2) * K + (r0 + 2 * (piece - 8) - ty * K)) * ldb;
         }
         bload_lds16(rsrc, stage + piece * 256, v, live ? so : SOFF_OOB);
     }
@@ -691,6 +696,9 @@ __device__ __forceinline__ void lgkm_done(float (&a)[4], float (&b)[4]) {
 __device__ __forceinline__ void lgkm_done(float (&a)[4], float (&b)[2]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]));
 }
+__device__ __forceinline__ void lgkm_done(float (&a)[2], float (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
 __device__ __forceinline__ void lgkm_done(float (&a)[4], float (&b)[1]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]));
 }
@@ -708,6 +716,38 @@ struct fwd_ow_of<AL, std::void_t<decltype(AL::OW_C)>> { static constexpr int val
 template <class AL>
 constexpr int fwd_ow() { return fwd_ow_of<AL>::value; }
 
+// multi-mode loaders (ConvDg5A2): traits with defaults for every other loader
+template <class AL>
+constexpr int mode_count_of() {
+    if constexpr (is_dualmode<AL>::value) return AL::MODES;
+    else return 1;
+}
+template <class AL>
+constexpr bool mode_plain_of(int m, int S) {       // k-step S of a mode-m chunk: plain (half-wave = next LDS row) or row-shared
+    if constexpr (is_dualmode<AL>::value) return AL::step_plain(m, S);
+    else return false;
+}
+template <class AL>
+constexpr unsigned mode_mask_of(int m, int S) {    // ... and the accumulator blocks its MFMAs feed
+    if constexpr (is_dualmode<AL>::value) return AL::step_mask(m, S);
+    else return 0xFu;
+}
+template <class AL>
+constexpr int ksteps_of() {                        // k-steps per chunk (the folded four-phase form: 8 row-shared + 4 plain)
+    if constexpr (is_dualmode<AL>::value) return AL::KSTEPS;
+    else return BK / 2;
+}
+template <class AL>
+constexpr int step_arow_of(int m, int S) {         // first LDS row of k-step S (plain steps: two rows per step)
+    if constexpr (is_dualmode<AL>::value) return AL::step_arow(m, S);
+    else return S;
+}
+template <class AL>
+constexpr int step_brow_of(int m, int S) {         // first row of the B image k-step S multiplies
+    if constexpr (is_dualmode<AL>::value) return AL::step_brow(m, S);
+    else return 2 * S;
+}
+
 // KG = 2 (round 5): TWO wave groups of four wavefronts in one 512-thread workgroup work on the SAME output tile, each on
 // half of the workgroup's reduction range with an LDS ring of its own, and meet in LDS at the end (group 1 parks its
 // accumulators, group 0 adds them and runs the epilogue).  For launches whose tiles x reduction splits give a CU only
@@ -723,12 +763,15 @@ __global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel
                                                                               typename Epi::Params pe, GridMap gm) {
     constexpr int LDA = AL::LD, LDB = BL::LD;
     constexpr int TM = Cfg::TM, TN = Cfg::TN;
-    static_assert(TM == 4 && (TN == 1 || TN == 2 || TN == 4), "fragment registers of the hand-ordered k-step");
+    static_assert((TM == 4 || (TM == 2 && is_dualmode<AL>::value)) && (TN == 1 || TN == 2 || TN == 4),
+                  "fragment registers of the hand-ordered k-step");
     static_assert(KG == 1 || (KG == 2 && TN <= 2), "two wave groups: the parked accumulators must fit the LDS");
     constexpr bool RS = is_rowshare<AL>::value;
     constexpr bool FR = is_fwdrows<AL>::value;
-    constexpr bool DM = is_dualmode<AL>::value;      // (ConvDg5A2) chunks >= al.chunksA are plain chunks on accumulator block 0
-    static_assert(!DM || (RS && KG == 1 && TN == 2), "dual mode: row-shared loader, px pair in the two accumulator blocks");
+    // (ConvDg5A2) MODES consecutive chunk ranges, each with its own k-step form: row-shared or plain fragment addressing
+    // and the accumulator blocks (output phases) its MFMAs feed -- AL::mode_plain(m), AL::mode_mask(m), al.bound[]
+    constexpr bool DM = is_dualmode<AL>::value;
+    static_assert(!DM || (RS && KG == 1 && (TN == 2 || TN == 4)), "multi-mode: row-shared loader, phases in the accumulator blocks");
     constexpr int A_EXTRA = igemm2_a_extra<AL>();
     constexpr int A_ELEMS = AL::ROWS * LDA + A_EXTRA, B_ELEMS = BL::ROWS * LDB;
     constexpr int STAGE = A_ELEMS + B_ELEMS;
@@ -842,7 +885,8 @@ __global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel
     }
     const uint32_t b_addr = lds0 + (uint32_t)(half * LDB + wn * TN * 32 + l32) * 4u;
 
-    constexpr int NPA = AL::PIECES, NPB = BL::PIECES, NP = NPA + NPB, STEPS = BK / 2;
+    constexpr int NPA = AL::PIECES, NPB = BL::PIECES, NP = NPA + NPB, STEPS = ksteps_of<AL>();
+    static_assert(STEPS == 8 || STEPS == 12, "k-steps per chunk");
     constexpr int PPS = (NP + STEPS - 1) / STEPS;          // LDS-DMA pieces per k-step (1 for the 16-byte loaders)
     static_assert(PPS <= 4 && NP < 64, "pieces are spread over the k-step's four MFMA rows; vmcnt is 6 bits");
     auto issue_piece = [&](int kc, int st, int p, bool live) {
@@ -857,14 +901,24 @@ __global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel
         else bl.issue_piece(kc, sb, p - NPA, live);
     };
     // k-step S of the stage whose byte offset is `so`: raw fragments
-    auto fetch_b = [&](auto Sc, uint32_t so, float (&af)[TM], float (&bf)[TN]) {      // dual mode, part B
-        constexpr int S = decltype(Sc)::value;
-        constexpr int AO = 2 * LDA * S * 4, BO = 2 * S * LDB * 4;
-        af[0] = lds_rd<AO>(a_addrB[0] + so);
-        af[1] = lds_rd<AO>(a_addrB[1] + so);
-        af[2] = lds_rd<AO>(a_addrB[2] + so);
-        af[3] = lds_rd<AO>(a_addrB[3] + so);
-        bf[0] = lds_rd<BO>(b_addr + so);
+    auto fetch_m = [&](auto Sc, auto Mc, uint32_t so, float (&af)[TM], float (&bf)[TN]) {      // multi-mode loaders
+        constexpr int S = decltype(Sc)::value, MD = decltype(Mc)::value;
+        constexpr bool PL = mode_plain_of<AL>(MD, S);
+        constexpr unsigned MK = mode_mask_of<AL>(MD, S);
+        constexpr int AO = LDA * step_arow_of<AL>(MD, S) * 4, BO = step_brow_of<AL>(MD, S) * LDB * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = lds_rd<AO>((PL ? a_addrB[i] : a_addr[i]) + so);
+        if constexpr ((MK & 1u) != 0) bf[0] = lds_rd<BO>(b_addr + so);
+        if constexpr (TN >= 2 && (MK & 2u) != 0) bf[1] = lds_rd<BO + 128>(b_addr + so);
+        if constexpr (TN == 4 && (MK & 4u) != 0) bf[2] = lds_rd<BO + 256>(b_addr + so);
+        if constexpr (TN == 4 && (MK & 8u) != 0) bf[3] = lds_rd<BO + 384>(b_addr + so);
+    };
+    // the first fragments of chunk `kc`, in that chunk's mode
+    auto fetch_first = [&](int kc, uint32_t so, float (&af)[TM], float (&bf)[TN]) {
+        if constexpr (DM) {
+            if (al.mode_of(kc) == 0) fetch_m(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, so, af, bf);
+            else fetch_m(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, so, af, bf);
+        }
     };
     auto fetch = [&](auto Sc, uint32_t so, float (&af)[TM], float (&bf)[TN]) {
         constexpr int S = decltype(Sc)::value;
@@ -916,15 +970,12 @@ __global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel
 #ifdef GZ2_STEP_STAMPS
         unsigned long long step_cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, step_t = __builtin_amdgcn_s_memtime();
 #endif
-        int chunksA = 0x7fffffff;              // dual mode: first plain chunk
         if constexpr (DM) {
-            chunksA = al.chunksA;
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[q][j] = 0.f;
-            if (kc0 >= chunksA) fetch_b(std::integral_constant<int, 0>{}, 0u, af[0], bf[0]);
-            else fetch(std::integral_constant<int, 0>{}, 0u, af[0], bf[0]);
+            fetch_first(kc0, 0u, af[0], bf[0]);
         } else {
             fetch(std::integral_constant<int, 0>{}, 0u, af[0], bf[0]);
         }
@@ -933,7 +984,7 @@ __global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel
         int stage = 0;
         // (dual mode: the row-shared chunks and the plain chunks are TWO loops, one after the other -- a per-chunk branch
         // between the two k-step forms inside one loop made the register allocator spill accumulators in every iteration)
-        auto run_chunks = [&](int k_from, int k_to, auto MBc) {
+        auto run_chunks = [&](int k_from, int k_to, auto Mc) {
         for (int kc = k_from; kc < k_to; ++kc) {
             int s1 = stage + 1; if (s1 >= STAGES2) s1 -= STAGES2;
             int s2 = s1 + 1; if (s2 >= STAGES2) s2 -= STAGES2;
@@ -941,14 +992,22 @@ __global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel
             const bool more = kc + 2 < kc1;
             auto kstep = [&](auto Sc) {
                 constexpr int S = decltype(Sc)::value;
-                constexpr bool MB = decltype(MBc)::value;        // dual mode, part B: plain chunk, accumulator block 0 only
+                constexpr int MD = decltype(Mc)::value;          // multi-mode loaders: this loop's k-step form
                 constexpr int c = S & 1, n = c ^ 1;
                 auto mfma_row = [&](f32x16 (&cc)[TN], float a, const float (&b)[TN]) {
-                    if constexpr (MB) gz::mfma_one(cc[0], a, b[0]);
-                    else gz::mfma_row(cc, a, b);
+                    if constexpr (DM) {           // the accumulator blocks (output phases) this mode's taps feed
+                        constexpr unsigned MK = mode_mask_of<AL>(MD, S);
+                        if constexpr (MK == (TN == 4 ? 15u : 3u)) gz::mfma_row(cc, a, b);
+                        else {
+                            if constexpr ((MK & 1u) != 0) gz::mfma_one(cc[0], a, b[0]);
+                            if constexpr (TN >= 2 && (MK & 2u) != 0) gz::mfma_one(cc[1], a, b[1]);
+                            if constexpr (TN == 4 && (MK & 4u) != 0) gz::mfma_one(cc[2], a, b[2]);
+                            if constexpr (TN == 4 && (MK & 8u) != 0) gz::mfma_one(cc[3], a, b[3]);
+                        }
+                    } else gz::mfma_row(cc, a, b);
                 };
                 auto fetch_same = [&](auto S2c, uint32_t o, float (&fa)[TM], float (&fb)[TN]) {
-                    if constexpr (MB) fetch_b(S2c, o, fa, fb);
+                    if constexpr (DM) fetch_m(S2c, Mc, o, fa, fb);
                     else fetch(S2c, o, fa, fb);
                 };
                 // chunk kc+2's pieces go out in the FIRST k-steps, PPS per step, one behind each MFMA row (the stage
@@ -966,9 +1025,9 @@ __global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel
                     pieces(std::integral_constant<int, 0>{});
                     mfma_row(acc[1], af[c][1], bf[c]);
                     pieces(std::integral_constant<int, 1>{});
-                    mfma_row(acc[2], af[c][2], bf[c]);
+                    if constexpr (TM == 4) mfma_row(acc[2], af[c][2], bf[c]);
                     pieces(std::integral_constant<int, 2>{});
-                    mfma_row(acc[3], af[c][3], bf[c]);
+                    if constexpr (TM == 4) mfma_row(acc[3], af[c][3], bf[c]);
                     pieces(std::integral_constant<int, 3>{});
                 } else {
                     // last k-step: half of its MFMAs, then chunk kc+1 must have landed (all but the NP pieces of chunk
@@ -976,7 +1035,7 @@ __global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel
                     // chunk kc+1 are fetched under the other half
                     mfma_row(acc[0], af[c][0], bf[c]);
                     pieces(std::integral_constant<int, 0>{});
-                    mfma_row(acc[1], af[c][1], bf[c]);
+                    if constexpr (TM == 4) mfma_row(acc[1], af[c][1], bf[c]);
                     pieces(std::integral_constant<int, 1>{});
                     pieces(std::integral_constant<int, 2>{});
                     pieces(std::integral_constant<int, 3>{});
@@ -986,14 +1045,14 @@ __global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel
 #ifndef GZ2_EXP_NOBARRIER
                     __builtin_amdgcn_s_barrier();
 #endif
-                    if constexpr (DM) {      // the next chunk's first fragments, in ITS mode
-                        if (kc + 1 >= chunksA) fetch_b(std::integral_constant<int, 0>{}, sno, af[n], bf[n]);
-                        else fetch(std::integral_constant<int, 0>{}, sno, af[n], bf[n]);
+                    if constexpr (DM) fetch_first(kc + 1, sno, af[n], bf[n]);      // the next chunk's, in ITS mode
+                    else fetch(std::integral_constant<int, 0>{}, sno, af[n], bf[n]);
+                    if constexpr (TM == 4) {
+                        mfma_row(acc[2], af[c][2], bf[c]);
+                        mfma_row(acc[3], af[c][3], bf[c]);
                     } else {
-                        fetch(std::integral_constant<int, 0>{}, sno, af[n], bf[n]);
+                        mfma_row(acc[1], af[c][1], bf[c]);
                     }
-                    mfma_row(acc[2], af[c][2], bf[c]);
-                    mfma_row(acc[3], af[c][3], bf[c]);
                 }
 #ifdef GZ2_STEP_STAMPS      // diagnostic: cycles per k-step position, summed over the chunks
                 {
@@ -1013,14 +1072,20 @@ __global__ __launch_bounds__(NT * KG, KG == 1 ? Cfg::OCC : 2) void igemm2_kernel
             kstep(std::integral_constant<int, 5>{});
             kstep(std::integral_constant<int, 6>{});
             kstep(std::integral_constant<int, 7>{});
+            if constexpr (STEPS == 12) {
+                kstep(std::integral_constant<int, 8>{});
+                kstep(std::integral_constant<int, 9>{});
+                kstep(std::integral_constant<int, 10>{});
+                kstep(std::integral_constant<int, 11>{});
+            }
             stage = s1;
         }
         };
-        if constexpr (DM) {
-            run_chunks(kc0, min(kend, chunksA), std::false_type{});
-            run_chunks(max(kc0, chunksA), kend, std::true_type{});
+        if constexpr (DM) {          // one loop per mode, in order (a mode switch inside ONE loop spilled accumulators)
+            run_chunks(kc0, min(kend, al.bound[0]), std::integral_constant<int, 0>{});
+            run_chunks(max(kc0, al.bound[0]), kend, std::integral_constant<int, 1>{});
         } else {
-            run_chunks(kc0, kend, std::false_type{});
+            run_chunks(kc0, kend, std::integral_constant<int, 0>{});
         }
         // drain the LDS-DMA queue; MFMA results must have retired before the epilogue's v_accvgpr_read (the hazard
         // recognizer does not look inside the asm statements)

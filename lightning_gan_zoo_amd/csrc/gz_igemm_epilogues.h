@@ -413,25 +413,23 @@ struct EpiPhaseB {
     }
 };
 
-// Column-phase PAIRS of a stride-2 transposed convolution (round 6, ConvDg5A2 / DgPairB2): the workgroup's columns are
-// (px, channel) -- accumulator block j = 0 holds the even output columns (px = 0) of 32 channels, j = 1 the odd columns
-// of the SAME channels -- and y is the row phase py.  A lane owns a pixel (a, b), so both of its values for a channel
-// are neighbours in the output row: ONE 8-byte store at x = 2b, 32 lanes = 256 contiguous bytes, whole 64-byte lines
-// leave the CU (EpiPhaseB's 4-byte stores at stride 8 filled half of every line and relied on the L2 to merge the
-// other column phase's workgroup -- which, with phases of unequal length ordered longest first, ran much later:
-// 181 MB written for a 67 MB tensor, profiles/r05_traffic_pmc_detail.json).  n_base is in IMAGE columns: tile_n * 128 +
-// wn * 64 (+ j * 32); the split-K finish pass hands over single 32 x 32 blocks (TN = 1): 4-byte stores of that px.
-struct EpiPhasePairB {
+// All four output phases of a stride-2 transposed convolution in the accumulator blocks (round 6, ConvDg5A2): block
+// j = 2 py + px of the SAME 32 channels.  A lane owns pixel (a, b), so its values for a channel are a 2 x 2 patch of the
+// output: two 8-byte stores (rows 2a and 2a + 1 at x = 2b), 32 lanes = 256 contiguous bytes each -- whole 64-byte lines
+// leave the CU.  (EpiPhaseB's 4-byte stores at stride 8 filled half of every line and relied on the L2 to merge the
+// other column phase's workgroup -- which, with phases of unequal length ordered longest first, ran much later: 177 MB
+// written for a 67 MB tensor, profiles/r05_traffic_pmc_detail.json.)  n_base in image columns: tile_n * 128 (+ j * 32
+// from the split-K finish pass: single 4-byte stores of that phase).
+struct EpiPhaseQuadB {
     static constexpr bool SWAP = true;
     using Params = typename EpiPhase<2>::Params;
     template <int TM, int TN>
     __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
                                                  int n_base, int lane, int y, int z) {
-        static_assert(TN == 1 || TN == 2, "px pair or one px block");
+        static_assert(TN == 1 || TN == 4, "all four phases or one phase block");
         const int col_l = lane & 31, half = lane >> 5;
-        const int py = y;
-        const int chan_base = (n_base >> 7) * 64 + ((n_base & 127) >> 6) * 32;
-        const int px1 = TN == 1 ? ((n_base & 63) >> 5) : 0;
+        const int chan_base = (n_base >> 7) * 32;
+        const int j1 = TN == 1 ? ((n_base & 127) >> 5) : 0;
         const uint32_t chs = (uint32_t)(p.H * p.W) * 4u;                 // bytes between channel planes
         __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.out, (uint32_t)(p.M / (p.AH * p.AW)) * (uint32_t)p.C * chs);
         uint32_t voff[TM];
@@ -442,21 +440,23 @@ struct EpiPhasePairB {
             const uint32_t pix = (uint32_t)m - n * (uint32_t)(p.AH * p.AW);
             const uint32_t a = fdiv(pix, p.div_aw);
             const uint32_t b = pix - a * (uint32_t)p.AW;
-            const uint32_t o = ((n * (uint32_t)p.C + 4u * half) * (uint32_t)p.H + (2 * a + py)) * (uint32_t)p.W + (2 * b + px1);
+            const uint32_t o = ((n * (uint32_t)p.C + 4u * half) * (uint32_t)p.H + (2 * a + (j1 >> 1))) * (uint32_t)p.W + (2 * b + (j1 & 1));
             voff[i] = (m < p.M && chan_base < p.C) ? o * 4u : OOB;
         }
+        const uint32_t row = (uint32_t)p.W * 4u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const uint32_t so = (uint32_t)(chan_base + (r & 3) + 8 * (r >> 2)) * chs;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                if constexpr (TN == 2) {
+                if constexpr (TN == 4) {
                     typedef int v2i __attribute__((ext_vector_type(2)));
-                    const float v0 = acc[i][0][r], v1 = acc[i][1][r];
-                    v2i pr;
-                    pr.x = __builtin_bit_cast(int, v0);
-                    pr.y = __builtin_bit_cast(int, v1);
-                    __builtin_amdgcn_raw_buffer_store_b64(pr, rsrc, voff[i], so, 0);
+                    const float v0 = acc[i][0][r], v1 = acc[i][1][r], v2 = acc[i][2][r], v3 = acc[i][3][r];
+                    v2i top, bot;
+                    top.x = __builtin_bit_cast(int, v0); top.y = __builtin_bit_cast(int, v1);
+                    bot.x = __builtin_bit_cast(int, v2); bot.y = __builtin_bit_cast(int, v3);
+                    __builtin_amdgcn_raw_buffer_store_b64(top, rsrc, voff[i], so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(bot, rsrc, voff[i], so + row, 0);
                 } else {
                     const float v = acc[i][0][r];
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, voff[i], so, 0);

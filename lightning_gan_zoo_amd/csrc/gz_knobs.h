@@ -34,8 +34,7 @@ namespace gz {
     X(bool, no_dg5, "GZ_NO_DG5", false)                     /* 5x5 s2 p2 input gradients: the gather loader (round 5) */ \
     X(int, dg5_wgs, "GZ_DG5_WGS", 512)                      /* ConvDg5A2: workgroups a split launch aims at */        \
     X(int, dg5_min_chunks, "GZ_DG5_MIN_CHUNKS", 24)         /* ... and the shortest reduction piece it accepts */    \
-    X(bool, dg5_split, "GZ_DG5_SPLIT", false)               /* ... also for launches that must cut their reduction (measured: loses to the gather loader there) */ \
-    X(int, dg5_min_units, "GZ_DG5_MIN_UNITS", 4)            /* ... tiles x chunks per CU below which the small tiles keep the launch */ \
+    X(int, dg5_min_units, "GZ_DG5_MIN_UNITS", 80)            /* ... tiles x chunks per CU below which the small tiles keep the launch */ \
     X(int, kg2_min_chunks, "GZ_KG2_MIN_CHUNKS", 32)         /* ... chunks per workgroup at least */                  \
     X(int, tap64_min_chunks, "GZ_TAP64_MIN_CHUNKS", 32)     /* gather-loader launches too small for 256x128 take 256x64 tiles with >= this many chunks per piece (0: off) */ \
     X(int, tile, "GZ_TILE", -1)                             /* 0..3: force the igemm_kernel tile */                  \

@@ -64,7 +64,7 @@ class KernelTimer:
 
 _timer = None
 _TILES = {0: "128x128", 1: "128x64", 2: "128x32", 3: "64x64", 4: "256x256", 5: "256x128", 6: "512x64", 7: "128x256", 8: "256x64",
-          9: "256x(2x64)"}
+          9: "256x(4x32)"}
 
 
 def set_kernel_timer(timer):

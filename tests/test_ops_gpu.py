@@ -76,27 +76,32 @@ def test_conv_family(geom, case):
     assert rel(dw, dw_ref) < TOL
 
 
-@pytest.mark.parametrize("case", [
+DG5_CASES = [
     # (N, K feature channels, C image-side channels, OH = feature rows): M = N * OH * OH pixels per output phase
-    (40, 32, 64, 16),      # shortest reduction (K = 32: 18 / 12 chunks), 40 tiles
-    (37, 208, 64, 8),      # M = 2368: the last tile is ragged; K = 208 (ty rows of 208: chunk rows cross no ty boundary)
-    (3, 64, 128, 32),      # two column tiles (tile_n = 0, 1), rows of 32 pixels
-    (3, 32, 192, 64),      # three column tiles, rows of 64 pixels (four image rows per tile)
-    (64, 128, 64, 16),     # HoloGAN 64x64, D.block1's input gradient at bs 64
+    (40, 32, 64, 16),      # shortest reduction (K = 32: 12 chunks, the mode switch after 8), 40 x 2 tiles
+    (37, 208, 64, 8),      # M = 2368: the last tile is ragged; K = 208 (ty rows of 208: no chunk crosses a ty boundary)
+    (3, 64, 128, 32),      # four column tiles, rows of 32 pixels
+    (3, 32, 96, 64),       # three column tiles (C = 96), rows of 64 pixels (four image rows per tile)
+    (64, 128, 64, 16),     # HoloGAN 64x64, D.block1's input gradient at bs 64 (split)
     (16, 256, 128, 8),     # ... D.block2's shape, 8 x 8 features: a tile spans four samples (split)
     (16, 512, 256, 4),     # ... D.block3's, 4 x 4 features: sixteen samples per tile, long reduction, many slabs
     (8, 128, 64, 32),      # EXT-128 D.block1's shape
-    (1, 1104, 64, 16),     # ONE tile, 69 channel blocks
-    (4, 32, 192, 64),      # unsplit by default: 192 tiles
-    (48, 128, 64, 32),     # unsplit by default: EXT-128 D.block1's shape at bs 48
-])
-def test_transposed_conv_5x5_row_shared_column_phase_pairs(case):
-    """Round 6: the 5x5 s2 p2 input gradient on row-shared LDS rows with both column phases per workgroup (csrc/
-    gz_igemm2.h ConvDg5A2 / DgPairB2, EpiPhasePairB; HoloGAN's critic, reference core/models/hologan_discriminator.py:7-23)
+    (1, 1104, 64, 16),     # ONE pixel tile, 69 channel blocks
+    (64, 256, 128, 16),    # EXT-128 D.block2 at bs 64: default dispatch, unsplit (256 tiles)
+    (64, 512, 256, 8),     # EXT-128 D.block3 at bs 64: default dispatch, split
+]
+
+
+@pytest.mark.parametrize("case", DG5_CASES)
+def test_transposed_conv_5x5_row_shared_four_phases(case):
+    """Round 6: the 5x5 s2 p2 input gradient on row-shared LDS rows with all four output phases per workgroup (csrc/
+    gz_igemm2.h ConvDg5A2 / DgQuadB2, EpiPhaseQuadB; HoloGAN's critic, reference core/models/hologan_discriminator.py:7-23)
     against torch's conv_transpose2d: every row / column phase, image-edge zero columns (shift -1 at b = 0, +1 at b = AW
-    - 1), top / bottom rows, ragged last tile, one to three column tiles, unsplit and split launches (the finish pass's
-    single-block store path); bit-for-bit repeatable; the packed image is the tap-major one the gather loader reads, so
-    an activation (which the new kernel does not take) must give the gather loader's result on the same pack."""
+    - 1), top / bottom rows, ragged last tile, one to eight column tiles, both chunk modes, unsplit and split launches
+    (the finish pass's single-block store path); bit-for-bit repeatable; the packed image is the tap-major one the gather
+    loader reads, so an activation (which this kernel does not take) must give the gather loader's result on the same
+    pack.  By default only launches with >= 80 chunk-tiles per CU take this kernel (it loses to the gather loader below
+    that): the small cases run in test_..._small_shapes' child process (GZ_DG5_MIN_UNITS=0)."""
     import ctypes
     F = _F()
     from lightning_gan_zoo_amd._lib import lib
@@ -105,13 +110,12 @@ def test_transposed_conv_5x5_row_shared_column_phase_pairs(case):
     text = ctypes.create_string_buffer(256)
     lib.gz_conv2d_plan(1, N, C, H, H, K, OH, OH, 5, 5, 2, 2, text, 256)
     if b"ConvDg5A2" not in text.value:
-        # by default only launches that need no cut of their reduction take this kernel (it loses to the gather
-        # loader on the others); the split forms run in test_..._split_forms' child process (GZ_DG5_SPLIT=1)
-        assert not os.environ.get("GZ_RUN_DG5_SPLIT_CASES"), text.value
-        pytest.skip("split launch: covered by the GZ_DG5_SPLIT=1 child process")
+        assert not os.environ.get("GZ_RUN_DG5_SMALL_CASES"), text.value
+        pytest.skip("little work per CU: the gather loader keeps it; covered by the GZ_DG5_MIN_UNITS=0 child process")
     g = F.Geom(5, 5, 2, 2)
     gy = rnd(N, K, OH, OH, seed=61)
     w = rnd(K, C, 5, 5, seed=62, scale=0.05)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
     ref = TF.conv_transpose2d(gy, w, None, 2, 2, output_padding=1)
     gyd, wd = gy.cuda(), w.cuda()
     out = F._conv_dgrad_raw(gyd, wd, None, g, (H, H), F.ACT_NONE, 0.0)
@@ -130,15 +134,14 @@ def test_transposed_conv_5x5_row_shared_column_phase_pairs(case):
     assert rel(relu, torch.relu(ref)) < TOL
 
 
-def test_transposed_conv_5x5_row_shared_split_forms():
-    """The same cases with GZ_DG5_SPLIT=1 (an experiment switch, read once per process: hence a child process): every
-    launch takes the row-shared kernel, the ones that cut their reduction through slabs + the finish pass's
-    single-block store path included."""
+def test_transposed_conv_5x5_row_shared_small_shapes():
+    """The same cases with GZ_DG5_MIN_UNITS=0 (an experiment switch, read once per process: hence a child process): every
+    case takes the row-shared kernel, whatever its size."""
     import subprocess
     import sys
-    env = dict(os.environ, GZ_EXPERIMENTS="1", GZ_DG5_SPLIT="1", GZ_RUN_DG5_SPLIT_CASES="1")
+    env = dict(os.environ, GZ_EXPERIMENTS="1", GZ_DG5_MIN_UNITS="0", GZ_RUN_DG5_SMALL_CASES="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k",
-                        "test_transposed_conv_5x5_row_shared_column_phase_pairs"], env=env, stdout=subprocess.PIPE,
+                        "test_transposed_conv_5x5_row_shared_four_phases"], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout and "skipped" not in r.stdout, r.stdout[-3000:]
 
@@ -1485,7 +1488,7 @@ def test_igemm2_tap_major_transposed_conv_matches_torch(case):
     N, C, H, K = case
     geom = F.Geom(5, 5, 2, 2)
     tile = lib.gz_conv2d_tile(1, N, C, H, H, K, H // 2, H // 2, 5, 5, 2)
-    assert F._TILES[tile] == ("256x(2x64)" if case == (256, 128, 32, 128) else "256x128"), F._TILES[tile]
+    assert F._TILES[tile] == ("256x(4x32)" if case in ((256, 128, 32, 128), (64, 128, 32, 256), (64, 256, 16, 512)) else "256x128"), F._TILES[tile]
     gy = rnd(N, K, H // 2, H // 2, seed=61)
     w = rnd(K, C, 5, 5, seed=62, scale=0.05)
     torch.set_num_threads(min(16, torch.get_num_threads()))

@@ -22,8 +22,9 @@ def label_of(name):
     m = re.search(r"igemm_kernel<gz::TileCfg<(\d+), (\d+), (\d+), (\d+)>, gz::(\w+)<", name)
     if not m:
         # round 3: igemm2_kernel / igemm2r_kernel<gz::TileCfg2<WM, WN, TN, OCC>, loader...> (TM = 4)
-        m2 = re.search(r"igemm2r?_kernel<gz::TileCfg2<(\d+), (\d+), (\d+), (\d+)>, gz::(\w+)<", name)
-        mw = re.search(r"igemm2w_kernel<gz::TileCfg2<(\d+), (\d+), (\d+), (\d+)>, ", name)
+        # (round 6: TileCfg2 has a fifth argument, TM, printed as ", 4>" / ", 2>")
+        m2 = re.search(r"igemm2r?_kernel<gz::TileCfg2<(\d+), (\d+), (\d+), (\d+)(?:, \d+)?>, gz::(\w+)<", name)
+        mw = re.search(r"igemm2w_kernel<gz::TileCfg2<(\d+), (\d+), (\d+), (\d+)(?:, \d+)?>, ", name)
         if mw:        # weight gradient with both operands by LDS-DMA: no loader types in the name
             return "igemm<Wg,%dx%d>" % (int(mw.group(1)) * 128, int(mw.group(2)) * int(mw.group(3)) * 32)
         if not m2:
@@ -42,7 +43,7 @@ def label_of(name):
     else:
         return None
     if loader == "ConvDg5A2":          # (round 6) 256 pixels x (2 column phases x 64 channels): bench.py's label
-        return "igemm<Dg,256x(2x64)>"
+        return "igemm<Dg,256x(4x32)>"
     return "igemm<%s,%dx%d>" % (op, wm * tm * 32, wn * tn * 32)
 
 
