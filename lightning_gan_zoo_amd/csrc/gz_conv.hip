@@ -723,6 +723,33 @@ static int run_fwd_any(const float* x, const float* wp, const float* bias, float
     return launch_igemm<Cfg, AL, BL, EpiNCHW>(pa, pb, pe, M, s.K, Kt, 1, splits, st, slab);
 }
 
+// round 6: the run-time geometries on the igemm2 skeleton (ConvTapAnyA2: 4-byte LDS-DMA gather, 16 channels at one tap
+// per chunk; EpiNCHWBiasAct: lean stores with bias + ReLU) for launches that fill the chip unsplit -- most of InceptionV3
+// at the evaluation batch.  64-column tiles when the output channels are a multiple of 64 but not of 128 (192, 320, 448).
+template <class Cfg>
+static int run_fwd_any2(const float* x, const float* wp, const float* bias, float* y, const ConvShape& s, const AnyGeom& g,
+                        int act, float slope, hipStream_t st) {
+    using AL = ConvTapAnyA2<Cfg::BM>;
+    using BL = MContigB2<Cfg::BN>;
+    typename AL::Params pa{x, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW), g.KH, g.KW, g.SH, g.SW, g.PH, g.PW};
+    const int M = s.N * s.OH * s.OW;
+    EpiNCHW::Params pe{y, M, s.K, s.OH * s.OW, make_fastdiv(s.OH * s.OW), bias, act, slope, nullptr};
+    const int Kt = g.KH * g.KW * round_bk(s.C);
+    typename BL::Params pb{wp, Kt, round4(s.K), round4(s.K), 0};
+    return launch_igemm2<Cfg, AL, BL, EpiNCHWBiasAct>(pa, pb, pe, M, s.K, Kt, 1, 1, st);
+}
+// 0: not applicable; 64: the tile's column count (256x64 tiles, three workgroups per CU: the 256x128 instantiation with
+// the bias + ReLU epilogue needed 256 registers + 180 bytes of scratch and was not kept)
+static int fwd_any2_cols(const ConvShape& s, const AnyGeom& g, const float* bias, int act) {
+    if (knobs().no_igemm2 || knobs().no_any2 || !bias || !(act == ACT_NONE || act == ACT_RELU)) return 0;
+    // (output channels: any multiple of 16 from 48 up -- a ragged last column tile stores through EpiNCHW's element-wise
+    // path: 80, 96 and 48 of InceptionV3 fill 63-75 % of their last tile and still beat the 64x64 igemm_kernel tiles)
+    if (s.C < BK || (s.K & 15) || s.K < 48 || g.KH * g.KW * (round_bk(s.C) / BK) < 8) return 0;
+    const long long M = (long long)s.N * s.OH * s.OW;
+    const long long t64 = ((M + 255) / 256) * ((s.K + 63) / 64);
+    return t64 >= cus() * 7 / 8 ? 64 : 0;
+}
+
 static SplitPlan fwd_any_plan(const ConvShape& s, const AnyGeom& g) {
     long long M = (long long)s.N * s.OH * s.OW;
     return plan_split(M, s.K, g.KH * g.KW * round_bk(s.C), 1, pick_tile(M, s.K, 1));
@@ -2942,6 +2969,7 @@ int gz_conv2d_fwd_any(const float* x, const float* wpack, const float* bias, flo
     if (!any_shape_ok(s, g)) return GZ_ERR_BAD_SHAPE;
     if ((long long)N * C * H * W * 4 >= (1ll << 31) || (long long)N * K * OH * OW * 4 >= (1ll << 31)) return GZ_ERR_TOO_LARGE;
     long long M = (long long)N * OH * OW;
+    if (fwd_any2_cols(s, g, bias, act) == 64) return run_fwd_any2<Cfg256x64>(x, wpack, bias, y, s, g, act, slope, stream);
     SplitPlan sp = fwd_any_plan(s, g);
     if (sp.splits > 1 && (!workspace || ws_bytes < split_bytes(sp, M, K, KH * KW * round_bk(C), 1)))
         sp = SplitPlan{pick_tile(M, K, 1), 1};

@@ -237,6 +237,72 @@ struct ConvTapA2 {
     }
 };
 
+// ConvTapA2 with the geometry at RUN time (round 6: the evaluation path's InceptionV3 -- 1x7 / 7x1 / 3x3 / 5x5 / 1x1,
+// strides 1 and 2, asymmetric padding; reference core/submodules/gan_stability/metrics/inception.py): the same chunk =
+// (tap, 16 channels) gather, the same pieces; only the per-tap validity and scalar offset use run-time KW / strides /
+// paddings -- evaluated once per tap, not per chunk.
+template <int BM>
+struct ConvTapAnyA2 {
+    static constexpr bool TAPGATHER = true;
+    using Params = typename ConvFwdALoaderTapAny<BM>::Params;
+    static constexpr int LD = BM, ROWS = BK;
+    static constexpr int G = BM / 64;                      // 64-pixel groups per LDS row
+    static constexpr int PIECES = BK * G / 4;              // per wavefront and chunk: its 4 channel rows x G groups
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t vbase[G], veff[G];
+    int iy0[G], ix0[G];
+    int wave, C, H, W, HW, KW, cblocks, last_tap, last_kc, cb;
+    uint32_t tap_soff;
+    __device__ __forceinline__ void init(const Params& p, int tile, int y, int tid) {
+        const ConvShape& s = p.s;
+        const uint32_t shift = (uint32_t)(p.PH * s.W + p.PW) * 4u;
+        rsrc = make_rsrc(reinterpret_cast<const char*>(p.x) - shift, (uint32_t)s.N * s.C * s.H * s.W * 4u + shift);
+        const int lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        C = s.C; H = s.H; W = s.W; HW = s.H * s.W; KW = p.KW;
+        cblocks = round_bk(s.C) / BK;
+        last_tap = -1; last_kc = -1; cb = 0; tap_soff = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint32_t m = (uint32_t)tile * BM + g * 64 + lane;
+            const bool m_ok = m < (uint32_t)s.N * s.OH * s.OW;
+            const uint32_t n = fdiv(m, p.div_ohw);
+            const uint32_t pix = m - n * (uint32_t)(s.OH * s.OW);
+            const uint32_t oy = fdiv(pix, p.div_ow);
+            const uint32_t ox = pix - oy * (uint32_t)s.OW;
+            iy0[g] = m_ok ? (int)oy * p.SH - p.PH : -(1 << 20);      // rows past M: every tap out of range
+            ix0[g] = (int)ox * p.SW - p.PW;
+            vbase[g] = (n * (uint32_t)(s.C * HW) + (uint32_t)((iy0[g] + p.PH) * W + (ix0[g] + p.PW))) * 4u;   // shifted base
+            veff[g] = OOB;
+        }
+    }
+    __device__ __forceinline__ void issue_piece(int kc, float* stage, int p, bool live) {
+        if (p == 0) {
+            int tap = last_tap;
+            if (kc == last_kc + 1 && last_kc >= 0) {
+                cb += BK;
+                if (cb >= cblocks * BK) { cb = 0; ++tap; }
+            } else {
+                tap = kc / cblocks;
+                cb = (kc - tap * cblocks) * BK;
+            }
+            last_kc = kc;
+            if (tap != last_tap) {
+                last_tap = tap;
+                const int dy = tap / KW, dx = tap - dy * KW;
+                tap_soff = (uint32_t)(dy * W + dx) * 4u;
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    veff[g] = ((unsigned)(iy0[g] + dy) < (unsigned)H && (unsigned)(ix0[g] + dx) < (unsigned)W) ? vbase[g] : OOB;
+            }
+        }
+        const int row = wave * 4 + p / G, g = p % G;
+        const int c = cb + row;
+        bload_lds4(rsrc, stage + row * LD + g * 64, veff[g],
+                   (live && c < C) ? (uint32_t)c * (uint32_t)HW * 4u + tap_soff : SOFF_OOB);
+    }
+};
+
 // The same gather for the TRANSPOSED convolution, phase (py, px), tap-major (ConvDgALoaderTap's reduction order and
 // pack_dgrad_tap's weight rows): chunk = 16 feature channels at one of the phase's ny x nx taps,
 // A[k = (tap, ko)][m = (n, a, b)] = y[n][ko][oy0 - ty][ox0 - tx].  Phases have their own chunk counts.

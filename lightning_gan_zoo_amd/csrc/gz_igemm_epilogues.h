@@ -362,6 +362,50 @@ struct EpiNCHWB {
     }
 };
 
+// The lean NCHW store WITH per-channel bias and ReLU (round 6: the evaluation path -- BatchNorm folded into weights +
+// bias, then ReLU; csrc/gz_conv.hip run_fwd_any2).  A type of its own: adding bias / activation to EpiNCHWB's fast path
+// made EVERY igemm2 instantiation spill (round 4).  Channel blocks outside the tensor take EpiNCHW's element-wise path.
+struct EpiNCHWBiasAct {
+    static constexpr bool SWAP = true;
+    using Params = EpiNCHW::Params;
+    template <int TM, int TN>
+    __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
+                                                 int n_base, int lane, int y, int z) {
+        const bool fast = p.bias && (p.act == ACT_NONE || p.act == ACT_RELU) && n_base + TN * 32 <= p.CH;   // wave-uniform
+        if (!fast) {
+            EpiNCHW::template store<TM, TN>(p, acc, m_base, n_base, lane, y, z);
+            return;
+        }
+        const int col_l = lane & 31, half = lane >> 5;
+        const uint32_t chs = (uint32_t)p.HW * 4u;
+        __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.out, (uint32_t)(p.M / p.HW) * (uint32_t)p.CH * chs);
+        uint32_t voff[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m_base + i * 32 + col_l;
+            const uint32_t n = fdiv((uint32_t)m, p.div_hw);
+            const uint32_t pix = (uint32_t)m - n * (uint32_t)p.HW;
+            voff[i] = m < p.M ? ((n * (uint32_t)p.CH + 4u * half) * (uint32_t)p.HW + pix) * 4u : OOB;
+        }
+        const uint32_t soff = (uint32_t)n_base * chs;
+        const float floor_v = p.act == ACT_RELU ? 0.f : -3.402823466e38f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int chl = j * 32 + (r & 3) + 8 * (r >> 2);
+                const uint32_t so = soff + (uint32_t)chl * chs;
+                const float bv = p.bias[n_base + chl + 4 * half];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float v = fmaxf(acc[i][j][r] + bv, floor_v);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc, voff[i], so, 0);
+                }
+            }
+        }
+    }
+};
+
 // EpiPhase with a lean store path for the igemm2 skeleton, where a workgroup's epilogue is NOT hidden behind three
 // other resident workgroups: when there is no bias / activation and the wavefront's channel block lies inside the
 // tensor, an accumulator goes out as  v_accvgpr_read + buffer_store  with a per-lane byte offset computed once per

@@ -146,7 +146,11 @@ def test_state_dict_layout_is_torchvisions():
     (2, 3, 75, 75, 32, 3, 3, 2, 2, 0, 0), (2, 32, 37, 37, 32, 3, 3, 1, 1, 0, 0), (2, 48, 35, 35, 64, 5, 5, 1, 1, 2, 2),
     (2, 128, 17, 17, 128, 1, 7, 1, 1, 0, 3), (2, 160, 17, 17, 192, 7, 1, 1, 1, 3, 0),
     (3, 384, 8, 8, 384, 1, 3, 1, 1, 0, 1), (3, 384, 8, 8, 384, 3, 1, 1, 1, 1, 0), (2, 288, 35, 35, 384, 3, 3, 2, 2, 0, 0),
-    (1, 2048, 8, 8, 320, 1, 1, 1, 1, 0, 0), (2, 20, 13, 9, 7, 2, 4, 2, 1, 1, 2), (16, 192, 17, 17, 192, 3, 3, 2, 2, 0, 0)])
+    (1, 2048, 8, 8, 320, 1, 1, 1, 1, 0, 0), (2, 20, 13, 9, 7, 2, 4, 2, 1, 1, 2), (16, 192, 17, 17, 192, 3, 3, 2, 2, 0, 0),
+    # round 6: launches that fill the chip with 256x64 tiles take the igemm2 skeleton (ConvTapAnyA2 + EpiNCHWBiasAct):
+    # 1x7 / 7x1 with asymmetric padding, 5x5 p2 on 48 channels (three channel blocks), 3x3 stride 2, 1x1; ragged last tiles
+    (72, 128, 17, 17, 192, 1, 7, 1, 1, 0, 3), (72, 160, 17, 17, 192, 7, 1, 1, 1, 3, 0), (48, 48, 35, 35, 64, 5, 5, 1, 1, 2, 2),
+    (64, 288, 35, 35, 384, 3, 3, 2, 2, 0, 0), (96, 256, 17, 17, 192, 1, 1, 1, 1, 0, 0), (40, 64, 33, 37, 128, 3, 3, 1, 1, 1, 1)])
 def test_conv2d_fwd_any(case):
     from lightning_gan_zoo_amd import functional as F
     from lightning_gan_zoo_amd._lib import check, lib
@@ -166,6 +170,14 @@ def test_conv2d_fwd_any(case):
     check(lib.gz_conv2d_fwd_any(F._p(xd), F._p(wp), F._p(bd), F._p(y), F._p(ws), nb, N, C, H, W, K, OH, OW, KH, KW, SH, SW,
                                 PH, PW, F.ACT_RELU, 0.0, F._stream()), "fwd_any")
     assert rel(y, ref) < TOL
+    if N >= 40:          # (the igemm2 cases) also without the activation, and repeatable bit for bit
+        y2 = torch.empty_like(y)
+        check(lib.gz_conv2d_fwd_any(F._p(xd), F._p(wp), F._p(bd), F._p(y2), F._p(ws), nb, N, C, H, W, K, OH, OW, KH, KW, SH,
+                                    SW, PH, PW, F.ACT_RELU, 0.0, F._stream()), "fwd_any")
+        assert torch.equal(y, y2)
+        check(lib.gz_conv2d_fwd_any(F._p(xd), F._p(wp), F._p(bd), F._p(y2), F._p(ws), nb, N, C, H, W, K, OH, OW, KH, KW, SH,
+                                    SW, PH, PW, F.ACT_NONE, 0.0, F._stream()), "fwd_any")
+        assert rel(y2, TF.conv2d(x, w, b, (SH, SW), (PH, PW))) < TOL
 
 
 @pytest.mark.gpu
@@ -288,3 +300,20 @@ def test_fid_end_to_end_with_the_published_weight_file():
     assert np.isfinite(out["fid"]) and out["fid"] > 0 and np.isfinite(out["kid"])
     same = E.fid_from_weight_file(module, None, weights=path, n_samples=64, n_subsets=4)      # generated vs generated
     assert abs(same["fid"]) < 1e-3 * max(1.0, out["fid"])
+
+
+@pytest.mark.gpu
+def test_inception_features_do_not_depend_on_the_batch_size():
+    """Round 6: at the evaluation batch most convolutions take the igemm2 skeleton (ConvTapAnyA2 + EpiNCHWBiasAct) and the
+    pooling takes the plane-per-workgroup kernel; at batch 2 -- the size of the reference-fixture test above -- they take
+    the round-5 kernels.  Same seeded weights, same images: the 2048-d pool features of a batch of 96 must equal those of
+    the same images pushed through two at a time (1e-3; observed ~1e-6)."""
+    from lightning_gan_zoo_amd.inception import FIDInceptionV3
+    seed, _ = reference_features()
+    net = FIDInceptionV3()
+    net.load_state_dict(seeded_state(net, seed))
+    net = net.cuda()
+    x = torch.rand(96, 3, 64, 64, generator=torch.Generator().manual_seed(11)).cuda()
+    big = net(x)
+    small = torch.cat([net(x[i:i + 2]) for i in range(0, 96, 2)])
+    assert big.shape == (96, 2048) and rel(big, small) < TOL, rel(big, small)

@@ -17,5 +17,7 @@ for spec in "dc_gan_bs128:--batch 128:2" "hologan_ext128_bs64:--expt hologan --b
   [ -n "$kt" ] && python3 tools/gap_digest.py $kt "" $cyc 13 > gpurun_out/${tag}_gaps_${key}_gradsync_w1.txt 2>&1
 done
 OTHERS=1 bash tools/pmc_r05.sh $tag > /dev/null 2>&1
+# the bench line reads profiles/traffic.json: hand it this call's PMC table (stamped with the sources' digest) first
+cp gpurun_out/${tag}_traffic.json profiles/traffic.json
 python3 bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
 ls gpurun_out | grep "^${tag}_" | head -60
