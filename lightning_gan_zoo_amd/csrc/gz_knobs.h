@@ -32,6 +32,7 @@ namespace gz {
     X(bool, no_tile64, "GZ_NO_TILE64", false)               /* round 4's 256x64 igemm2 tile off */                   \
     X(bool, no_kg2, "GZ_NO_KG2", false)                     /* round 5's two wave groups per workgroup off */        \
     X(bool, no_pool_plane, "GZ_NO_POOL_PLANE", false)       /* evaluation path: the flat pooling kernel (round 5) */        \
+    X(bool, no_pool_group, "GZ_NO_POOL_GROUP", false)       /* evaluation path: no compile-time-window pooling */           \
     X(bool, no_any2, "GZ_NO_ANY2", false)                   /* evaluation path: run-time geometries on igemm_kernel only (round 5) */ \
     X(bool, no_dg5, "GZ_NO_DG5", false)                     /* 5x5 s2 p2 input gradients: the gather loader (round 5) */ \
     X(int, dg5_wgs, "GZ_DG5_WGS", 512)                      /* ConvDg5A2: workgroups a split launch aims at */        \

@@ -189,6 +189,23 @@ def test_pool_and_resize():
     assert rel(I._pool(xd, 3, 1, 1, I.MAX), TF.max_pool2d(x, 3, 1, 1)) < 1e-6
     assert rel(I._pool(xd, 3, 1, 1, I.AVG_NOPAD), TF.avg_pool2d(x, 3, 1, 1, count_include_pad=False)) < 1e-6
     assert rel(I._pool(xd, 3, 1, 1, I.AVG), TF.avg_pool2d(x, 3, 1, 1)) < 1e-6
+    # the compile-time 3 x 3 windows on groups of whole planes (round 6): InceptionV3's plane sizes, plane counts that
+    # leave a ragged last group, bit-equal to torch (same summation order; max is exact)
+    for (n, c, h, w) in ((2, 5, 35, 35), (3, 11, 17, 17), (2, 37, 8, 8), (1, 3, 71, 71), (5, 1, 3, 3), (2, 3, 9, 40)):
+        t = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(h))
+        td = t.cuda()
+        assert torch.equal(I._pool(td, 3, 2, 0, I.MAX).cpu(), TF.max_pool2d(t, 3, 2))
+        assert torch.equal(I._pool(td, 3, 1, 1, I.MAX).cpu(), TF.max_pool2d(t, 3, 1, 1))
+        assert rel(I._pool(td, 3, 1, 1, I.AVG_NOPAD), TF.avg_pool2d(t, 3, 1, 1, count_include_pad=False)) < 1e-6
+        assert rel(I._pool(td, 3, 1, 1, I.AVG), TF.avg_pool2d(t, 3, 1, 1)) < 1e-6
+        assert rel(I._pool(td, 3, 2, 0, I.AVG), TF.avg_pool2d(t, 3, 2)) < 1e-6
+    # planes beyond one LDS image go by bands of eight output rows (147 x 147 and a ragged 100 x 131)
+    for (n, c, h, w) in ((1, 3, 147, 147), (2, 2, 100, 131)):
+        t = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(h))
+        assert torch.equal(I._pool(t.cuda(), 3, 2, 0, I.MAX).cpu(), TF.max_pool2d(t, 3, 2))
+        assert rel(I._pool(t.cuda(), 3, 2, 0, I.AVG), TF.avg_pool2d(t, 3, 2)) < 1e-6
+    big = torch.randn(3, 41, 8, 8, generator=torch.Generator().manual_seed(3))          # 16 lanes per 8 x 8 plane
+    assert rel(I._pool(big.cuda(), 8, 1, 0, I.AVG), TF.adaptive_avg_pool2d(big, 1)) < 1e-6
     sq = torch.randn(2, 7, 8, 8, generator=torch.Generator().manual_seed(2))
     assert rel(I._pool(sq.cuda(), 8, 1, 0, I.AVG), TF.adaptive_avg_pool2d(sq, 1)) < 1e-6
     from lightning_gan_zoo_amd._lib import check, lib
