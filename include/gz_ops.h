@@ -230,6 +230,13 @@ size_t gz_conv2d_fwd_any_workspace_bytes(int N, int C, int H, int W, int K, int 
 int gz_conv2d_fwd_any(const float* x, const float* wpack, const float* bias, float* y, float* workspace,
                       size_t ws_bytes, int N, int C, int H, int W, int K, int OH, int OW, int KH, int KW, int SH, int SW,
                       int PH, int PW, int act, float slope, hipStream_t stream);
+/* The same convolution written into a channel slice of a concatenated tensor (InceptionV3's torch.cat of branch
+ * outputs, inception.py:92-94 etc.): y points at the slice's first channel inside image 0, images are
+ * y_image_channels * OH * OW floats apart.  Only the LDS-DMA launch takes a destination stride: GZ_ERR_UNSUPPORTED (-2)
+ * when the shape runs elsewhere -- the caller then convolves into a temporary and copies. */
+int gz_conv2d_fwd_any_into(const float* x, const float* wpack, const float* bias, float* y, int y_image_channels, int N,
+                           int C, int H, int W, int K, int OH, int OW, int KH, int KW, int SH, int SW, int PH, int PW,
+                           int act, float slope, hipStream_t stream);
 /* square-window pooling over `planes` = N*C images; mode 0 max, 1 average with count_include_pad=False (the FID
  * network's patched pools), 2 average over KS*KS.  nn.AdaptiveAvgPool2d(1) = KS = H, S = 1, P = 0, mode 2. */
 int gz_pool2d(const float* x, float* y, long long planes, int H, int W, int OH, int OW, int KS, int S, int P, int mode,

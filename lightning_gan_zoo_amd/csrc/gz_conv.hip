@@ -728,12 +728,12 @@ static int run_fwd_any(const float* x, const float* wp, const float* bias, float
 // at the evaluation batch.  64-column tiles when the output channels are a multiple of 64 but not of 128 (192, 320, 448).
 template <class Cfg>
 static int run_fwd_any2(const float* x, const float* wp, const float* bias, float* y, const ConvShape& s, const AnyGeom& g,
-                        int act, float slope, hipStream_t st) {
+                        int act, float slope, hipStream_t st, int y_image_channels) {
     using AL = ConvTapAnyA2<Cfg::BM>;
     using BL = MContigB2<Cfg::BN>;
     typename AL::Params pa{x, s, make_fastdiv(s.OH * s.OW), make_fastdiv(s.OW), g.KH, g.KW, g.SH, g.SW, g.PH, g.PW};
     const int M = s.N * s.OH * s.OW;
-    EpiNCHW::Params pe{y, M, s.K, s.OH * s.OW, make_fastdiv(s.OH * s.OW), bias, act, slope, nullptr};
+    EpiNCHWBiasAct::Params pe{y, M, s.K, s.OH * s.OW, make_fastdiv(s.OH * s.OW), bias, act, slope, y_image_channels};
     const int Kt = g.KH * g.KW * round_bk(s.C);
     typename BL::Params pb{wp, Kt, round4(s.K), round4(s.K), 0};
     return launch_igemm2<Cfg, AL, BL, EpiNCHWBiasAct>(pa, pb, pe, M, s.K, Kt, 1, 1, st);
@@ -2969,7 +2969,7 @@ int gz_conv2d_fwd_any(const float* x, const float* wpack, const float* bias, flo
     if (!any_shape_ok(s, g)) return GZ_ERR_BAD_SHAPE;
     if ((long long)N * C * H * W * 4 >= (1ll << 31) || (long long)N * K * OH * OW * 4 >= (1ll << 31)) return GZ_ERR_TOO_LARGE;
     long long M = (long long)N * OH * OW;
-    if (fwd_any2_cols(s, g, bias, act) == 64) return run_fwd_any2<Cfg256x64>(x, wpack, bias, y, s, g, act, slope, stream);
+    if (fwd_any2_cols(s, g, bias, act) == 64) return run_fwd_any2<Cfg256x64>(x, wpack, bias, y, s, g, act, slope, stream, K);
     SplitPlan sp = fwd_any_plan(s, g);
     if (sp.splits > 1 && (!workspace || ws_bytes < split_bytes(sp, M, K, KH * KW * round_bk(C), 1)))
         sp = SplitPlan{pick_tile(M, K, 1), 1};
@@ -2980,6 +2980,19 @@ int gz_conv2d_fwd_any(const float* x, const float* wpack, const float* bias, flo
         case T128x32: return run_fwd_any<Cfg128x32>(x, wpack, bias, y, s, g, act, slope, stream, sp.splits, slab);
         default: return run_fwd_any<Cfg64x64>(x, wpack, bias, y, s, g, act, slope, stream, sp.splits, slab);
     }
+}
+
+int gz_conv2d_fwd_any_into(const float* x, const float* wpack, const float* bias, float* y, int y_image_channels, int N,
+                           int C, int H, int W, int K, int OH, int OW, int KH, int KW, int SH, int SW, int PH, int PW,
+                           int act, float slope, hipStream_t stream) {
+    gz::clear_stale_error();
+    ConvShape s{N, C, H, W, K, OH, OW};
+    AnyGeom g{KH, KW, SH, SW, PH, PW};
+    if (!any_shape_ok(s, g) || y_image_channels < K) return GZ_ERR_BAD_SHAPE;
+    if ((long long)N * C * H * W * 4 >= (1ll << 31) || (long long)N * y_image_channels * OH * OW * 4 >= (1ll << 31))
+        return GZ_ERR_TOO_LARGE;
+    if (fwd_any2_cols(s, g, bias, act) != 64) return GZ_ERR_UNSUPPORTED;
+    return run_fwd_any2<Cfg256x64>(x, wpack, bias, y, s, g, act, slope, stream, y_image_channels);
 }
 
 #ifdef GZ2_STAMPS

@@ -367,25 +367,52 @@ struct EpiNCHWB {
 // made EVERY igemm2 instantiation spill (round 4).  Channel blocks outside the tensor take EpiNCHW's element-wise path.
 struct EpiNCHWBiasAct {
     static constexpr bool SWAP = true;
-    using Params = EpiNCHW::Params;
+    struct Params {
+        float* out;              // channel 0 of THIS launch's output inside image 0 of the destination
+        int M, CH, HW;           // M = N*HW rows, CH channels of this launch
+        FastDiv div_hw;
+        const float* bias;
+        int act;
+        float slope;
+        int CHD;                 // channels per image of the destination (>= CH: a channel slice of a concatenation)
+    };
     template <int TM, int TN>
     __device__ __forceinline__ static void store(const Params& p, f32x16 (&acc)[TM][TN], int m_base,
                                                  int n_base, int lane, int y, int z) {
         const bool fast = p.bias && (p.act == ACT_NONE || p.act == ACT_RELU) && n_base + TN * 32 <= p.CH;   // wave-uniform
+        const int col_l = lane & 31, half = lane >> 5;
         if (!fast) {
-            EpiNCHW::template store<TM, TN>(p, acc, m_base, n_base, lane, y, z);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m_base + i * 32 + col_l;
+                if (m >= p.M) continue;
+                const uint32_t n = fdiv((uint32_t)m, p.div_hw);
+                const uint32_t pix = (uint32_t)m - n * (uint32_t)p.HW;
+                float* base = p.out + (long long)n * p.CHD * p.HW + pix;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ch = n_base + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (ch < p.CH) {
+                            float bv = p.bias ? p.bias[ch] : 0.f;
+                            base[(long long)ch * p.HW] = act_fwd(acc[i][j][r] + bv, p.act, p.slope);
+                        }
+                    }
+                }
+            }
             return;
         }
-        const int col_l = lane & 31, half = lane >> 5;
         const uint32_t chs = (uint32_t)p.HW * 4u;
-        __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.out, (uint32_t)(p.M / p.HW) * (uint32_t)p.CH * chs);
+        const uint32_t images = (uint32_t)(p.M / p.HW);
+        __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.out, ((images - 1u) * (uint32_t)p.CHD + (uint32_t)p.CH) * chs);
         uint32_t voff[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m_base + i * 32 + col_l;
             const uint32_t n = fdiv((uint32_t)m, p.div_hw);
             const uint32_t pix = (uint32_t)m - n * (uint32_t)p.HW;
-            voff[i] = m < p.M ? ((n * (uint32_t)p.CH + 4u * half) * (uint32_t)p.HW + pix) * 4u : OOB;
+            voff[i] = m < p.M ? ((n * (uint32_t)p.CHD + 4u * half) * (uint32_t)p.HW + pix) * 4u : OOB;
         }
         const uint32_t soff = (uint32_t)n_base * chs;
         const float floor_v = p.act == ACT_RELU ? 0.f : -3.402823466e38f;

@@ -12,6 +12,8 @@ Forward only (evaluation): every convolution is ``gz_conv2d_fwd_any`` (MFMA impl
 in its epilogue; pools and the resize are ``gz_pool2d`` / ``gz_resize_bilinear``.  The nn.Conv2d / nn.BatchNorm2d
 children are parameter holders.
 """
+import ctypes
+
 import numpy as np
 import torch
 from torch import nn
@@ -59,7 +61,14 @@ class BasicConv2d(nn.Module):
         self._folded = (key, wp, b)
         return wp, b
 
-    def forward(self, x):
+    def out_shape(self, x):
+        c = self.conv
+        (KH, KW), (SH, SW), (PH, PW) = c.kernel_size, c.stride, c.padding
+        return (x.shape[0], c.out_channels, (x.shape[2] + 2 * PH - KH) // SH + 1, (x.shape[3] + 2 * PW - KW) // SW + 1)
+
+    def forward(self, x, out=None):
+        """``out``: a channel slice [:, a:b] of a contiguous (N, channels, OH, OW) tensor -- the block's concatenation --
+        to write into instead of a fresh tensor (round 6: the eleven torch.cat of a pass were 3 % of it)."""
         x = F._req(x, "x")
         wp, b = self._fold()
         c = self.conv
@@ -67,14 +76,38 @@ class BasicConv2d(nn.Module):
         K = c.out_channels
         (KH, KW), (SH, SW), (PH, PW) = c.kernel_size, c.stride, c.padding
         OH, OW = (H + 2 * PH - KH) // SH + 1, (W + 2 * PW - KW) // SW + 1
-        y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
         if FLOPS is not None:
             FLOPS[0] += 2.0 * N * OH * OW * K * C * KH * KW
+        if out is not None:
+            assert out.shape == (N, K, OH, OW) and out.stride()[1:] == (OH * OW, OW, 1) and out.stride(0) % (OH * OW) == 0
+            rc = lib.gz_conv2d_fwd_any_into(_p(x), _p(wp), _p(b), ctypes.c_void_p(out.data_ptr()),
+                                            out.stride(0) // (OH * OW), N, C, H, W, K, OH, OW, KH, KW, SH, SW, PH, PW,
+                                            F.ACT_RELU, 0.0, _stream())
+            if rc == 0:
+                return out
+            if rc != -2:                     # (-2: this shape does not run on the launch with a destination stride)
+                check(rc, "conv2d_fwd_any_into")
+        y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.float32)
         ws, nbytes = F._scratch(lib.gz_conv2d_fwd_any_workspace_bytes(N, C, H, W, K, OH, OW, KH, KW, SH, SW, PH, PW),
                                 x.device)
         check(lib.gz_conv2d_fwd_any(_p(x), _p(wp), _p(b), _p(y), _p(ws), nbytes, N, C, H, W, K, OH, OW, KH, KW, SH, SW,
                                     PH, PW, F.ACT_RELU, 0.0, _stream()), "conv2d_fwd_any")
+        if out is not None:
+            out.copy_(y)
+            return out
         return y
+
+
+def _concat(x, OH, OW, parts):
+    """torch.cat(..., 1) of a block's branches without the copy: every branch's last layer writes its channel slice of
+    the result.  parts: [(last BasicConv2d | channel count, fn(out_slice))] in the reference's concatenation order."""
+    chans = [p.conv.out_channels if isinstance(p, BasicConv2d) else int(p) for p, _ in parts]
+    y = torch.empty((x.shape[0], sum(chans), OH, OW), device=x.device, dtype=torch.float32)
+    a = 0
+    for c, (_, fn) in zip(chans, parts):
+        fn(y[:, a:a + c])
+        a += c
+    return y
 
 
 class InceptionA(nn.Module):
@@ -89,9 +122,11 @@ class InceptionA(nn.Module):
         self.branch_pool = BasicConv2d(cin, pool_features, 1)
 
     def forward(self, x):
-        return torch.cat([self.branch1x1(x), self.branch5x5_2(self.branch5x5_1(x)),
-                          self.branch3x3dbl_3(self.branch3x3dbl_2(self.branch3x3dbl_1(x))),
-                          self.branch_pool(_pool(x, 3, 1, 1, AVG_NOPAD))], 1)
+        return _concat(x, x.shape[2], x.shape[3], [
+            (self.branch1x1, lambda o: self.branch1x1(x, o)),
+            (self.branch5x5_2, lambda o: self.branch5x5_2(self.branch5x5_1(x), o)),
+            (self.branch3x3dbl_3, lambda o: self.branch3x3dbl_3(self.branch3x3dbl_2(self.branch3x3dbl_1(x)), o)),
+            (self.branch_pool, lambda o: self.branch_pool(_pool(x, 3, 1, 1, AVG_NOPAD), o))])
 
 
 class InceptionB(nn.Module):
@@ -103,8 +138,10 @@ class InceptionB(nn.Module):
         self.branch3x3dbl_3 = BasicConv2d(96, 96, 3, stride=2)
 
     def forward(self, x):
-        return torch.cat([self.branch3x3(x), self.branch3x3dbl_3(self.branch3x3dbl_2(self.branch3x3dbl_1(x))),
-                          _pool(x, 3, 2, 0, MAX)], 1)
+        return _concat(x, (x.shape[2] - 3) // 2 + 1, (x.shape[3] - 3) // 2 + 1, [
+            (self.branch3x3, lambda o: self.branch3x3(x, o)),
+            (self.branch3x3dbl_3, lambda o: self.branch3x3dbl_3(self.branch3x3dbl_2(self.branch3x3dbl_1(x)), o)),
+            (x.shape[1], lambda o: o.copy_(_pool(x, 3, 2, 0, MAX)))])
 
 
 class InceptionC(nn.Module):
@@ -122,9 +159,12 @@ class InceptionC(nn.Module):
         self.branch_pool = BasicConv2d(cin, 192, 1)
 
     def forward(self, x):
-        b7 = self.branch7x7_3(self.branch7x7_2(self.branch7x7_1(x)))
-        d = self.branch7x7dbl_5(self.branch7x7dbl_4(self.branch7x7dbl_3(self.branch7x7dbl_2(self.branch7x7dbl_1(x)))))
-        return torch.cat([self.branch1x1(x), b7, d, self.branch_pool(_pool(x, 3, 1, 1, AVG_NOPAD))], 1)
+        return _concat(x, x.shape[2], x.shape[3], [
+            (self.branch1x1, lambda o: self.branch1x1(x, o)),
+            (self.branch7x7_3, lambda o: self.branch7x7_3(self.branch7x7_2(self.branch7x7_1(x)), o)),
+            (self.branch7x7dbl_5, lambda o: self.branch7x7dbl_5(self.branch7x7dbl_4(self.branch7x7dbl_3(
+                self.branch7x7dbl_2(self.branch7x7dbl_1(x)))), o)),
+            (self.branch_pool, lambda o: self.branch_pool(_pool(x, 3, 1, 1, AVG_NOPAD), o))])
 
 
 class InceptionD(nn.Module):
@@ -138,8 +178,11 @@ class InceptionD(nn.Module):
         self.branch7x7x3_4 = BasicConv2d(192, 192, 3, stride=2)
 
     def forward(self, x):
-        b7 = self.branch7x7x3_4(self.branch7x7x3_3(self.branch7x7x3_2(self.branch7x7x3_1(x))))
-        return torch.cat([self.branch3x3_2(self.branch3x3_1(x)), b7, _pool(x, 3, 2, 0, MAX)], 1)
+        return _concat(x, (x.shape[2] - 3) // 2 + 1, (x.shape[3] - 3) // 2 + 1, [
+            (self.branch3x3_2, lambda o: self.branch3x3_2(self.branch3x3_1(x), o)),
+            (self.branch7x7x3_4, lambda o: self.branch7x7x3_4(self.branch7x7x3_3(self.branch7x7x3_2(
+                self.branch7x7x3_1(x))), o)),
+            (x.shape[1], lambda o: o.copy_(_pool(x, 3, 2, 0, MAX)))])
 
 
 class InceptionE(nn.Module):
@@ -159,8 +202,12 @@ class InceptionE(nn.Module):
     def forward(self, x):
         b3 = self.branch3x3_1(x)
         d = self.branch3x3dbl_2(self.branch3x3dbl_1(x))
-        return torch.cat([self.branch1x1(x), self.branch3x3_2a(b3), self.branch3x3_2b(b3), self.branch3x3dbl_3a(d),
-                          self.branch3x3dbl_3b(d), self.branch_pool(_pool(x, 3, 1, 1, self.pool_mode))], 1)
+        return _concat(x, x.shape[2], x.shape[3], [
+            (self.branch1x1, lambda o: self.branch1x1(x, o)),
+            (self.branch3x3_2a, lambda o: self.branch3x3_2a(b3, o)), (self.branch3x3_2b, lambda o: self.branch3x3_2b(b3, o)),
+            (self.branch3x3dbl_3a, lambda o: self.branch3x3dbl_3a(d, o)),
+            (self.branch3x3dbl_3b, lambda o: self.branch3x3dbl_3b(d, o)),
+            (self.branch_pool, lambda o: self.branch_pool(_pool(x, 3, 1, 1, self.pool_mode), o))])
 
 
 class FIDInceptionV3(nn.Module):

@@ -178,6 +178,21 @@ def test_conv2d_fwd_any(case):
         check(lib.gz_conv2d_fwd_any(F._p(xd), F._p(wp), F._p(bd), F._p(y2), F._p(ws), nb, N, C, H, W, K, OH, OW, KH, KW, SH,
                                     SW, PH, PW, F.ACT_NONE, 0.0, F._stream()), "fwd_any")
         assert rel(y2, TF.conv2d(x, w, b, (SH, SW), (PH, PW))) < TOL
+        # ... and into a channel slice of a wider tensor (a block's concatenation): the same bits, neighbours untouched
+        import ctypes
+        before, after = 24, 40
+        wide = torch.full((N, before + K + after, OH, OW), 7.0, device="cuda")
+        dst = wide[:, before:before + K]
+        rc = lib.gz_conv2d_fwd_any_into(F._p(xd), F._p(wp), F._p(bd), ctypes.c_void_p(dst.data_ptr()), before + K + after,
+                                        N, C, H, W, K, OH, OW, KH, KW, SH, SW, PH, PW, F.ACT_RELU, 0.0, F._stream())
+        assert rc == 0, rc
+        assert torch.equal(dst, y)
+        assert bool((wide[:, :before] == 7.0).all()) and bool((wide[:, before + K:] == 7.0).all())
+    else:                # launches without a destination stride say so instead of writing a dense tensor into the slice
+        import ctypes
+        rc = lib.gz_conv2d_fwd_any_into(F._p(xd), F._p(wp), F._p(bd), ctypes.c_void_p(y.data_ptr()), K + 8, N, C, H, W, K,
+                                        OH, OW, KH, KW, SH, SW, PH, PW, F.ACT_RELU, 0.0, F._stream())
+        assert rc == -2, rc
 
 
 @pytest.mark.gpu
