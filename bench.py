@@ -77,6 +77,9 @@ def parse_args(argv=None):
                     help="headline configuration only (skip the dc_gan bs128 / wgan_gp / hologan sub-records)")
     ap.add_argument("--sub-steps", type=int, default=10, help="timed optimizer cycles per repetition of a sub-record")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--detail", action="store_true",
+                    help="full sub-configuration records (per-label igemm tables, bucket layouts); the default line keeps "
+                         "them to their numbers so that the whole line fits the ~8 KB of stdout a driver record keeps")
     ap.add_argument("--graph", action="store_true",
                     help="replay each optimizer step from a captured HIP graph (single GPU)")
     ap.add_argument("--fid-samples", type=int, default=50000,
@@ -491,6 +494,36 @@ def gradsync_w1_records(F, args, device, use_timer, out, head_key):
     return recs
 
 
+def compact_record(rec):
+    """A sub-configuration record reduced to its numbers (the default line; ``--detail`` prints the full records, and
+    tools/profile_r06.sh commits that form as profiles/rNN_bench_line.json)."""
+    out = {}
+    if "workload" in rec:
+        w = rec["workload"]
+        cut = w.find(" (Lightning alternation")
+        tail = " (EXT-128: stride-2 extension, not parity-pinned)" if "EXT-128" in w else ""
+        out["workload"] = (w[:cut] + tail) if cut > 0 else w
+    for k in ("value", "unit", "ms_per_step", "ms_per_step_each", "seconds", "finite", "vs_plain", "plain_ms_per_step",
+              "transport", "error"):
+        if k in rec:
+            out[k] = rec[k]
+    r = rec.get("roofline")
+    if r:
+        out["roofline"] = {k: r[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "traffic", "traffic_stale",
+                                             "igemm_share_of_step") if k in r}
+        if "whole_step" in r:
+            out["roofline"]["whole_step"] = {k: r["whole_step"][k] for k in ("achieved", "frac") if k in r["whole_step"]}
+    g = rec.get("grad_exchange")
+    if g:
+        out["grad_exchange"] = {k: g[k] for k in ("buckets", "buckets_from_hooks", "buckets_after_backward",
+                                                  "buckets_deferred_tail") if k in g}
+        ov = g.get("overlap") or {}
+        for k in ("exposed_wait_ms_per_step", "waits_per_step"):
+            if k in ov:
+                out["grad_exchange"][k] = ov[k]
+    return out
+
+
 def run_rank(args):
     import torch
     import torch.distributed as dist
@@ -600,6 +633,10 @@ def run_rank(args):
         if world == 1 and not args.no_cpu_baseline and args.expt == "dc_gan":
             out["cpu_baseline"] = cpu_baseline(128, 12.0)
             out["cpu_baseline"]["bs64"] = cpu_baseline(64, 7.0)        # BASELINE config 1's batch
+        subs = out.pop("sub_configs", None)
+        if subs is not None:              # last in the line: a record that keeps only the tail of stdout keeps these
+            # (N > 1 runs carry three records: full, with per-rank times and the overlap report)
+            out["sub_configs"] = subs if (args.detail or world > 1) else {k: compact_record(v) for k, v in subs.items()}
         print(json.dumps(out), file=result_out, flush=True)
     if dist.is_initialized():
         dist.barrier()

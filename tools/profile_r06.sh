@@ -19,5 +19,5 @@ done
 OTHERS=1 bash tools/pmc_r05.sh $tag > /dev/null 2>&1
 # the bench line reads profiles/traffic.json: hand it this call's PMC table (stamped with the sources' digest) first
 cp gpurun_out/${tag}_traffic.json profiles/traffic.json
-python3 bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
+python3 bench.py --detail > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
 ls gpurun_out | grep "^${tag}_" | head -60
